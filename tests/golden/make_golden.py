@@ -1,0 +1,155 @@
+"""Generates the committed golden vectors by running the UNMODIFIED reference
+(/root/reference, imported through oracle/ref_loader.py with third-party stubs).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+Outputs (committed): tests/golden/{masks,rotary,small,cfg1}.pt
+
+RNG protocol: the reference draws, from the global CPU generator,
+randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
+step; we replay the same calls under the same seed to record the injected values.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader, restate  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def replay_draws(x1, seed):
+    torch.manual_seed(seed)
+    b = x1.shape[0]
+    x0 = torch.randn_like(x1)
+    times = torch.rand((b,), dtype=x1.dtype)
+    frac = torch.zeros((b,)).float().uniform_(0.7, 1.0)
+    rand = torch.zeros_like(frac).float().uniform_(0, 1)
+    return x0, times, frac, rand
+
+
+def build_reference(ref, cfg, state=None, seed=0):
+    torch.manual_seed(seed)
+    vb = ref.VoiceBox(dim=cfg.dim, num_cond_tokens=500, depth=cfg.depth, dim_head=cfg.dim_head,
+                      heads=cfg.heads, condition_on_text=False,
+                      num_register_tokens=cfg.num_register_tokens)
+    wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb)
+    if state is not None:
+        missing = vb.load_state_dict(state, strict=False)
+        # only the non-persistent-free buffer inv_freq may be absent from our recipe dict
+        assert all(k.endswith("rotary_emb.inv_freq") for k in missing.missing_keys), missing
+        assert not missing.unexpected_keys, missing
+    return vb, wrapper
+
+
+def gen_masks(ref):
+    fr = torch.tensor([0.7, 0.85, 0.9999, 1.0, 0.7123, 0.93])
+    rd = torch.tensor([0.0, 0.5, 0.999, 0.3, 0.77, 1.0 - 1e-7])
+    out = {"frac": fr, "rand": rd, "cases": {}}
+    for n in (8, 37, 1024):
+        lengths = (fr * n).long()
+        start = ((n - lengths) * rd).clamp(min=0)
+        out["cases"][n] = ref.mask_from_start_end_indices(n, start, start + lengths)
+    s = torch.tensor([2.9, 0.0, 7.2])
+    e = torch.tensor([5.9, 0.99, 8.0])
+    out["start"], out["end"] = s, e
+    out["start_end_8"] = ref.mask_from_start_end_indices(8, s, e)
+    # the full helper with its own RNG draw, replayed
+    torch.manual_seed(11)
+    out["frac_helper_1024"] = ref.mask_from_frac_lengths(1024, fr)
+    torch.manual_seed(11)
+    out["frac_helper_rand"] = torch.zeros_like(fr).float().uniform_(0, 1)
+    torch.save(out, os.path.join(HERE, "masks.pt"))
+
+
+def gen_rotary(ref):
+    rot = ref.RotaryEmbedding(dim=64)
+    pos = torch.cat((torch.full((16,), -10000, dtype=torch.long), torch.arange(48)))
+    freqs = rot(pos)
+    t = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    torch.save({"positions": pos, "freqs": freqs, "t": t, "rotated": ref.apply_rotary_pos_emb(freqs, t)},
+               os.path.join(HERE, "rotary.pt"))
+
+
+def gen_small(ref):
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    vb, wrapper = build_reference(ref, cfg, seed=0)
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():  # randomise the zero-initialised adaLN projections
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or ".to_beta." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            if name.endswith("_norm.gamma") or name.endswith("final_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+    state = {k: v.detach().clone() for k, v in vb.state_dict().items()}
+    b, n = 2, 40
+    x1 = torch.randn(b, n, cfg.dim, generator=torch.Generator().manual_seed(7))
+    x0, times, frac, rand = replay_draws(x1, seed=99)
+    torch.manual_seed(99)
+    loss = wrapper(x1)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    # padded-batch variant: key-padding / loss mask given
+    mask = torch.ones(b, n, dtype=torch.bool)
+    mask[1, 29:] = False
+    vb.zero_grad()
+    torch.manual_seed(99)
+    loss_m = wrapper(x1, mask=mask)
+    loss_m.backward()
+    grads_m = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    # eval forward (prediction) with an explicit cond / cond_mask
+    vb.eval()
+    cond = torch.randn(b, n, cfg.dim, generator=torch.Generator().manual_seed(8))
+    cmask = torch.zeros(b, n, dtype=torch.bool)
+    cmask[:, 10:30] = True
+    tt = torch.tensor([0.25, 0.8])
+    with torch.no_grad():
+        pred = vb(x1, times=tt, cond_token_ids=None, cond=cond, cond_mask=cmask, cond_drop_prob=0.0)
+        pred_scalar_t = vb(x1, times=torch.tensor(0.5), cond_token_ids=None, cond=cond, cond_drop_prob=0.0)
+    # sampling, steps=3 and steps=5 with the :1289 draw replayed
+    torch.manual_seed(3)
+    y0 = torch.randn_like(cond)
+    torch.manual_seed(3)
+    s3 = wrapper.sample(cond=cond, steps=3)
+    torch.manual_seed(3)
+    s5 = wrapper.sample(cond=cond, steps=5)
+    torch.save(dict(cfg=dict(dim=64, depth=2, heads=2, dim_head=64), state=state, x1=x1, x0=x0, times=times,
+                    frac=frac, rand=rand, loss=loss.detach(), grads=grads, mask=mask, loss_masked=loss_m.detach(),
+                    grads_masked=grads_m, cond=cond, cond_mask=cmask, eval_times=tt, pred=pred,
+                    pred_scalar_t=pred_scalar_t, y0=y0, sample3=s3, sample5=s5),
+               os.path.join(HERE, "small.pt"))
+    print("small: loss", float(loss), "masked", float(loss_m))
+
+
+def gen_cfg1(ref):
+    """BASELINE config 1/2: dim 512, depth 2, heads 16, B=2, N=1024.  Weights by the committed
+    recipe oracle.restate.init_state_dict(seed=0) (too big to commit); only scalars/slices stored."""
+    cfg = restate.Cfg(dim=512, depth=2, heads=16, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=0)
+    vb, wrapper = build_reference(ref, cfg, state=state)
+    x1 = torch.randn(2, 1024, 512, generator=torch.Generator().manual_seed(0))
+    x0, times, frac, rand = replay_draws(x1, seed=1)
+    torch.manual_seed(1)
+    loss = wrapper(x1)
+    loss.backward()
+    gnorm = {k: float(p.grad.norm()) for k, p in vb.named_parameters() if p.grad is not None}
+    gslice = {k: p.grad.flatten()[:16].clone() for k, p in vb.named_parameters() if p.grad is not None}
+    vb.eval()
+    with torch.no_grad():
+        pred = vb(x1, times=torch.tensor(0.37), cond_token_ids=None, cond=x1, cond_drop_prob=0.0)
+    torch.save(dict(loss=loss.detach(), grad_norms=gnorm, grad_slices=gslice, pred_slice=pred[:, :8, :32].clone(),
+                    pred_norm=float(pred.norm()), x0_check=x0[0, 0, :4].clone(), times=times, frac=frac, rand=rand),
+               os.path.join(HERE, "cfg1.pt"))
+    print("cfg1: loss", float(loss))
+
+
+if __name__ == "__main__":
+    ref = ref_loader.load_reference()
+    gen_masks(ref)
+    gen_rotary(ref)
+    gen_small(ref)
+    gen_cfg1(ref)

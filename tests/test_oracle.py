@@ -1,0 +1,100 @@
+"""CPU: the oracle restatement (oracle/restate.py) against the golden vectors the UNMODIFIED
+reference produced (tests/golden/make_golden.py), plus -- when /root/reference is present --
+directly against the reference."""
+import pytest
+import torch
+
+from oracle import restate, ref_loader
+
+
+def _cfg(d):
+    return restate.Cfg(**d)
+
+
+def test_masks_bit_exact(golden):
+    g = golden("masks")
+    for n, expect in g["cases"].items():
+        got = restate.frac_lengths_mask(n, g["frac"], g["rand"])
+        assert torch.equal(got, expect), n
+    assert torch.equal(restate.span_mask(8, g["start"], g["end"]), g["start_end_8"])
+    assert torch.equal(restate.frac_lengths_mask(1024, g["frac"], g["frac_helper_rand"]), g["frac_helper_1024"])
+    # SURVEY 3.4 #5 known answers
+    m = restate.frac_lengths_mask(1024, torch.tensor([0.7, 0.85, 0.9999, 1.0]), torch.zeros(4))
+    assert m.sum(-1).tolist() == [716, 870, 1023, 1024]
+    assert restate.span_mask(8, torch.tensor([2.9]), torch.tensor([5.9]))[0].int().tolist() == [0, 0, 1, 1, 1, 0, 0, 0]
+
+
+def test_rotary_bit_exact(golden):
+    g = golden("rotary")
+    fr = restate.rotary_freqs(g["positions"], 64, 50000.0)
+    assert torch.equal(fr, g["freqs"])
+    assert torch.equal(restate.apply_rotary(fr, g["t"]), g["rotated"])
+
+
+def test_small_model_loss_and_grads(golden):
+    g = golden("small")
+    cfg = _cfg(g["cfg"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    loss = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        got = p[k].grad
+        assert got is not None, k
+        assert torch.allclose(got, ref, rtol=2e-3, atol=2e-6), (k, float((got - ref).abs().max()))
+    # padded batch
+    p2 = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    loss_m = restate.cfm_loss(p2, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask=g["mask"])
+    assert abs(float(loss_m) - float(g["loss_masked"])) < 1e-5
+    loss_m.backward()
+    for k, ref in g["grads_masked"].items():
+        assert torch.allclose(p2[k].grad, ref, rtol=2e-3, atol=2e-6), k
+
+
+def test_small_model_eval_and_sample(golden):
+    g = golden("small")
+    cfg = _cfg(g["cfg"])
+    p = g["state"]
+    with torch.no_grad():
+        pred = restate.voicebox_forward(p, cfg, g["x1"], g["eval_times"], g["cond"], g["cond_mask"])
+        assert torch.allclose(pred, g["pred"], rtol=1e-4, atol=1e-5)
+        ones = torch.ones(g["x1"].shape[:2], dtype=torch.bool)
+        pred_s = restate.voicebox_forward(p, cfg, g["x1"], torch.tensor(0.5), g["cond"], ones)
+        assert torch.allclose(pred_s, g["pred_scalar_t"], rtol=1e-4, atol=1e-5)
+        for steps, key in ((3, "sample3"), (5, "sample5")):
+            s = restate.sample_midpoint(p, cfg, g["y0"], steps)
+            assert torch.allclose(s, g[key], rtol=1e-4, atol=1e-5), key
+
+
+def test_cfg1_loss(golden):
+    """BASELINE config 1 (dim 512, depth 2, B=2, N=1024) on CPU: restatement vs reference scalars."""
+    g = golden("cfg1")
+    cfg = restate.Cfg(dim=512, depth=2, heads=16, dim_head=64)
+    p = restate.init_state_dict(cfg, seed=0)
+    x1 = torch.randn(2, 1024, 512, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(1)
+    x0 = torch.randn_like(x1)
+    assert torch.equal(x0[0, 0, :4], g["x0_check"])
+    with torch.no_grad():
+        loss = restate.cfm_loss(p, cfg, x1, x0, g["times"], g["frac"], g["rand"])
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference sources only exist in the build container")
+def test_restatement_vs_live_reference():
+    ref = ref_loader.load_reference()
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=4)
+    vb = ref.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    vb.load_state_dict(state, strict=False)
+    wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb)
+    x1 = torch.randn(3, 50, 64)
+    torch.manual_seed(5)
+    ref_loss = wrapper(x1)
+    torch.manual_seed(5)
+    x0 = torch.randn_like(x1)
+    times = torch.rand((3,))
+    frac = torch.zeros((3,)).float().uniform_(0.7, 1.0)
+    rand = torch.zeros_like(frac).float().uniform_(0, 1)
+    got = restate.cfm_loss(state, cfg, x1, x0, times, frac, rand)
+    assert abs(float(got) - float(ref_loss)) < 1e-5
