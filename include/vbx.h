@@ -1,0 +1,195 @@
+/*
+ * vbx.h -- C ABI of libvbx_hip.so: the MI355X (gfx950) native hot path of
+ * lucidrains/voicebox-pytorch (VoiceBox transformer fwd/bwd + CFM sampling loop).
+ *
+ * The reference has NO FFI / plugin interface: its "operators" are ATen calls made
+ * from Python modules.  Each entry point below therefore cites the reference *Python call site*
+ * (file:line under /root/reference/voicebox_pytorch/) whose ATen work it replaces.  A maintainer
+ * binds these with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers owned by the caller
+ *    (PyTorch-allocated); the library never allocates or frees device memory and never
+ *    synchronises, so every entry point is hipGraph-capture safe.
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*; 0 = default stream).
+ *  - return 0 on success; negative = VBX_E* argument error (checked before launch);
+ *    positive = hipError_t of the launch.  vbx_last_error() returns a thread-local message.
+ *  - dtypes: bf16/fp16 tensors are raw 16-bit; masks are uint8 (torch.bool); statistics fp32.
+ *  - activations are token-major: row r = b * Np + n  (Np = frames + register tokens).
+ */
+#ifndef VBX_H
+#define VBX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBX_VERSION 1
+
+enum { VBX_OK = 0, VBX_EINVAL = -1, VBX_EUNSUPPORTED = -2, VBX_EWORKSPACE = -3 };
+
+int vbx_version(void);
+const char* vbx_last_error(void);
+/* Device sanity: returns 0 iff device `dev` reports gcnArchName gfx950. */
+int vbx_check_device(int dev);
+
+/* ------------------------------------------------------------------ GEMM (MFMA bf16, fp32 acc) */
+/* mode: how the two operands are laid out (contraction index k):
+ *   NT: A[M,K] (k contiguous), B[N,K] (k contiguous)  -> C[M,N] = A . B^T    nn.Linear forward
+ *   NN: A[M,K] (k contiguous), B[K,N] (n contiguous)  -> C[M,N] = A . B      dgrad  (dX = dY . W)
+ *   TN: A[K,M] (m contiguous), B[K,N] (n contiguous)  -> C[M,N] = A^T . B    wgrad  (dW = dY^T . X)
+ * Replaces every nn.Linear / F.linear on the path (voicebox_pytorch.py:314-315,320,333,345,348,
+ * 938,966,1078,1092) and their autograd backward. */
+enum { VBX_GEMM_NT = 0, VBX_GEMM_NN = 1, VBX_GEMM_TN = 2 };
+
+enum {
+  VBX_EPI_BF16 = 0,       /* C bf16 [M,ldc]   (+bias if given)                                     */
+  VBX_EPI_F32 = 1,        /* C fp32 [M,ldc]   (+bias) (+resid fp32 [M,ldc]) ; optional bf16 copy   */
+  VBX_EPI_QKV = 2,        /* to_qkv + MultiheadRMSNorm + rotary (voicebox_pytorch.py:320-328)       */
+  VBX_EPI_GEGLU = 3,      /* FeedForward[0] + GEGLU (voicebox_pytorch.py:338-340,345)               */
+  VBX_EPI_SPLITK = 4      /* fp32 partial slabs [splits][M][N] for TN wgrad                        */
+};
+
+typedef struct {
+  int mode, epilogue;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const void* A;            /* bf16 */
+  const void* B;            /* bf16 */
+  void* C;                  /* per epilogue */
+  const float* bias;        /* [N] or NULL */
+  const float* resid;       /* EPI_F32: fp32 [M,ldc] added, or NULL */
+  void* C2;                 /* EPI_F32: optional bf16 copy [M,ldc]; EPI_GEGLU: bf16 pre-activation [M,N] or NULL */
+  int splits;               /* EPI_SPLITK: number of K splits (>=1) */
+  /* EPI_QKV: N = 3*H*64.  rows r = b*Np + n. */
+  int Np, H;
+  float qk_scale;           /* sqrt(dim_head) (MultiheadRMSNorm.scale); <= 0 disables qk-norm */
+  const float* q_gamma;     /* [H,64] */
+  const float* k_gamma;     /* [H,64] */
+  const float* rot_cos;     /* [Np,32] fp32 (host-built table, rotary freqs are (ang,ang)) */
+  const float* rot_sin;     /* [Np,32] */
+  void* q16; void* k16;     /* fp16 [B,H,Np,64]  : operands of QK^T */
+  void* qb;  void* kb;      /* bf16 [B,H,Np,64]  : backward operands (may be NULL in eval) */
+  void* v;                  /* bf16 [B,H,Np,64] */
+  float* q_rnorm; float* k_rnorm; /* fp32 [B,H,Np] 1/max(|t|,1e-12) (may be NULL in eval) */
+} vbx_gemm_desc;
+
+int vbx_gemm(const vbx_gemm_desc* d, void* stream);
+/* Sum split-K slabs [splits][M][N] and scatter into dst (fp32): dst[rowmap(i)][j] (+)= sum_s slab.
+ * rowmap: 0 identity; 1 GEGLU de-interleave with (F, Fp): packed row p -> ((p%128)<64 ?
+ * (p/128)*64+p%128 : F + (p/128)*64 + p%128-64), rows/cols beyond the valid range dropped. */
+int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, float* dst, int dst_rows, int dst_cols,
+                      int dst_ld, int rowmap, int F, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ norms */
+/* AdaptiveRMSNorm / RMSNorm forward (voicebox_pytorch.py:246-247, 270-276):
+ * y[r,:] = x[r,:]/max(|x[r,:]|,1e-12)*sqrt(D) * gamma[b(r),:] + beta[b(r),:]  -> bf16.
+ * gamma/beta: fp32 with batch stride gb_stride (0 for the non-adaptive RMSNorm), beta may be NULL.
+ * Rows: for each batch b, rows n in [n0, n0+rows_per_batch) of x (row stride Np per batch);
+ * output y is dense [B*rows_per_batch, D]. */
+int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
+                    int B, int Np, int n0, int rows_per_batch, int D, void* stream);
+/* backward: dx_out = dx_in (or 0 if NULL) + d/dx ; partial dgamma/dbeta sums per 16-row chunk:
+ * part[b][chunk][2][D] (chunk count = ceil(rows_per_batch/16)).  dy is dense bf16 [B*rows, D].
+ * dx tensors have the same (Np, n0) row addressing as x.  dxb: optional bf16 copy of dx_out (same addressing). */
+int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
+                    float* dx_out, void* dxb_bf16, float* part, int B, int Np, int n0, int rows_per_batch, int D,
+                    void* stream);
+
+/* ------------------------------------------------------------------ attention */
+/* Attend.forward math path (attend.py:121-135): softmax(scale * q k^T + key-pad mask) v, fused
+ * flash-style (scores never materialised).  q16,k16 fp16 and v bf16 are [B,H,Np,64]; mask uint8
+ * [B,Np] or NULL; out bf16 [B,Np,H*64]; lse fp32 [B,H,Np] in log2 units (m + log2 l). */
+int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, float* lse,
+                 int B, int H, int Np, float scale, void* stream);
+/* backward.  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
+ * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d]. */
+int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                 const uint8_t* mask, const void* out, const void* dout, const float* lse, float* delta,
+                 float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale, void* stream);
+/* backward of MultiheadRMSNorm + rotary (voicebox_pytorch.py:286-287,199): consumes dq/dk fp32
+ * [B,H,Np,64] and the saved q16/k16 + rnorm, writes d(raw q|k) bf16 into dqkv[(b*Np+n)*ld + which*H*64
+ * + h*64 + d] and partial gamma grads gpart[2][vbx_qknorm_rope_bwd_gpart_rows(B)][H][64]. */
+int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
+                        const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
+                        const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np,
+                        void* stream);
+
+/* ------------------------------------------------------------------ small / memory-bound ops */
+/* x_cat bf16 [B*N, 2*D] = (x, cond * ~cond_mask)   (voicebox_pytorch.py:1035,1075-1076) */
+int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_bf16, int B, int N,
+                         int D, void* stream);
+/* ConvPositionEmbed + residual + register tokens (voicebox_pytorch.py:220-233,1080,422-425):
+ * xs[b, R+n, :] = e[b,n,:] + mask*gelu(conv(mask*e)[b,n,:] + bias);  xs[b, r<R, :] = reg[r,:]. */
+int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
+                    float* xs, int B, int N, int R, int D, int ksize, void* stream);
+/* backward: de = dxs[:,R:] + conv-transpose(...) ; dw/db partials [chunks][D][ksize+1]; dreg [R,D]. */
+int vbx_convpos_bwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* dxs,
+                    float* dpre_tmp /* fp32 [B,N,D] scratch */, float* de, void* de_bf16,
+                    float* wpart /* [chunks][D][64]: k<ksize weight grads, [63] bias grad */, float* dreg, int B, int N,
+                    int R, int D, int ksize, void* stream);
+int vbx_convpos_bwd_chunks(int B, int N);
+/* time embedding: LearnedSinusoidalPosEmb -> Linear -> SiLU (voicebox_pytorch.py:163-167,916-920) */
+int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, const float* b1, float* four,
+                       float* pre, float* temb, int B, int D, int Th, void* stream);
+int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, const float* four, const float* pre,
+                       const float* dtemb, float* dw_sin, float* dw1, float* db1, float* scratch /* B*D floats */, int B,
+                       int D, int Th, void* stream);
+/* all adaLN projections at once: ada[b][j] = bias[j] + sum_t temb[b][t] * W[j][t],  W bf16 [J,Th]
+ * (J = depth*2 norms*(gamma,beta)*D) (voicebox_pytorch.py:273). */
+int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias, float* ada, int B, int Th, int J,
+                       void* stream);
+/* dW[j][t] = sum_b dada[b][j]*temb[b][t] (fp32 [J,Th]), dbias[j] = sum_b dada[b][j],
+ * dtemb[b][t] = sum_j dada[b][j] * W[j][t]. */
+int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias, float* dtemb,
+                       float* scratch, int B, int Th, int J, void* stream);
+int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J);
+/* reduce rmsnorm_bwd partials over chunks: out[b][2][D] = sum_chunk part[b][chunk][2][D] */
+int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D, int sum_batch,
+                             void* stream);
+/* GEGLU backward on the interleaved pre-activation (voicebox_pytorch.py:338-340) */
+int vbx_geglu_bwd(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, void* stream);
+/* column sums: out[c] (+)= sum_r in[r][c]   (bias grads) ; rowmap as in vbx_splitk_reduce */
+int vbx_colsum_bf16(const void* in_bf16, int M, int C, int ld, float* out, int out_len, int rowmap, int F,
+                    float* scratch, void* stream);
+int vbx_colsum_f32(const float* in, int M, int C, int ld, float* out, float* scratch, void* stream);
+int vbx_colsum_scratch_floats(int M, int C);
+/* out[j] (+)= sum_{i<rows} in[i*ld + j], j < cols   (partials -> gradients) */
+int vbx_sum_rows_f32(const float* in, long rows, long ld, float* out, long cols, int accumulate, void* stream);
+/* rows of the gpart buffer of vbx_qknorm_rope_bwd per `which`: gpart is [2][rows][H][64] */
+int vbx_qknorm_rope_bwd_gpart_rows(int B);
+/* masked MSE (voicebox_pytorch.py:1099-1115): loss scalar fp32; per_b: 2*B floats (per-sample loss, denominators). */
+int vbx_masked_mse_fwd(const float* pred, const float* target, const uint8_t* loss_mask, float* per_b, float* loss,
+                       int B, int N, int D, void* stream);
+int vbx_masked_mse_bwd(const float* pred, const float* target, const uint8_t* loss_mask, const float* per_b,
+                       const float* gscale /* device scalar d(loss) or NULL (=1) */, float* dpred, void* dpred_bf16, int B,
+                       int N, int D, void* stream);
+/* CFM inputs (voicebox_pytorch.py:1404-1410): w = (1-(1-sigma)t)x0 + t x1 ; flow = x1-(1-sigma)x0 */
+int vbx_cfm_inputs(const float* x1, const float* x0, const float* times, float sigma, float* w, float* flow, int B,
+                   long per_batch, void* stream);
+/* y_out = y + coef[idx] * f   (ODE midpoint axpy; coef device-resident so graphs hold no host scalars) */
+int vbx_axpy_dev(const float* y, const float* f, const float* coef, int idx, float* out, long n, void* stream);
+/* fp32 -> bf16 weight packing with optional row map / K padding:
+ * dst[p][c] = (src row of p valid && c < src_cols) ? src[row][c] : 0 ; dst is [dst_rows, dst_cols] */
+int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, int dst_rows, int dst_cols,
+                    int rowmap, int F, void* stream);
+int vbx_pack_bias(const float* src, int n, float* dst, int dst_n, int rowmap, int F, void* stream);
+/* fused Adam (torch.optim.Adam semantics, no weight decay/amsgrad) over a flat fp32 buffer; grads are
+ * pre-multiplied by *gscale (device scalar, e.g. clip coefficient) if non-NULL. */
+int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, const float* gscale, void* stream);
+/* sum of squares of a flat buffer -> out[0] (two-stage, deterministic) ; scratch >= 1024 floats */
+int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
+/* clip coefficient: coef = min(1, max_norm / (sqrt(sumsq)+1e-6)) */
+int vbx_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+
+/* ------------------------------------------------------------------ hardware probes (tests only) */
+int vbx_probe_tr16(const void* in_u16_4096, const int* lane_elem_off, void* out_u16_256, void* stream);
+int vbx_probe_mfma(int which, const float* a, const float* b, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBX_H */

@@ -1,0 +1,532 @@
+"""GPU parity tests, op level: every C-ABI kernel entry point of libvbx_hip.so against a CPU fp32/fp64
+PyTorch restatement of the reference op (oracle/restate.py) on the same seeded inputs.
+
+Tolerances are stated per test.  bf16 operands carry 2^-9 relative rounding, so GEMM-like ops are
+compared against a reference computed from the *same bf16-rounded inputs* in fp64 (isolates the
+kernel's own error: fp32 accumulation order) with rtol 2e-3, and norms/elementwise at bf16 output
+precision (rel 2^-8).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restate
+
+pytestmark = pytest.mark.gpu
+
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from voicebox_pytorch_amd import _lib
+
+    _lib.lib()
+    _lib.call("vbx_check_device", 0)
+    return _lib
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).norm() / ref.norm().clamp(min=1e-30))
+
+
+def max_err(got, ref):
+    return float((got.double().cpu() - ref.double().cpu()).abs().max())
+
+
+# ----------------------------------------------------------------------------- hardware probes
+def test_probe_tr16(L):
+    """ds_read_b64_tr_b16 semantics assumed by gemm.hip/attn.hip: inside each 16-lane group, lane a
+    receives element (a&3) of the 8 bytes addressed by lanes 4j + (a>>2), j=0..3."""
+    data = torch.arange(4096, dtype=torch.int16, device=dev)
+    g = torch.Generator().manual_seed(0)
+    for trial in range(3):
+        if trial == 0:
+            off = torch.arange(64, dtype=torch.int32) * 4  # dense
+        else:
+            off = (torch.randperm(1024, generator=g)[:64] * 4).to(torch.int32)
+        out = torch.zeros(256, dtype=torch.int16, device=dev)
+        L.call("vbx_probe_tr16", data, off.to(dev), out, st())
+        torch.cuda.synchronize()
+        out = out.cpu().view(64, 4).to(torch.int64)
+        exp = torch.zeros(64, 4, dtype=torch.int64)
+        for l in range(64):
+            grp, a = l // 16, l % 16
+            for j in range(4):
+                sup = grp * 16 + 4 * j + (a >> 2)
+                exp[l, j] = int(off[sup]) + (a & 3)
+        assert torch.equal(out, exp), f"trial {trial}\n got {out.tolist()}\n exp {exp.tolist()}"
+
+
+@pytest.mark.parametrize("which,shape", [(0, (16, 32, 16)), (1, (32, 16, 32)), (2, (32, 16, 32))])
+def test_probe_mfma_layout(L, which, shape):
+    m, k, n = shape
+    g = torch.Generator().manual_seed(which)
+    a = torch.randint(-4, 5, (m, k), generator=g).float()
+    b = torch.randint(-4, 5, (k, n), generator=g).float()  # asymmetric integers: exact in bf16/fp16
+    c = torch.zeros(m, n, device=dev)
+    L.call("vbx_probe_mfma", which, a.to(dev), b.to(dev), c, st())
+    assert torch.equal(c.cpu(), a @ b)
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(L, mode, epi, A, B, M, N, K, **kw):
+    d = L.GemmDesc()
+    d.mode, d.epilogue, d.M, d.N, d.K = mode, epi, M, N, K
+    d.A, d.B = A.data_ptr(), B.data_ptr()
+    d.lda, d.ldb = A.shape[-1], B.shape[-1]
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    rc = L.lib().vbx_gemm(d, st())
+    assert rc == 0, L.lib().vbx_last_error()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512)])
+def test_gemm_nt_bf16_f32(L, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    Bw = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    ref = A.double().cpu() @ Bw.double().cpu().t()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_BF16, A, Bw, M, N, K, C=out, ldc=N, bias=bias)
+    assert rel_err(out, ref + bias.double().cpu()) < 4e-3  # bf16 output rounding
+    out32 = torch.empty(M, N, device=dev)
+    out_b = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_F32, A, Bw, M, N, K, C=out32, ldc=N, bias=bias, resid=resid, C2=out_b)
+    full = ref + bias.double().cpu() + resid.double().cpu()
+    assert rel_err(out32, full) < 1e-5
+    assert rel_err(out_b, full) < 4e-3
+    out32b = torch.empty(M, N, device=dev)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_F32, A, Bw, M, N, K, C=out32b, ldc=N)
+    assert rel_err(out32b, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408)])
+def test_gemm_nn(L, M, N, K):
+    """dgrad layout: C[M,N] = A[M,K] . B[K,N]  (B read through the hardware transpose path)."""
+    g = torch.Generator().manual_seed(M * 3 + N)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    Bm = bf(torch.randn(K, N, generator=g) * K ** -0.5).to(dev)
+    ref = A.double().cpu() @ Bm.double().cpu()
+    out32 = torch.empty(M, N, device=dev)
+    gemm(L, L.VBX_GEMM_NN, L.VBX_EPI_F32, A, Bm, M, N, K, C=out32, ldc=N)
+    assert rel_err(out32, ref) < 1e-5
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    gemm(L, L.VBX_GEMM_NN, L.VBX_EPI_BF16, A, Bm, M, N, K, C=out, ldc=N)
+    assert rel_err(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(264, 200, 300, 1), (256, 128, 8320, 8), (2816, 512, 1000, 3)])
+def test_gemm_tn_splitk(L, M, N, K, splits):
+    """wgrad layout: C[M,N] = A[K,M]^T . B[K,N], fp32 split-K slabs + deterministic reduce."""
+    g = torch.Generator().manual_seed(M + K)
+    A = bf(torch.randn(K, M, generator=g)).to(dev)
+    Bm = bf(torch.randn(K, N, generator=g)).to(dev)
+    ref = A.double().cpu().t() @ Bm.double().cpu()
+    slabs = torch.empty(splits, M, N, device=dev)
+    gemm(L, L.VBX_GEMM_TN, L.VBX_EPI_SPLITK, A, Bm, M, N, K, C=slabs, splits=splits)
+    dst = torch.full((M, N), 7.0, device=dev)
+    L.call("vbx_splitk_reduce", slabs, splits, M, N, dst, M, N, N, 0, 0, 0, st())
+    assert rel_err(dst, ref) < 1e-5
+    # accumulate + column trim
+    dst2 = torch.ones(M, N - 3, device=dev)
+    L.call("vbx_splitk_reduce", slabs, splits, M, N, dst2, M, N - 3, N - 3, 0, 0, 1, st())
+    assert rel_err(dst2, ref[:, : N - 3] + 1) < 1e-5
+
+
+def test_gemm_tn_geglu_rowmap(L):
+    Fd, D, K = 170, 64, 333  # packed rows 2*Fp with Fp = 192
+    Fp = 192
+    g = torch.Generator().manual_seed(1)
+    A = bf(torch.randn(K, 2 * Fp, generator=g)).to(dev)
+    Bm = bf(torch.randn(K, D, generator=g)).to(dev)
+    ref_packed = A.double().cpu().t() @ Bm.double().cpu()
+    slabs = torch.empty(2, 2 * Fp, D, device=dev)
+    gemm(L, L.VBX_GEMM_TN, L.VBX_EPI_SPLITK, A, Bm, 2 * Fp, D, K, C=slabs, splits=2)
+    dst = torch.zeros(2 * Fd, D, device=dev)
+    L.call("vbx_splitk_reduce", slabs, 2, 2 * Fp, D, dst, 2 * Fd, D, D, 1, Fd, 0, st())
+    exp = torch.zeros(2 * Fd, D, dtype=torch.float64)
+    for p in range(2 * Fp):
+        blk, w = p // 128, p % 128
+        f = blk * 64 + (w & 63)
+        if f < Fd:
+            exp[f if w < 64 else Fd + f] = ref_packed[p]
+    assert rel_err(dst, exp) < 1e-5
+
+
+def rot_tables(Np, R):
+    pos = torch.cat((torch.full((R,), -10000, dtype=torch.long), torch.arange(Np - R)))
+    fr = restate.rotary_freqs(pos, 64, 50000.0)
+    return fr, fr[:, :32].cos().contiguous(), fr[:, :32].sin().contiguous()
+
+
+@pytest.mark.parametrize("Bsz,Np,H,D,qknorm", [(2, 56, 2, 64, True), (2, 1040, 4, 256, True), (1, 40, 2, 128, False)])
+def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm):
+    """to_qkv + MultiheadRMSNorm + rotary fused (voicebox_pytorch.py:320-328)."""
+    g = torch.Generator().manual_seed(Np)
+    I = H * 64
+    M = Bsz * Np
+    x = bf(torch.randn(M, D, generator=g)).to(dev)
+    W = bf(torch.randn(3 * I, D, generator=g) * D ** -0.5).to(dev)
+    qg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
+    kg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
+    fr, rc, rs = rot_tables(Np, 16)
+    q16 = torch.empty(Bsz, H, Np, 64, dtype=torch.float16, device=dev)
+    k16 = torch.empty_like(q16)
+    qb = torch.empty(Bsz, H, Np, 64, dtype=torch.bfloat16, device=dev)
+    kb = torch.empty_like(qb)
+    v = torch.empty_like(qb)
+    qrn = torch.empty(Bsz, H, Np, device=dev)
+    krn = torch.empty_like(qrn)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_QKV, x, W, M, 3 * I, D, Np=Np, H=H, qk_scale=8.0 if qknorm else 0.0,
+         q_gamma=qg, k_gamma=kg, rot_cos=rc.to(dev), rot_sin=rs.to(dev), q16=q16, k16=k16, qb=qb, kb=kb, v=v,
+         q_rnorm=qrn, k_rnorm=krn)
+    qkv = (x.double().cpu() @ W.double().cpu().t()).view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, vv = qkv[0], qkv[1], qkv[2]
+    if qknorm:
+        assert rel_err(qrn, 1 / q.norm(dim=-1)) < 1e-5
+        q = restate.l2norm_scale(q, 64) * qg.double().cpu()[:, None, :]
+        k = restate.l2norm_scale(k, 64) * kg.double().cpu()[:, None, :]
+    q, k = restate.apply_rotary(fr.double(), q), restate.apply_rotary(fr.double(), k)
+    assert rel_err(q16, q) < 6e-4 and rel_err(k16, k) < 6e-4  # fp16 storage: 2^-11
+    assert rel_err(qb, q) < 4e-3 and rel_err(kb, k) < 4e-3
+    assert rel_err(v, vv) < 4e-3
+
+
+def test_gemm_geglu_epilogue(L):
+    """FeedForward[0] + GEGLU fused, packed/interleaved weights (voicebox_pytorch.py:338-345)."""
+    g = torch.Generator().manual_seed(3)
+    M, D, Fd = 200, 128, 341
+    Fp = 384
+    x = bf(torch.randn(M, D, generator=g)).to(dev)
+    W1 = torch.randn(2 * Fd, D, generator=g) * D ** -0.5
+    b1 = torch.randn(2 * Fd, generator=g) * 0.1
+    W1p = torch.empty(2 * Fp, D, dtype=torch.bfloat16, device=dev)
+    b1p = torch.empty(2 * Fp, device=dev)
+    L.call("vbx_pack_weight", W1.to(dev), 2 * Fd, D, W1p, 2 * Fp, D, 1, Fd, st())
+    L.call("vbx_pack_bias", b1.to(dev), 2 * Fd, b1p, 2 * Fp, 1, Fd, st())
+    gout = torch.empty(M, Fp, dtype=torch.bfloat16, device=dev)
+    h1 = torch.empty(M, 2 * Fp, dtype=torch.bfloat16, device=dev)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_GEGLU, x, W1p, M, 2 * Fp, D, C=gout, ldc=Fp, bias=b1p, C2=h1)
+    hdn = x.double().cpu() @ bf(W1).double().t() + b1.double()
+    a, gate = hdn.chunk(2, dim=-1)
+    ref = F.gelu(gate) * a
+    assert rel_err(gout[:, :Fd], ref) < 4e-3
+    assert float(gout[:, Fd:].float().abs().max()) == 0.0  # padding columns are exactly zero
+    # saved pre-activation is the interleaved layout
+    blk = h1.float().cpu().view(M, Fp // 64, 2, 64)
+    assert rel_err(blk[:, :, 0].reshape(M, Fp)[:, :Fd], a) < 4e-3
+    assert rel_err(blk[:, :, 1].reshape(M, Fp)[:, :Fd], gate) < 4e-3
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("Bsz,Np,n0,rpb,D,adaptive", [(2, 40, 0, 40, 64, True), (8, 1040, 0, 1040, 512, True),
+                                                     (2, 56, 16, 40, 256, False), (3, 33, 0, 33, 1024, True)])
+def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
+    g = torch.Generator().manual_seed(D + Np)
+    x = torch.randn(Bsz, Np, D, generator=g)
+    if adaptive:
+        gamma, beta = 1 + 0.3 * torch.randn(Bsz, D, generator=g), 0.3 * torch.randn(Bsz, D, generator=g)
+        stride = D
+    else:
+        gamma, beta, stride = 1 + 0.3 * torch.randn(D, generator=g), None, 0
+    y = torch.empty(Bsz * rpb, D, dtype=torch.bfloat16, device=dev)
+    xd, gd = x.to(dev), gamma.to(dev)
+    bd = beta.to(dev) if beta is not None else None
+    L.call("vbx_rmsnorm_fwd", xd, gd, bd, stride, y, Bsz, Np, n0, rpb, D, st())
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True) if beta is not None else None
+    xs = xr[:, n0:n0 + rpb]
+    nrm = restate.l2norm_scale(xs, D)
+    ref = nrm * (gr[:, None, :] if adaptive else gr) + (br[:, None, :] if adaptive else 0.0)
+    assert rel_err(y.view(Bsz, rpb, D), ref) < 4e-3
+    # backward
+    dy = bf(torch.randn(Bsz, rpb, D, generator=g))
+    ref.backward(dy.double())
+    dx_in = torch.randn(Bsz, Np, D, generator=g)
+    dx_out = torch.zeros(Bsz, Np, D, device=dev)
+    dxb = torch.zeros(Bsz, Np, D, dtype=torch.bfloat16, device=dev)
+    chunks = (rpb + 15) // 16
+    part = torch.zeros(Bsz, chunks, 2, D, device=dev)
+    L.call("vbx_rmsnorm_bwd", xd, gd, stride, dy.to(dev), dx_in.to(dev), dx_out, dxb, part, Bsz, Np, n0, rpb, D, st())
+    exp_dx = xr.grad[:, n0:n0 + rpb] + dx_in[:, n0:n0 + rpb].double()
+    assert rel_err(dx_out[:, n0:n0 + rpb], exp_dx) < 1e-5
+    assert rel_err(dxb[:, n0:n0 + rpb], exp_dx) < 4e-3
+    if adaptive:
+        out = torch.zeros(Bsz, 2, D, device=dev)
+        L.call("vbx_reduce_norm_partials", part, out, 2 * D, Bsz, chunks, D, 0, st())
+        assert rel_err(out[:, 0], gr.grad) < 1e-5 and rel_err(out[:, 1], br.grad) < 1e-5
+    else:
+        out = torch.zeros(2, D, device=dev)
+        L.call("vbx_reduce_norm_partials", part, out, 0, Bsz, chunks, D, 1, st())
+        assert rel_err(out[0], gr.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_inputs(Bsz, H, Np, seed, qnorm=8.0):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(Bsz, H, Np, 64, generator=g)
+    k = torch.randn(Bsz, H, Np, 64, generator=g)
+    if qnorm:
+        q = q / q.norm(dim=-1, keepdim=True) * qnorm
+        k = k / k.norm(dim=-1, keepdim=True) * qnorm
+    v = torch.randn(Bsz, H, Np, 64, generator=g)
+    return q.half(), k.half(), bf(v)
+
+
+@pytest.mark.parametrize("Bsz,H,Np,scale,masked", [(1, 2, 64, 10.0, False), (2, 2, 1040, 10.0, False),
+                                                   (2, 3, 77, 10.0, True), (1, 2, 200, 0.125, True),
+                                                   (2, 2, 1040, 10.0, True)])
+def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked):
+    """Attend.forward math path (attend.py:121-135) at the reference's logit scale (10 * q.k, |q|=|k|=8)."""
+    q16, k16, v = attn_inputs(Bsz, H, Np, seed=Np + H, qnorm=8.0 if scale == 10.0 else None)
+    mask = None
+    if masked:
+        mask = torch.ones(Bsz, Np, dtype=torch.bool)
+        mask[0, Np - 13:] = False
+        if Bsz > 1:
+            mask[1, 5:9] = False
+    out = torch.empty(Bsz, Np, H * 64, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(Bsz, H, Np, device=dev)
+    qd, kd, vd = q16.to(dev), k16.to(dev), v.to(dev)
+    md = mask.to(dev) if masked else None
+    L.call("vbx_attn_fwd", qd, kd, vd, md, out, lse, Bsz, H, Np, scale, st())
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q16, k16, v))
+    ref = restate.attend(qr, kr, vr, mask=mask, scale=scale)  # (b,h,n,d)
+    ref_t = ref.permute(0, 2, 1, 3).reshape(Bsz, Np, H * 64)
+    # P is rounded to bf16 before P.V (rel 2^-9 per weight) and the output is stored in bf16
+    assert rel_err(out, ref_t) < 6e-3, rel_err(out, ref_t)
+    sim = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    if masked:
+        sim = sim.masked_fill(~mask[:, None, None, :], -float("inf"))
+    ref_lse = torch.logsumexp(sim, dim=-1) / math.log(2.0)
+    assert max_err(lse, ref_lse) < 2e-3
+    # ---- backward
+    g = torch.Generator().manual_seed(5)
+    dout = bf(torch.randn(Bsz, Np, H * 64, generator=g) * 1e-3)  # gradient-sized values (fp16 would flush these)
+    ref_t.backward(dout.double())
+    qb, kb = bf(q16.float()).to(dev), bf(k16.float()).to(dev)
+    delta = torch.empty(Bsz, H, Np, device=dev)
+    dq = torch.zeros(Bsz, H, Np, 64, device=dev)
+    dk = torch.zeros(Bsz, H, Np, 64, device=dev)
+    dv = torch.zeros(Bsz, Np, 3 * H * 64, dtype=torch.bfloat16, device=dev)
+    dv_view = dv[:, :, 2 * H * 64:]
+    L.call("vbx_attn_bwd", qd, kd, qb, kb, vd, md, out, dout.to(dev), lse, delta, dq, dk,
+           dv_view.data_ptr(), 3 * H * 64, Bsz, H, Np, scale, st())
+    torch.cuda.synchronize()
+    dv_got = dv_view.float().cpu().view(Bsz, Np, H, 64).permute(0, 2, 1, 3)
+    # operands of the backward GEMMs (P, dS, q, k, dO) are bf16 -> ~1e-2 relative on the result
+    assert rel_err(dv_got, vr.grad) < 1.5e-2, rel_err(dv_got, vr.grad)
+    assert rel_err(dq, qr.grad) < 2e-2, rel_err(dq, qr.grad)
+    assert rel_err(dk, kr.grad) < 2e-2, rel_err(dk, kr.grad)
+
+
+@pytest.mark.parametrize("qknorm", [True, False])
+def test_qknorm_rope_bwd(L, qknorm):
+    Bsz, H, Np = 2, 2, 70
+    g = torch.Generator().manual_seed(9)
+    t = torch.randn(2, Bsz, H, Np, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    gam = (1 + 0.2 * torch.randn(2, H, 64, generator=g, dtype=torch.float64)).requires_grad_(True)
+    fr, rc, rs = rot_tables(Np, 16)
+    outs = []
+    for w in range(2):
+        y = restate.l2norm_scale(t[w], 64) * gam[w][:, None, :] if qknorm else t[w]
+        outs.append(restate.apply_rotary(fr.double(), y))
+    up = torch.randn(2, Bsz, H, Np, 64, generator=g)
+    (outs[0] * up[0].double()).sum().backward(retain_graph=True)
+    (outs[1] * up[1].double()).sum().backward()
+    rn = (1 / t.detach().norm(dim=-1)).float()
+    dqkv = torch.zeros(Bsz * Np, 3 * H * 64, dtype=torch.bfloat16, device=dev)
+    rows = L.lib().vbx_qknorm_rope_bwd_gpart_rows(Bsz)
+    gpart = torch.zeros(2, rows, H, 64, device=dev)
+    L.call("vbx_qknorm_rope_bwd", up[0].to(dev), up[1].to(dev), outs[0].detach().half().to(dev),
+           outs[1].detach().half().to(dev), rn[0].to(dev), rn[1].to(dev), gam[0].detach().float().to(dev),
+           gam[1].detach().float().to(dev), rc.to(dev), rs.to(dev), 8.0 if qknorm else 0.0, dqkv, 3 * H * 64, gpart,
+           Bsz, H, Np, st())
+    got = dqkv.float().cpu().view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
+    for w in range(2):
+        assert rel_err(got[w], t.grad[w]) < 5e-3, (w, rel_err(got[w], t.grad[w]))
+    if qknorm:
+        assert rel_err(gpart.sum(1), gam.grad) < 2e-3
+
+
+# ----------------------------------------------------------------------------- small ops
+@pytest.mark.parametrize("masked", [False, True])
+def test_convpos_fwd_bwd(L, masked):
+    Bsz, N, R, D, ks = 2, 150, 16, 128, 31
+    g = torch.Generator().manual_seed(2)
+    e = torch.randn(Bsz, N, D, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(D, 1, ks, generator=g, dtype=torch.float64) * ks ** -0.5).requires_grad_(True)
+    b = (0.1 * torch.randn(D, generator=g, dtype=torch.float64)).requires_grad_(True)
+    reg = torch.randn(R, D, generator=g)
+    mask = None
+    if masked:
+        mask = torch.ones(Bsz, N, dtype=torch.bool)
+        mask[1, 100:] = False
+    ref = restate.conv_pos_embed(e, w, b, mask) + e
+    xs = torch.zeros(Bsz, N + R, D, device=dev)
+    ed, wd, bd = e.detach().float().to(dev), w.detach().float().to(dev), b.detach().float().to(dev)
+    md = mask.to(dev) if masked else None
+    L.call("vbx_convpos_fwd", ed, wd, bd, md, reg.to(dev), xs, Bsz, N, R, D, ks, st())
+    assert rel_err(xs[:, R:], ref) < 1e-5
+    assert torch.equal(xs[:, :R].cpu(), reg.expand(Bsz, R, D))
+    dxs = torch.randn(Bsz, N + R, D, generator=g)
+    ref.backward(dxs[:, R:].double())
+    chunks = L.lib().vbx_convpos_bwd_chunks(Bsz, N)
+    dpre = torch.empty(Bsz, N, D, device=dev)
+    de = torch.empty(Bsz, N, D, device=dev)
+    deb = torch.empty(Bsz, N, D, dtype=torch.bfloat16, device=dev)
+    wpart = torch.zeros(chunks, D, 64, device=dev)
+    dreg = torch.zeros(R, D, device=dev)
+    L.call("vbx_convpos_bwd", ed, wd, bd, md, dxs.to(dev), dpre, de, deb, wpart, dreg, Bsz, N, R, D, ks, st())
+    assert rel_err(de, e.grad) < 1e-5
+    assert rel_err(deb, e.grad) < 4e-3
+    wsum = wpart.sum(0)
+    assert rel_err(wsum[:, :ks], w.grad[:, 0]) < 1e-5
+    assert rel_err(wsum[:, 63], b.grad) < 1e-5
+    assert rel_err(dreg, dxs[:, :R].sum(0)) < 1e-6
+
+
+def test_time_embed_and_adaln(L):
+    Bsz, D, Th, J = 3, 64, 256, 512
+    g = torch.Generator().manual_seed(4)
+    times = torch.rand(Bsz, generator=g)
+    p = {"sinu_pos_emb.0.weights": torch.randn(D // 2, generator=g),
+         "sinu_pos_emb.1.weight": torch.randn(Th, D, generator=g) * D ** -0.5,
+         "sinu_pos_emb.1.bias": torch.randn(Th, generator=g) * 0.1}
+    pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    temb_ref = restate.time_embedding(times.double(), pr)
+    four = torch.empty(Bsz, D, device=dev)
+    pre = torch.empty(Bsz, Th, device=dev)
+    temb = torch.empty(Bsz, Th, device=dev)
+    pd = {k: v.to(dev) for k, v in p.items()}
+    L.call("vbx_time_embed_fwd", times.to(dev), pd["sinu_pos_emb.0.weights"], pd["sinu_pos_emb.1.weight"],
+           pd["sinu_pos_emb.1.bias"], four, pre, temb, Bsz, D, Th, st())
+    assert rel_err(temb, temb_ref) < 1e-5
+    # adaLN projection
+    W = torch.randn(J, Th, generator=g) * 0.02
+    bias = torch.randn(J, generator=g)
+    Wb = bf(W).to(dev)
+    Wr = bf(W).double().requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    ada_ref = temb_ref @ Wr.t() + br
+    ada = torch.empty(Bsz, J, device=dev)
+    L.call("vbx_adaln_proj_fwd", temb, Wb, bias.to(dev), ada, Bsz, Th, J, st())
+    assert rel_err(ada, ada_ref) < 1e-5
+    dada = torch.randn(Bsz, J, generator=g)
+    ada_ref.backward(dada.double())
+    dW = torch.empty(J, Th, device=dev)
+    dbias = torch.empty(J, device=dev)
+    dtemb = torch.empty(Bsz, Th, device=dev)
+    scratch = torch.empty(L.lib().vbx_adaln_proj_bwd_scratch_floats(Bsz, Th, J), device=dev)
+    L.call("vbx_adaln_proj_bwd", temb, Wb, dada.to(dev), dW, dbias, dtemb, scratch, Bsz, Th, J, st())
+    assert rel_err(dW, Wr.grad) < 1e-5 and rel_err(dbias, br.grad) < 1e-5
+    # time-embedding backward from the oracle's d(temb)
+    dtemb_ref = dada.double() @ Wr.detach()
+    assert rel_err(dtemb, dtemb_ref) < 1e-5
+    dws = torch.empty(D // 2, device=dev)
+    dw1 = torch.empty(Th, D, device=dev)
+    db1 = torch.empty(Th, device=dev)
+    sc = torch.empty(Bsz * D, device=dev)
+    L.call("vbx_time_embed_bwd", times.to(dev), pd["sinu_pos_emb.0.weights"], pd["sinu_pos_emb.1.weight"], four, pre,
+           dtemb, dws, dw1, db1, sc, Bsz, D, Th, st())
+    assert rel_err(dw1, pr["sinu_pos_emb.1.weight"].grad) < 1e-4
+    assert rel_err(db1, pr["sinu_pos_emb.1.bias"].grad) < 1e-4
+    assert rel_err(dws, pr["sinu_pos_emb.0.weights"].grad) < 1e-4
+
+
+def test_geglu_bwd_and_colsum(L):
+    M, Fd, Fp = 100, 170, 192
+    g = torch.Generator().manual_seed(6)
+    h1 = bf(torch.randn(M, 2 * Fp, generator=g))
+    dg = bf(torch.randn(M, Fp, generator=g))
+    dh1 = torch.empty(M, 2 * Fp, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_geglu_bwd", h1.to(dev), dg.to(dev), dh1, M, Fp, st())
+    blk = h1.double().view(M, Fp // 64, 2, 64)
+    xr = blk[:, :, 0].reshape(M, Fp).requires_grad_(True)
+    gr = blk[:, :, 1].reshape(M, Fp).requires_grad_(True)
+    (F.gelu(gr) * xr).backward(dg.double())
+    got = dh1.float().cpu().view(M, Fp // 64, 2, 64)
+    assert rel_err(got[:, :, 0].reshape(M, Fp), xr.grad) < 4e-3
+    assert rel_err(got[:, :, 1].reshape(M, Fp), gr.grad) < 4e-3
+    # column sums with the GEGLU un-mapping (bias grad of FeedForward[0])
+    out = torch.zeros(2 * Fd, device=dev)
+    scratch = torch.empty(L.lib().vbx_colsum_scratch_floats(M, 2 * Fp), device=dev)
+    L.call("vbx_colsum_bf16", dh1, M, 2 * Fp, 2 * Fp, out, 2 * Fd, 1, Fd, scratch, st())
+    cs = dh1.float().cpu().double().sum(0).view(Fp // 64, 2, 64)
+    exp = torch.cat((cs[:, 0].reshape(-1)[:Fd], cs[:, 1].reshape(-1)[:Fd]))
+    assert rel_err(out, exp) < 1e-5
+    x32 = torch.randn(M, 96, generator=g)
+    o2 = torch.zeros(96, device=dev)
+    sc2 = torch.empty(L.lib().vbx_colsum_scratch_floats(M, 96), device=dev)
+    L.call("vbx_colsum_f32", x32.to(dev), M, 96, 96, o2, sc2, st())
+    assert rel_err(o2, x32.double().sum(0)) < 1e-6
+
+
+def test_masked_mse_cfm_axpy(L):
+    Bsz, N, D = 3, 50, 64
+    g = torch.Generator().manual_seed(8)
+    pred = torch.randn(Bsz, N, D, generator=g, dtype=torch.float64, requires_grad=True)
+    target = torch.randn(Bsz, N, D, generator=g, dtype=torch.float64)
+    lm = torch.rand(Bsz, N, generator=g) < 0.6
+    lm[2] = False  # a sample with an empty loss mask: den clamps to 1e-5 (voicebox_pytorch.py:1112)
+    per = ((pred - target) ** 2).mean(-1).masked_fill(~lm, 0.0)
+    ref = (per.sum(-1) / lm.sum(-1).clamp(min=1e-5)).mean()
+    ref.backward()
+    per_b = torch.zeros(2 * Bsz, device=dev)
+    loss = torch.zeros(1, device=dev)
+    pd, td, ld = pred.detach().float().to(dev), target.float().to(dev), lm.to(dev)
+    L.call("vbx_masked_mse_fwd", pd, td, ld, per_b, loss, Bsz, N, D, st())
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    dpred = torch.empty(Bsz, N, D, device=dev)
+    dpb = torch.empty(Bsz, N, D, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_masked_mse_bwd", pd, td, ld, per_b, None, dpred, dpb, Bsz, N, D, st())
+    assert rel_err(dpred, pred.grad) < 1e-5
+    assert rel_err(dpb, pred.grad) < 4e-3
+    # CFM inputs (voicebox_pytorch.py:1404-1410)
+    x1, x0 = torch.randn(Bsz, N, D, generator=g), torch.randn(Bsz, N, D, generator=g)
+    times = torch.rand(Bsz, generator=g)
+    for sigma in (0.0, 0.1):
+        w_ref, f_ref = restate.cfm_inputs(x1, x0, times, sigma)
+        w, fl = torch.empty(Bsz, N, D, device=dev), torch.empty(Bsz, N, D, device=dev)
+        L.call("vbx_cfm_inputs", x1.to(dev), x0.to(dev), times.to(dev), sigma, w, fl, Bsz, N * D, st())
+        assert max_err(w, w_ref) < 1e-6 and max_err(fl, f_ref) < 1e-6
+    coef = torch.tensor([0.5, -0.25], device=dev)
+    out = torch.empty(Bsz, N, D, device=dev)
+    L.call("vbx_axpy_dev", x1.to(dev), x0.to(dev), coef, 1, out, Bsz * N * D, st())
+    assert max_err(out, x1 - 0.25 * x0) < 1e-6
+
+
+def test_adam_sumsq_clip(L):
+    n = 100003
+    g = torch.Generator().manual_seed(10)
+    p = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref_p], lr=3e-4, betas=(0.9, 0.99), eps=1e-8)
+    pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    ss, coef, scratch = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1024, device=dev)
+    for step, gr in enumerate(grads, 1):
+        ref_p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        gd = gr.to(dev)
+        L.call("vbx_sumsq", gd, n, ss, scratch, st())
+        assert abs(float(ss) - float(gr.double().pow(2).sum())) < 1e-4 * float(ss)
+        L.call("vbx_clip_coef", ss, 0.5, coef, st())
+        L.call("vbx_adam_step", pd, gd, m, v, n, 3e-4, 0.9, 0.99, 1e-8, step, coef, st())
+    assert max_err(pd, ref_p.detach()) < 2e-6

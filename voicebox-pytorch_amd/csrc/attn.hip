@@ -1,0 +1,527 @@
+// Fused attention for gfx950: Attend.forward math path (attend.py:121-135) without materialising
+// the (Np x Np) score matrix, plus its backward (two kernels: dq, and dk/dv).
+//
+// Everything is "transposed" so that the softmax axis is lane-local:
+//   S^T[key][q] = K . Q^T   (v_mfma_f32_32x32x16_f16; q-hat/k-hat are fp16: logits are 10 * q.k with
+//                            |q|=|k|=8, std ~80 -- bf16 operands would perturb them by O(0.1))
+//   O^T[d][q]   = V^T . P^T (v_mfma_f32_32x32x16_bf16; V^T fragments come straight from the row-major
+//                            V tile through ds_read_b64_tr_b16)
+// With the 32x32 C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) a lane owns ONE
+// query column of S^T and of O^T: row max / sum / rescale are per-lane scalars plus one lane^32 exchange,
+// and the P^T accumulator registers are already the B operand of the next MFMA (slot s of half hi <->
+// key (s&3) + 8*(s>>2) + 4*hi inside each 16-key group; the V^T fragment uses the same key order).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TILE16 = 64 * 128;  // one [64 rows][64 x 16-bit] tile, 16-byte XOR swizzle: 8192 B
+constexpr float NEG_INF = -__builtin_inff();
+
+VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// cooperative (256 threads) load of a [64][64] 16-bit tile: 2 x 16 B per thread.
+struct Stage2 {
+  uint4 v[2];
+};
+VBX_DEV void tile_g2r(Stage2& s, const u16* __restrict__ base, long row_stride, int row0, int row_lim, bool zero_oob, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, ch = c & 7;
+    int gr = row0 + row;
+    const bool oob = gr >= row_lim;
+    if (oob) gr = row_lim - 1;
+    uint4 v = *reinterpret_cast<const uint4*>(base + (long)gr * row_stride + ch * 8);
+    if (oob && zero_oob) v = make_uint4(0u, 0u, 0u, 0u);
+    s.v[i] = v;
+  }
+}
+VBX_DEV void tile_r2s(const Stage2& s, char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int c = tid + 256 * i;
+    *reinterpret_cast<uint4*>(tile + swz_off(c >> 3, c & 7)) = s.v[i];
+  }
+}
+
+// K-contiguous fragment: row (lane&31) of the 32-row block, 8 elements at d = 16*t + 8*hi.
+template <class V8>
+VBX_DEV V8 row_frag(const char* tile, int blk32, int t, int lane) {
+  const int row = blk32 * 32 + (lane & 31);
+  return *reinterpret_cast<const V8*>(tile + swz_off(row, 2 * t + (lane >> 5)));
+}
+
+// Transposed fragment (hardware transpose read): operand X^T[i = d_local][kk = slot], for the 16 rows
+// [rbase, rbase+16) of the tile and the 32 columns [d0, d0+32).  Slot s of lane-half hi is row
+// rbase + (s&3) + 8*(s>>2) + 4*hi.
+VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
+  const int G = lane >> 4, a = lane & 15;
+  const int row = rbase + 4 * (G >> 1) + (a >> 2);
+  const int d = d0 + (G & 1) * 16 + 4 * (a & 3);
+  const char* p = tile + row * 128 + (((d >> 3) ^ (row & 7)) << 4) + (d & 7) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 8 * 128));  // row+8 keeps row&7
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
+  bf16x8 r;
+#pragma unroll
+  for (int s = 0; s < 8; s++) r[s] = (__bf16)p[8 * t2 + s];
+  return r;
+}
+
+VBX_DEV int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
+
+// ============================================================================ forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                          const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                          u16* __restrict__ out, float* __restrict__ lse, int H, int Np,
+                                                          float scale2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * H + h;
+  const u16* kbase = k16 + bh * Np * 64;
+  const u16* vbase = vv + bh * Np * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < Np;
+  const int q = q0 + (lane & 31);
+  const int qc = min(q, Np - 1);
+
+  f16x8 qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const int ntiles = (Np + 63) / 64;
+  Stage2 sk, sv;
+  tile_g2r(sk, kbase, 64, 0, Np, false, tid);
+  tile_g2r(sv, vbase, 64, 0, Np, false, tid);
+  tile_r2s(sk, smem, tid);
+  tile_r2s(sv, smem + TILE16, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; kt++) {
+    const char* Kt = smem + (kt & 1) * 2 * TILE16;
+    const char* Vt = Kt + TILE16;
+    const bool more = kt + 1 < ntiles;
+    if (more) {
+      tile_g2r(sk, kbase, 64, (kt + 1) * 64, Np, false, tid);
+      tile_g2r(sv, vbase, 64, (kt + 1) * 64, Np, false, tid);
+    }
+    if (active) {
+      const int k0 = kt * 64;
+      const int nblk = (Np - k0 > 32) ? 2 : 1;  // the tail tile may hold <= 32 valid keys
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[kb][i] = 0.f;
+        if (kb < nblk) {
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Kt, kb, t, lane), qf[t], s[kb], 0, 0, 0);
+        }
+      }
+      const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
+      if (need_mask) {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int kg = k0 + kb * 32 + acc_row(r, hi);
+            bool ok = kg < Np;
+            if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
+            if (!ok) s[kb][r] = NEG_INF;
+          }
+      }
+      float mx = NEG_INF;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * scale2);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = exp2f(m_run - m_use);
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float p = exp2f(fmaf(s[kb][r], scale2, -m_use));
+          s[kb][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        if (kb < nblk) {
+#pragma unroll
+          for (int t2 = 0; t2 < 2; t2++) {
+            const bf16x8 pf = pack_frag(s[kb], t2);
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, kb * 32 + 16 * t2, db * 32, lane), pf, o[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) {
+      char* Kn = smem + ((kt + 1) & 1) * 2 * TILE16;
+      tile_r2s(sk, Kn, tid);
+      tile_r2s(sv, Kn + TILE16, tid);
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+    if (q < Np) {
+      u16* orow = out + ((long)b * Np + q) * (H * 64) + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          const int d = db * 32 + 8 * g4 + 4 * hi;
+          uint2 pk;
+          pk.x = pack_bf16x2(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
+          pk.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d) = pk;
+        }
+      if (hi == 0) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
+    }
+  }
+}
+
+// ============================================================================ backward: delta
+// delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d]
+__global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
+                                  int Np, long total_chunks) {
+  const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one 8-element chunk per thread
+  const long cc = min(c, total_chunks - 1);
+  const uint4 a = *reinterpret_cast<const uint4*>(o + cc * 8);
+  const uint4 g = *reinterpret_cast<const uint4*>(dout + cc * 8);
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s += bf16_to_f32((u16)(aw[i] & 0xffff)) * bf16_to_f32((u16)(gw[i] & 0xffff));
+    s += bf16_to_f32((u16)(aw[i] >> 16)) * bf16_to_f32((u16)(gw[i] >> 16));
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (c < total_chunks && (c & 7) == 0) {
+    const long rowhead = c >> 3;  // (b*Np + n)*H + h
+    const int hh = (int)(rowhead % H);
+    const long bn = rowhead / H;
+    const int n = (int)(bn % Np);
+    const long bb = bn / Np;
+    delta[(bb * H + hh) * Np + n] = s;
+  }
+}
+
+// ============================================================================ backward: dq
+// grid as forward.  LDS per buffer: K16 | Kb | V tiles.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                             const u16* __restrict__ kb16, const u16* __restrict__ vv,
+                                                             const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             float* __restrict__ dq, int H, int Np, float scale2,
+                                                             float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * H + h;
+  const u16* kbase = k16 + bh * Np * 64;
+  const u16* kbbase = kb16 + bh * Np * 64;
+  const u16* vbase = vv + bh * Np * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < Np;
+  const int q = q0 + (lane & 31);
+  const int qc = min(q, Np - 1);
+
+  f16x8 qf[4];
+  bf16x8 dof[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+    dof[t] = *reinterpret_cast<const bf16x8*>(dout + ((long)b * Np + qc) * (H * 64) + h * 64 + 16 * t + 8 * hi);
+  }
+  const float L2 = lse[bh * Np + qc];
+  const float dlt = delta[bh * Np + qc];
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  const int ntiles = (Np + 63) / 64;
+  Stage2 sk, skb, sv;
+  tile_g2r(sk, kbase, 64, 0, Np, false, tid);
+  tile_g2r(skb, kbbase, 64, 0, Np, false, tid);
+  tile_g2r(sv, vbase, 64, 0, Np, false, tid);
+  tile_r2s(sk, smem, tid);
+  tile_r2s(skb, smem + TILE16, tid);
+  tile_r2s(sv, smem + 2 * TILE16, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; kt++) {
+    const char* Kt = smem + (kt & 1) * 3 * TILE16;
+    const char* Kbt = Kt + TILE16;
+    const char* Vt = Kt + 2 * TILE16;
+    const bool more = kt + 1 < ntiles;
+    if (more) {
+      tile_g2r(sk, kbase, 64, (kt + 1) * 64, Np, false, tid);
+      tile_g2r(skb, kbbase, 64, (kt + 1) * 64, Np, false, tid);
+      tile_g2r(sv, vbase, 64, (kt + 1) * 64, Np, false, tid);
+    }
+    if (active) {
+      const int k0 = kt * 64;
+      const int nblk = (Np - k0 > 32) ? 2 : 1;
+      const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        if (kb < nblk) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Kt, kb, t, lane), qf[t], s, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<bf16x8>(Vt, kb, t, lane), dof[t], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            float p = exp2f(fmaf(s[r], scale2, -L2));
+            if (need_mask) {
+              const int kg = k0 + kb * 32 + acc_row(r, hi);
+              bool ok = kg < Np;
+              if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
+              if (!ok) p = 0.f;
+            }
+            s[r] = p * (dp[r] - dlt);
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < 2; t2++) {
+            const bf16x8 dsf = pack_frag(s, t2);
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kbt, kb * 32 + 16 * t2, db * 32, lane), dsf, acc[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) {
+      char* Kn = smem + ((kt + 1) & 1) * 3 * TILE16;
+      tile_r2s(sk, Kn, tid);
+      tile_r2s(skb, Kn + TILE16, tid);
+      tile_r2s(sv, Kn + 2 * TILE16, tid);
+    }
+    __syncthreads();
+  }
+
+  if (active && q < Np) {
+    float* drow = dq + (bh * Np + q) * 64;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        *reinterpret_cast<float4*>(drow + d) = make_float4(acc[db][4 * g4] * scale, acc[db][4 * g4 + 1] * scale,
+                                                           acc[db][4 * g4 + 2] * scale, acc[db][4 * g4 + 3] * scale);
+      }
+  }
+}
+
+// ============================================================================ backward: dk, dv
+// WG owns 128 keys (4 waves x 32), loops over 64-row q tiles.  LDS per buffer: Q16 | Qb | dO tiles + L2[64] + delta[64].
+constexpr int DKV_BUF = 3 * TILE16 + 512;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __restrict__ q16, const u16* __restrict__ qb16,
+                                                               const u16* __restrict__ k16, const u16* __restrict__ vv,
+                                                               const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dk, u16* __restrict__ dv, int dv_ld, int H,
+                                                               int Np, float scale2, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * H + h;
+  const u16* qbase = q16 + bh * Np * 64;
+  const u16* qbbase = qb16 + bh * Np * 64;
+  const u16* dobase = dout + (long)b * Np * (H * 64) + h * 64;
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const bool active = key0 < Np;
+  const int key = key0 + (lane & 31);
+  const int keyc = min(key, Np - 1);
+  bool kvalid = key < Np;
+  if (kvalid && mask) kvalid = mask[(long)b * Np + key] != 0;
+
+  f16x8 kf[4];
+  bf16x8 vf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    kf[t] = *reinterpret_cast<const f16x8*>(k16 + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
+    vf[t] = *reinterpret_cast<const bf16x8*>(vv + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
+  }
+  f32x16 adk[2], adv[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { adk[0][i] = 0.f; adk[1][i] = 0.f; adv[0][i] = 0.f; adv[1][i] = 0.f; }
+
+  const int ntiles = (Np + 63) / 64;
+  Stage2 sq, sqb, sdo;
+  float sl = 0.f;  // staged L2 (tid<64) / delta (64<=tid<128)
+  auto stage_stats = [&](int qt) {
+    if (tid < 128) {
+      const int n = qt * 64 + (tid & 63);
+      if (tid < 64) sl = (n < Np) ? lse[bh * Np + n] : 1e30f;
+      else sl = (n < Np) ? delta[bh * Np + n] : 0.f;
+    }
+  };
+  tile_g2r(sq, qbase, 64, 0, Np, false, tid);
+  tile_g2r(sqb, qbbase, 64, 0, Np, false, tid);
+  tile_g2r(sdo, dobase, H * 64, 0, Np, true, tid);
+  stage_stats(0);
+  tile_r2s(sq, smem, tid);
+  tile_r2s(sqb, smem + TILE16, tid);
+  tile_r2s(sdo, smem + 2 * TILE16, tid);
+  if (tid < 128) reinterpret_cast<float*>(smem + 3 * TILE16)[tid] = sl;
+  __syncthreads();
+
+  for (int qt = 0; qt < ntiles; qt++) {
+    const char* Qt = smem + (qt & 1) * DKV_BUF;
+    const char* Qbt = Qt + TILE16;
+    const char* dOt = Qt + 2 * TILE16;
+    const float* stats = reinterpret_cast<const float*>(Qt + 3 * TILE16);
+    const bool more = qt + 1 < ntiles;
+    if (more) {
+      tile_g2r(sq, qbase, 64, (qt + 1) * 64, Np, false, tid);
+      tile_g2r(sqb, qbbase, 64, (qt + 1) * 64, Np, false, tid);
+      tile_g2r(sdo, dobase, H * 64, (qt + 1) * 64, Np, true, tid);
+      stage_stats(qt + 1);
+    }
+    if (active) {
+      const int nblk = (Np - qt * 64 > 32) ? 2 : 1;
+#pragma unroll
+      for (int qb = 0; qb < 2; qb++) {
+        if (qb < nblk) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
+          // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (A = tile rows, B = per-lane key fragments)
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Qt, qb, t, lane), kf[t], s, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<bf16x8>(dOt, qb, t, lane), vf[t], dp, 0, 0, 0);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; g4++) {
+            const int ql = qb * 32 + 8 * g4 + 4 * hi;
+            const float4 l4 = *reinterpret_cast<const float4*>(stats + ql);
+            const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + ql);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int r = 4 * g4 + j;
+              float p = exp2f(fmaf(s[r], scale2, -lv[j]));
+              if (!kvalid) p = 0.f;
+              s[r] = p;
+              dp[r] = p * (dp[r] - dv4[j]);
+            }
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < 2; t2++) {
+            const bf16x8 pf = pack_frag(s, t2);
+            const bf16x8 dsf = pack_frag(dp, t2);
+#pragma unroll
+            for (int db = 0; db < 2; db++) {
+              adv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOt, qb * 32 + 16 * t2, db * 32, lane), pf, adv[db], 0, 0, 0);
+              adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qbt, qb * 32 + 16 * t2, db * 32, lane), dsf, adk[db], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (more) {
+      char* Qn = smem + ((qt + 1) & 1) * DKV_BUF;
+      tile_r2s(sq, Qn, tid);
+      tile_r2s(sqb, Qn + TILE16, tid);
+      tile_r2s(sdo, Qn + 2 * TILE16, tid);
+      if (tid < 128) reinterpret_cast<float*>(Qn + 3 * TILE16)[tid] = sl;
+    }
+    __syncthreads();
+  }
+
+  if (active && key < Np) {
+    float* krow = dk + (bh * Np + key) * 64;
+    u16* vrow = dv + ((long)b * Np + key) * dv_ld + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        *reinterpret_cast<float4*>(krow + d) = make_float4(adk[db][4 * g4] * scale, adk[db][4 * g4 + 1] * scale,
+                                                           adk[db][4 * g4 + 2] * scale, adk[db][4 * g4 + 3] * scale);
+        uint2 pk;
+        pk.x = pack_bf16x2(adv[db][4 * g4 + 0], adv[db][4 * g4 + 1]);
+        pk.y = pack_bf16x2(adv[db][4 * g4 + 2], adv[db][4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(vrow + d) = pk;
+      }
+  }
+}
+
+}  // namespace
+
+static const float LOG2E = 1.4426950408889634f;
+
+extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, float* lse,
+                            int B, int H, int Np, float scale, void* stream) {
+  VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
+  dim3 grid(cdiv(Np, 128), H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
+                     (const u16*)v, mask, (u16*)out, lse, H, Np, scale * LOG2E);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                            const uint8_t* mask, const void* out, const void* dout, const float* lse, float* delta,
+                            float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale, void* stream) {
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 4 == 0, "vbx_attn_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
+    attr = true;
+  }
+  const long chunks = (long)B * Np * H * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout, delta,
+                     H, Np, chunks);
+  VBX_LAUNCH_CHECK();
+  dim3 grid(cdiv(Np, 128), H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
+                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
+                     (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
+                     scale * LOG2E, scale);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,81 @@
+// Shared device/host helpers for libvbx_hip.so (gfx950 only -- no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vbx.h"
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define VBX_DEV __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---- host side error plumbing -------------------------------------------------------------
+void vbx_set_error(const char* fmt, ...);
+#define VBX_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      vbx_set_error(__VA_ARGS__);         \
+      return VBX_EINVAL;                  \
+    }                                     \
+  } while (0)
+#define VBX_LAUNCH_CHECK()                                                  \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      vbx_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 / fp16 scalar helpers -----------------------------------------------------------
+VBX_DEV float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+VBX_DEV u16 f32_to_bf16(float f) {  // round-to-nearest-even (NaN preserved)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(u16, b);
+}
+VBX_DEV unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+VBX_DEV u16 f32_to_f16(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(u16, h);
+}
+VBX_DEV float f16_to_f32(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+VBX_DEV unsigned pack_f16x2(float lo, float hi) { return (unsigned)f32_to_f16(lo) | ((unsigned)f32_to_f16(hi) << 16); }
+
+// ---- wave64 reductions ----------------------------------------------------------------------
+VBX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+VBX_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative -- nn.GELU()/F.gelu default (voicebox_pytorch.py:217,340)
+VBX_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+VBX_DEV float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// GEGLU packed-row map: packed row p -> reference row (or -1 when it is padding).
+// Packed layout: blocks of 128 rows; first 64 = "x" rows f0..f0+63, last 64 = "gate" rows F+f0..F+f0+63.
+__host__ __device__ inline int geglu_row_unmap(int p, int F) {
+  int blk = p >> 7, w = p & 127;
+  int f = blk * 64 + (w & 63);
+  if (f >= F) return -1;
+  return (w < 64) ? f : F + f;
+}

@@ -1,0 +1,440 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.  One kernel template, three operand layouts:
+//   NT (nn.Linear forward), NN (dgrad), TN (wgrad, split-K).
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.
+// K-contiguous operands are staged [row][k] with a 16-byte XOR swizzle and read with ds_read_b128;
+// K-strided operands (the transposed ones of NN/TN) are staged [k][col] and read with the gfx950
+// hardware transpose read ds_read_b64_tr_b16, so no transposed copies of weights or activations
+// ever exist in HBM.  The fp32 C tile is staged through LDS so every epilogue stores 16/32 B per lane.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int KS_STRIDE = 272;               // bytes per k-row of a K-strided tile (128 bf16 + 16 B pad)
+constexpr int TILE_BYTES = BK * KS_STRIDE;   // 17408 (a K-contiguous tile needs 16384)
+constexpr int CS_LD = 132;                   // floats per row of the staged C tile
+constexpr int GEMM_LDS = 4 * TILE_BYTES;     // 69632 >= 128*132*4
+static_assert(GEMM_LDS >= BM * CS_LD * 4, "C staging must fit");
+
+struct Staged {
+  uint4 v[4];
+};
+
+// global -> registers.  MODE 0: tile [128 outer][64 k] (k contiguous).  MODE 1: tile [64 k][128 outer].
+template <int MODE>
+VBX_DEV void g2r(Staged& st, const u16* __restrict__ X, long ld, int o0, int olim, int k0, int kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + 256 * i;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (MODE == 0) {
+      const int row = c >> 3, ch = c & 7;
+      const int go = o0 + row, gk = k0 + ch * 8;
+      if (go < olim && gk < kend) v = *reinterpret_cast<const uint4*>(X + (long)go * ld + gk);
+    } else {
+      const int kr = c >> 4, ch = c & 15;
+      const int gk = k0 + kr, go = o0 + ch * 8;
+      if (gk < kend && go < olim) v = *reinterpret_cast<const uint4*>(X + (long)gk * ld + go);
+    }
+    st.v[i] = v;
+  }
+}
+
+template <int MODE>
+VBX_DEV void r2s(const Staged& st, char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + 256 * i;
+    int off;
+    if (MODE == 0) {
+      const int row = c >> 3, ch = c & 7;
+      off = row * 128 + ((ch ^ (row & 7)) << 4);
+    } else {
+      const int kr = c >> 4, ch = c & 15;
+      off = kr * KS_STRIDE + ch * 16;
+    }
+    *reinterpret_cast<uint4*>(tile + off) = st.v[i];
+  }
+}
+
+// MFMA 16x16x32 operand fragment for the 16 outer indices [woff + s*16, +16) and k-step kk (32 k).
+// lane l holds outer index (l&15) and k = (l>>4)*8 .. +8.
+template <int MODE>
+VBX_DEV bf16x8 frag(const char* tile, int woff, int s, int kk, int lane) {
+  if (MODE == 0) {
+    const int r = woff + s * 16 + (lane & 15);
+    const int ch = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((ch ^ (r & 7)) << 4));
+  } else {
+    // ds_read_b64_tr_b16: within each 16-lane group, lane a receives element (a&3) of the 8 bytes
+    // addressed by lanes 4j + (a>>2), j = 0..3.  With supplier lane s pointing at
+    // [k = k0 + (s>>2)][col = c0 + 4*(s&3)] lane a therefore receives [k0 + j][c0 + a].
+    const int g = lane >> 4, a = lane & 15;
+    const int kr = kk * 32 + g * 8 + (a >> 2);
+    const int col = woff + s * 16 + 4 * (a & 3);
+    const char* p = tile + kr * KS_STRIDE + col * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 4 * KS_STRIDE));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  }
+}
+
+struct GemmParams {
+  const u16* A;
+  const u16* B;
+  int M, N, K;
+  long lda, ldb;
+  int kchunk;  // K range handled by one blockIdx.y (multiple of BK); == K when not split
+  int tiles_m;
+};
+
+template <int MA, int MB, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  // LDS map: [A buf0][B buf0][A buf1][B buf1]
+#define TILE_A(buf) (smem + (buf) * 2 * TILE_BYTES)
+#define TILE_B(buf) (smem + (buf) * 2 * TILE_BYTES + TILE_BYTES)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  Staged sa, sb;
+  if (nt > 0) {
+    g2r<MA>(sa, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+    g2r<MB>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+    r2s<MA>(sa, TILE_A(0), tid);
+    r2s<MB>(sb, TILE_B(0), tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; t++) {
+    const int cur = t & 1;
+    const bool more = (t + 1) < nt;
+    if (more) {  // issue next tile's global loads before the MFMA phase (latency hides under it)
+      g2r<MA>(sa, p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid);
+      g2r<MB>(sb, p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) af[s] = frag<MA>(TILE_A(cur), wm * 64, s, kk, lane);
+#pragma unroll
+      for (int s = 0; s < 4; s++) bfr[s] = frag<MB>(TILE_B(cur), wn * 64, s, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      r2s<MA>(sa, TILE_A(cur ^ 1), tid);
+      r2s<MB>(sb, TILE_B(cur ^ 1), tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- stage the fp32 C tile through LDS (C layout: col = lane&15, row = (lane>>4)*4 + reg) ----
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int col = wn * 64 + j * 16 + (lane & 15);
+        Cs[row * CS_LD + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  epi(Cs, m0, n0, tid, split, p.M, p.N);
+}
+
+VBX_DEV void load8(const float* Cs, int row, int cc, float v[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8);
+  const float4 b = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8 + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+VBX_DEV uint4 pack8_bf16(const float v[8]) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+VBX_DEV uint4 pack8_f16(const float v[8]) {
+  return make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------------------- epilogues
+struct EpiBF16 {
+  u16* C; long ldc; const float* bias;
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 16 + (tid >> 4), cc = tid & 15;
+      const int gr = m0 + row, gc = n0 + cc * 8;
+      if (gr < M && gc < N) {
+        float v[8];
+        load8(Cs, row, cc, v);
+        if (bias) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
+        }
+        *reinterpret_cast<uint4*>(C + (long)gr * ldc + gc) = pack8_bf16(v);
+      }
+    }
+  }
+};
+
+struct EpiF32 {
+  float* C; long ldc; const float* bias; const float* resid; u16* C2;
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 16 + (tid >> 4), cc = tid & 15;
+      const int gr = m0 + row, gc = n0 + cc * 8;
+      if (gr < M && gc < N) {
+        float v[8];
+        load8(Cs, row, cc, v);
+        const long o = (long)gr * ldc + gc;
+        if (bias) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
+        }
+        if (resid) {
+          const float4 a = *reinterpret_cast<const float4*>(resid + o);
+          const float4 b = *reinterpret_cast<const float4*>(resid + o + 4);
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (C2) *reinterpret_cast<uint4*>(C2 + o) = pack8_bf16(v);
+      }
+    }
+  }
+};
+
+struct EpiSplitK {
+  float* C;
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int split, int M, int N) const {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 16 + (tid >> 4), cc = tid & 15;
+      const int gr = m0 + row, gc = n0 + cc * 8;
+      if (gr < M && gc < N) {
+        float v[8];
+        load8(Cs, row, cc, v);
+        float* o = C + ((long)split * M + gr) * N + gc;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+  }
+};
+
+// FeedForward[0] + GEGLU (voicebox_pytorch.py:338-340,345).  Weight rows are packed so that every
+// 128-column tile holds 64 "x" columns followed by their 64 "gate" columns.
+struct EpiGEGLU {
+  u16* G; long ldg; const float* bias; u16* H1; long ldh;
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 32 + (tid >> 3), cc = tid & 7;
+      const int gr = m0 + row;
+      if (gr < M) {
+        float x[8], g[8], o[8];
+        load8(Cs, row, cc, x);
+        load8(Cs, row, cc + 8, g);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float xv = x[i] + bias[n0 + cc * 8 + i];
+          const float gv = g[i] + bias[n0 + 64 + cc * 8 + i];
+          o[i] = gelu_erf(gv) * xv;
+        }
+        *reinterpret_cast<uint4*>(G + (long)gr * ldg + (n0 >> 1) + cc * 8) = pack8_bf16(o);
+      }
+    }
+    if (H1) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int row = it * 16 + (tid >> 4), cc = tid & 15;
+        const int gr = m0 + row, gc = n0 + cc * 8;
+        if (gr < M) {
+          float v[8];
+          load8(Cs, row, cc, v);
+#pragma unroll
+          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
+          *reinterpret_cast<uint4*>(H1 + (long)gr * ldh + gc) = pack8_bf16(v);
+        }
+      }
+    }
+  }
+};
+
+// to_qkv + MultiheadRMSNorm + rotary, written head-major (voicebox_pytorch.py:320-328).
+struct EpiQKV {
+  int Np, H;
+  float qk_scale;
+  const float* qg; const float* kg; const float* rc; const float* rs;
+  u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn;
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
+    const int I = H * 64;
+    const int which = n0 / I;
+    const int hbase = (n0 % I) >> 6;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 16 + (tid >> 4), cc = tid & 15;
+      const int gr = m0 + row;
+      const bool valid = gr < M;
+      const int grc = valid ? gr : (M - 1);
+      const int b = grc / Np, n = grc - b * Np;
+      const int head = hbase + (cc >> 3);
+      const int d0 = (cc & 7) * 8;
+      float t[8];
+      load8(Cs, row, cc, t);
+      const long o = (((long)b * H + head) * Np + n) * 64 + d0;
+      if (which == 2) {
+        if (valid) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
+        continue;
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) ss += t[i] * t[i];
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      if (qk_scale > 0.f) {
+        const float* gam = (which == 0 ? qg : kg) + head * 64 + d0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = t[i] * rinv * qk_scale * gam[i];
+      }
+      float out[8];
+      const float sgn = (d0 < 32) ? -1.f : 1.f;
+      const float* cp = rc + (long)n * 32 + (d0 & 31);
+      const float* sp = rs + (long)n * 32 + (d0 & 31);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float partner = __shfl_xor(t[i], 4, 64);
+        out[i] = t[i] * cp[i] + sgn * partner * sp[i];
+      }
+      if (valid) {
+        *reinterpret_cast<uint4*>((which == 0 ? q16 : k16) + o) = pack8_f16(out);
+        u16* bcopy = (which == 0 ? qb : kb);
+        if (bcopy) *reinterpret_cast<uint4*>(bcopy + o) = pack8_bf16(out);
+        float* rn = (which == 0 ? qrn : krn);
+        if (rn && (cc & 7) == 0) rn[((long)b * H + head) * Np + n] = rinv;
+      }
+    }
+  }
+};
+
+template <int MA, int MB, class Epi>
+int launch(const GemmParams& p, const Epi& epi, int splits, hipStream_t st) {
+  static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
+  auto kern = gemm_kernel<MA, MB, Epi>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * cdiv(p.N, BN), splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), GEMM_LDS, st, p, epi);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int M, int N, float* __restrict__ dst,
+                                     int dst_rows, int dst_cols, long dst_ld, int rowmap, int F, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / N), c = (int)(i - (long)r * N);
+    int dr = r;
+    if (rowmap == 1) dr = geglu_row_unmap(r, F);
+    if (dr < 0 || dr >= dst_rows || c >= dst_cols) continue;
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += slabs[(long)k * total + i];
+    float* o = dst + (long)dr * dst_ld + c;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+
+}  // namespace
+
+extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  VBX_REQUIRE(d && d->A && d->B, "vbx_gemm: null operand");
+  VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
+  VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "vbx_gemm: leading dims must be multiples of 8 (16-byte rows)");
+  VBX_REQUIRE(d->N % 8 == 0, "vbx_gemm: N must be a multiple of 8");
+  GemmParams p;
+  p.A = (const u16*)d->A; p.B = (const u16*)d->B;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
+  p.kchunk = d->K; p.tiles_m = cdiv(d->M, BM);
+  if (d->mode == VBX_GEMM_NT) VBX_REQUIRE(d->K % 8 == 0, "vbx_gemm NT: K must be a multiple of 8");
+  if (d->mode == VBX_GEMM_TN) VBX_REQUIRE(d->M % 8 == 0, "vbx_gemm TN: M must be a multiple of 8");
+
+  switch (d->epilogue) {
+    case VBX_EPI_BF16: {
+      VBX_REQUIRE(d->C && d->ldc % 8 == 0, "vbx_gemm BF16: bad C/ldc");
+      EpiBF16 e{(u16*)d->C, d->ldc, d->bias};
+      if (d->mode == VBX_GEMM_NT) return launch<0, 0>(p, e, 1, st);
+      if (d->mode == VBX_GEMM_NN) return launch<0, 1>(p, e, 1, st);
+      break;
+    }
+    case VBX_EPI_F32: {
+      VBX_REQUIRE(d->C && d->ldc % 8 == 0, "vbx_gemm F32: bad C/ldc");
+      EpiF32 e{(float*)d->C, d->ldc, d->bias, d->resid, (u16*)d->C2};
+      if (d->mode == VBX_GEMM_NT) return launch<0, 0>(p, e, 1, st);
+      if (d->mode == VBX_GEMM_NN) return launch<0, 1>(p, e, 1, st);
+      break;
+    }
+    case VBX_EPI_QKV: {
+      VBX_REQUIRE(d->mode == VBX_GEMM_NT, "vbx_gemm QKV: NT only");
+      VBX_REQUIRE(d->H > 0 && d->H % 2 == 0 && d->N == 3 * d->H * 64, "vbx_gemm QKV: need even H and N == 3*H*64");
+      VBX_REQUIRE(d->Np > 0 && d->M % d->Np == 0, "vbx_gemm QKV: M must be B*Np");
+      VBX_REQUIRE(d->q16 && d->k16 && d->v && d->rot_cos && d->rot_sin, "vbx_gemm QKV: null output/table");
+      VBX_REQUIRE(d->qk_scale <= 0.f || (d->q_gamma && d->k_gamma), "vbx_gemm QKV: qk-norm needs gammas");
+      EpiQKV e{d->Np, d->H, d->qk_scale, d->q_gamma, d->k_gamma, d->rot_cos, d->rot_sin,
+               (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm};
+      return launch<0, 0>(p, e, 1, st);
+    }
+    case VBX_EPI_GEGLU: {
+      VBX_REQUIRE(d->mode == VBX_GEMM_NT, "vbx_gemm GEGLU: NT only");
+      VBX_REQUIRE(d->N % 128 == 0 && d->bias && d->C, "vbx_gemm GEGLU: N must be a multiple of 128, bias/C required");
+      EpiGEGLU e{(u16*)d->C, d->ldc, d->bias, (u16*)d->C2, d->N};
+      return launch<0, 0>(p, e, 1, st);
+    }
+    case VBX_EPI_SPLITK: {
+      VBX_REQUIRE(d->mode == VBX_GEMM_TN && d->C && d->splits >= 1, "vbx_gemm SPLITK: TN only");
+      int kc = cdiv(cdiv(d->K, d->splits), BK) * BK;
+      p.kchunk = kc;
+      EpiSplitK e{(float*)d->C};
+      return launch<1, 1>(p, e, d->splits, st);
+    }
+    default: break;
+  }
+  vbx_set_error("vbx_gemm: unsupported mode/epilogue combination (%d,%d)", d->mode, d->epilogue);
+  return VBX_EUNSUPPORTED;
+}
+
+extern "C" int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, float* dst, int dst_rows, int dst_cols,
+                                 int dst_ld, int rowmap, int F, int accumulate, void* stream) {
+  VBX_REQUIRE(slabs && dst && splits >= 1 && M > 0 && N > 0, "vbx_splitk_reduce: bad args");
+  const long total = (long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, splits, M, N, dst,
+                     dst_rows, dst_cols, (long)dst_ld, rowmap, F, accumulate);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,321 @@
+// RMSNorm / AdaptiveRMSNorm forward+backward and the backward of MultiheadRMSNorm+rotary.
+// Memory-bound row kernels: one wave64 per row, float4 (16 B/lane) loads, wave-shuffle reductions.
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
+
+// ---------------------------------------------------------------- forward
+// y = x / max(|x|, 1e-12) * sqrt(D) * gamma[b] (+ beta[b])        (voicebox_pytorch.py:246-247, 270-276)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, long gb_stride,
+                                                           u16* __restrict__ y, int B, int Np, int n0, int rpb, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2;
+  const float sqrtD = sqrtf((float)D);
+  const long rows = (long)B * rpb;
+  for (long ri = (long)blockIdx.x * 4 + wave; ri < rows; ri += (long)gridDim.x * 4) {
+    const int b = (int)(ri / rpb), j = (int)(ri - (long)b * rpb);
+    const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
+    float4 v[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        v[i] = xr[c];
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      }
+    }
+    ss = wave_sum(ss);
+    const float r = sqrtD / fmaxf(sqrtf(ss), 1e-12f);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
+    const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)b * gb_stride) : nullptr;
+    uint2* yr = reinterpret_cast<uint2*>(y + ri * D);
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const float4 g = g4[c];
+        float4 o = make_float4(v[i].x * r * g.x, v[i].y * r * g.y, v[i].z * r * g.z, v[i].w * r * g.w);
+        if (b4) {
+          const float4 bb = b4[c];
+          o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+        }
+        yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// u = x/|x| ; y = sqrt(D) u*gamma + beta
+// dgamma[b] += sqrt(D) u*dy ; dbeta[b] += dy ; du = sqrt(D) gamma*dy ; dx = (du - u (u.du)) / |x|
+// grid (chunks, B); each block handles 16 rows of one batch; partials -> part[b][chunk][2][D]
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           long gb_stride, const u16* __restrict__ dy,
+                                                           const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                           u16* __restrict__ dxb, float* __restrict__ part, int Np, int n0,
+                                                           int rpb, int D) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
+  const int D4 = D >> 2;
+  const float sqrtD = sqrtf((float)D);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
+  float4 ag[MAXC], ab[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  for (int k = 0; k < 4; k++) {
+    const int j = chunk * 16 + wave + 4 * k;
+    if (j >= rpb) break;
+    const long xrow = ((long)b * Np + n0 + j) * D;
+    const long drow = ((long)b * rpb + j) * D;
+    const float4* xr = reinterpret_cast<const float4*>(x + xrow);
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow);
+    float4 xv[MAXC], dv[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        xv[i] = xr[c];
+        const uint2 p = dyr[c];
+        dv[i] = make_float4(bf16_to_f32((u16)(p.x & 0xffff)), bf16_to_f32((u16)(p.x >> 16)),
+                            bf16_to_f32((u16)(p.y & 0xffff)), bf16_to_f32((u16)(p.y >> 16)));
+        ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const float4 g = g4[c];
+        // u
+        xv[i].x *= inv; xv[i].y *= inv; xv[i].z *= inv; xv[i].w *= inv;
+        ag[i].x += sqrtD * xv[i].x * dv[i].x; ag[i].y += sqrtD * xv[i].y * dv[i].y;
+        ag[i].z += sqrtD * xv[i].z * dv[i].z; ag[i].w += sqrtD * xv[i].w * dv[i].w;
+        ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+        // du
+        dv[i].x *= sqrtD * g.x; dv[i].y *= sqrtD * g.y; dv[i].z *= sqrtD * g.z; dv[i].w *= sqrtD * g.w;
+        dot += xv[i].x * dv[i].x + xv[i].y * dv[i].y + xv[i].z * dv[i].z + xv[i].w * dv[i].w;
+      }
+    }
+    dot = wave_sum(dot);
+    const float4* din = dx_in ? reinterpret_cast<const float4*>(dx_in + xrow) : nullptr;
+    float4* dout = reinterpret_cast<float4*>(dx_out + xrow);
+    uint2* dbo = dxb ? reinterpret_cast<uint2*>(dxb + xrow) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        float4 o = make_float4((dv[i].x - xv[i].x * dot) * inv, (dv[i].y - xv[i].y * dot) * inv,
+                               (dv[i].z - xv[i].z * dot) * inv, (dv[i].w - xv[i].w * dot) * inv);
+        if (din) {
+          const float4 a = din[c];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        dout[c] = o;
+        if (dbo) dbo[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      }
+    }
+  }
+  // cross-wave reduction of the gamma/beta partials
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int i = 0; i < MAXC; i++) {
+    const int c = lane + 64 * i;
+    if (c < D4) {
+      r4[(wave * 2 + 0) * D4 + c] = ag[i];
+      r4[(wave * 2 + 1) * D4 + c] = ab[i];
+    }
+  }
+  __syncthreads();
+  float4* p4 = reinterpret_cast<float4*>(part + ((long)b * chunks + chunk) * 2 * D);
+  for (int idx = threadIdx.x; idx < 2 * D4; idx += 256) {
+    const int which = idx / D4, c = idx - which * D4;
+    float4 s = r4[(0 * 2 + which) * D4 + c];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const float4 t = r4[(w * 2 + which) * D4 + c];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    p4[which * D4 + c] = s;
+  }
+}
+
+// out[b][which][d] = sum_chunk part[b][chunk][which][d]   (optionally also summed over b)
+__global__ void reduce_norm_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long out_b_stride,
+                                            int B, int chunks, int D, int sum_batch) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*D
+  if (idx >= 2 * D) return;
+  if (sum_batch) {
+    float s = 0.f;
+    for (int b = 0; b < B; b++)
+      for (int c = 0; c < chunks; c++) s += part[((long)b * chunks + c) * 2 * D + idx];
+    out[idx] = s;
+  } else {
+    const int b = blockIdx.y;
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += part[((long)b * chunks + c) * 2 * D + idx];
+    out[(long)b * out_b_stride + idx] = s;
+  }
+}
+
+// ---------------------------------------------------------------- MultiheadRMSNorm + rotary backward
+// forward (per (b,h,n), vector t in R^64):  u = t/|t| ; y = u * qk_scale * gamma[h] ; qhat = R(n) y
+// R(n) y [d] = y[d] c[d%32] + (d<32 ? -y[d+32] : y[d-32]) s[d%32]
+// grid (H, B, 2*NSPLIT): z = which*NSPLIT + split.  8 lanes per row, 8 d's per lane.
+constexpr int NSPLIT = 4;
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
+                                                              const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                              const float* __restrict__ qrn, const float* __restrict__ krn,
+                                                              const float* __restrict__ qg, const float* __restrict__ kg,
+                                                              const float* __restrict__ rc, const float* __restrict__ rs,
+                                                              float qk_scale, u16* __restrict__ dqkv, int ld,
+                                                              float* __restrict__ gpart, int B, int H, int Np) {
+  __shared__ float red[32][64];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int which = blockIdx.z / NSPLIT, split = blockIdx.z % NSPLIT;
+  const float* dsrc = which == 0 ? dq : dk;
+  const u16* hsrc = which == 0 ? q16 : k16;
+  const float* rn = which == 0 ? qrn : krn;
+  const float* gam = (which == 0 ? qg : kg);
+  const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;  // 32 row slots
+  const int d0 = sub * 8;
+  const bool lowhalf = d0 < 32;
+  const long bh = (long)b * H + h;
+  const int per = (Np + NSPLIT - 1) / NSPLIT;
+  const int nbeg = split * per, nend = min(Np, nbeg + per);
+  float gacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) gacc[i] = 0.f;
+  float gm[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) gm[i] = (qk_scale > 0.f) ? gam[h * 64 + d0 + i] : 1.f;
+
+  for (int nb = nbeg; nb < nend; nb += 32) {
+    const int n = nb + slot;
+    const bool valid = n < nend;
+    const int nc = valid ? n : (nend - 1);
+    const long ro = (bh * Np + nc) * 64 + d0;
+    float g[8], qh[8];
+    {
+      const float4 a = *reinterpret_cast<const float4*>(dsrc + ro);
+      const float4 c = *reinterpret_cast<const float4*>(dsrc + ro + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = c.x; g[5] = c.y; g[6] = c.z; g[7] = c.w;
+      const uint4 hq = *reinterpret_cast<const uint4*>(hsrc + ro);
+      const unsigned w[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        qh[2 * i] = f16_to_f32((u16)(w[i] & 0xffff));
+        qh[2 * i + 1] = f16_to_f32((u16)(w[i] >> 16));
+      }
+    }
+    const float* cp = rc + (long)nc * 32 + (d0 & 31);
+    const float* sp = rs + (long)nc * 32 + (d0 & 31);
+    float dy[8], yv[8];
+    const float sgn = lowhalf ? 1.f : -1.f;  // transpose rotation
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float gp = __shfl_xor(g[i], 4, 64);
+      const float qp = __shfl_xor(qh[i], 4, 64);
+      dy[i] = g[i] * cp[i] + sgn * gp * sp[i];
+      yv[i] = qh[i] * cp[i] + sgn * qp * sp[i];
+    }
+    float out[8];
+    if (qk_scale > 0.f) {
+      const float rinv = rn[bh * Np + nc];
+      float u[8], du[8], dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float sg = qk_scale * gm[i];
+        u[i] = (fabsf(sg) > 1e-20f) ? yv[i] / sg : 0.f;
+        if (valid) gacc[i] += dy[i] * u[i] * qk_scale;
+        du[i] = dy[i] * sg;
+        dot += u[i] * du[i];
+      }
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+#pragma unroll
+      for (int i = 0; i < 8; i++) out[i] = (du[i] - u[i] * dot) * rinv;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) out[i] = dy[i];
+    }
+    if (valid) {
+      u16* o = dqkv + ((long)b * Np + n) * ld + which * H * 64 + h * 64 + d0;
+      *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(out[0], out[1]), pack_bf16x2(out[2], out[3]),
+                                                pack_bf16x2(out[4], out[5]), pack_bf16x2(out[6], out[7]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[slot][d0 + i] = gacc[i];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int r = 0; r < 32; r++) s += red[r][threadIdx.x];
+    gpart[(((long)which * B * NSPLIT + (long)b * NSPLIT + split) * H + h) * 64 + threadIdx.x] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16, int B,
+                               int Np, int n0, int rows_per_batch, int D, void* stream) {
+  VBX_REQUIRE(x && gamma && y_bf16, "vbx_rmsnorm_fwd: null pointer");
+  VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+  VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_fwd: bad row range");
+  const long rows = (long)B * rows_per_batch;
+  int blocks = cdiv(rows, 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
+                     (u16*)y_bf16, B, Np, n0, rows_per_batch, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
+                               float* dx_out, void* dxb_bf16, float* part, int B, int Np, int n0, int rows_per_batch, int D,
+                               void* stream) {
+  VBX_REQUIRE(x && gamma && dy_bf16 && dx_out && part, "vbx_rmsnorm_bwd: null pointer");
+  VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+  VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_bwd: bad row range");
+  dim3 grid(cdiv(rows_per_batch, 16), B);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 4 * 2 * D * sizeof(float), (hipStream_t)stream, x, gamma,
+                     gb_stride, (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, Np, n0, rows_per_batch, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D,
+                                        int sum_batch, void* stream) {
+  VBX_REQUIRE(part && out && B > 0 && chunks > 0 && D > 0, "vbx_reduce_norm_partials: bad args");
+  dim3 grid(cdiv(2 * D, 256), sum_batch ? 1 : B);
+  hipLaunchKernelGGL(reduce_norm_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, out_b_stride, B,
+                     chunks, D, sum_batch);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_qknorm_rope_bwd_gpart_rows(int B) { return B * NSPLIT; }
+
+extern "C" int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
+                                   const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
+                                   const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H,
+                                   int Np, void* stream) {
+  VBX_REQUIRE(dq && dk && q16 && k16 && rot_cos && rot_sin && dqkv && gpart, "vbx_qknorm_rope_bwd: null pointer");
+  VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma), "vbx_qknorm_rope_bwd: qk-norm needs stats");
+  VBX_REQUIRE(ld % 8 == 0, "vbx_qknorm_rope_bwd: ld must be a multiple of 8");
+  dim3 grid(H, B, 2 * NSPLIT);
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dq, dk, (const u16*)q16,
+                     (const u16*)k16, q_rnorm, k_rnorm, q_gamma, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, gpart,
+                     B, H, Np);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,822 @@
+// Memory-bound / small kernels of the VoiceBox hot path (everything that is not a big GEMM, a norm or
+// attention): embed packing, conv positional embedding, time embedding, adaLN projections, GEGLU
+// backward, column sums, masked MSE, CFM inputs, ODE axpy, weight packing, Adam, grad-norm.
+#include "common.hpp"
+
+namespace {
+
+VBX_DEV void unpack8_bf16(const uint4 p, float v[8]) {
+  const unsigned w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = bf16_to_f32((u16)(w[i] & 0xffff));
+    v[2 * i + 1] = bf16_to_f32((u16)(w[i] >> 16));
+  }
+}
+VBX_DEV uint4 pack8(const float v[8]) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
+// ---------------------------------------------------------------- embed input packing
+__global__ void pack_embed_kernel(const float* __restrict__ x, const float* __restrict__ cond,
+                                  const uint8_t* __restrict__ cmask, u16* __restrict__ out, long rows, int D) {
+  const int cpr = D / 8;  // chunks per half row
+  const long total = rows * 2 * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / (2 * cpr);
+    const int c = (int)(i - row * 2 * cpr);
+    const bool second = c >= cpr;
+    const int d = (second ? c - cpr : c) * 8;
+    const float* src = (second ? cond : x) + row * D + d;
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (second && cmask && cmask[row]) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = 0.f;
+    }
+    *reinterpret_cast<uint4*>(out + row * 2 * D + (second ? D : 0) + d) = pack8(v);
+  }
+}
+
+// ---------------------------------------------------------------- conv positional embedding
+// tile: 64 frames x 64 channels per block; thread (dl = tid&63, ng = tid>>6) computes 16 frames of channel dl.
+constexpr int CT = 64;
+template <int MODE, int KS>  // MODE 0: forward -> xs ; 1: dpre = dxs * m * gelu'(pre) -> out.  KS: compile-time kernel size
+__global__ __launch_bounds__(256) void convpos_fwd_kernel(const float* __restrict__ e, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const uint8_t* __restrict__ mask,
+                                                          const float* __restrict__ dxs, float* __restrict__ out, int N,
+                                                          int R, int D) {
+  extern __shared__ float tile[];  // [(CT + ks - 1)][64]
+  constexpr int ks = KS;
+  const int half = ks / 2;
+  const int n0 = blockIdx.x * CT, dbase = blockIdx.y * 64, b = blockIdx.z;
+  const int dl = threadIdx.x & 63, ng = threadIdx.x >> 6;
+  const int d = dbase + dl;
+  const int rows = CT + ks - 1;
+  for (int r = ng; r < rows; r += 4) {
+    const int n = n0 + r - half;
+    float v = 0.f;
+    if (n >= 0 && n < N && d < D && (!mask || mask[(long)b * N + n])) v = e[((long)b * N + n) * D + d];
+    tile[r * 64 + dl] = v;
+  }
+  __syncthreads();
+  if (d >= D) return;
+  float wr[KS];
+#pragma unroll
+  for (int k = 0; k < ks; k++) wr[k] = w[(long)d * ks + k];
+  const float bb = bias[d];
+  const int Np = N + R;
+  for (int i = 0; i < 16; i++) {
+    const int nl = ng * 16 + i, n = n0 + nl;
+    if (n >= N) break;
+    float acc = bb;
+#pragma unroll
+    for (int k = 0; k < ks; k++) acc += wr[k] * tile[(nl + k) * 64 + dl];
+    const bool m = !mask || mask[(long)b * N + n];
+    if (MODE == 0) {
+      // residual uses the UNMASKED e (voicebox_pytorch.py:1080 adds x, conv masks internally)
+      const float ev = e[((long)b * N + n) * D + d];
+      out[((long)b * Np + R + n) * D + d] = ev + (m ? gelu_erf(acc) : 0.f);
+    } else {
+      const float g = dxs[((long)b * Np + R + n) * D + d];
+      out[((long)b * N + n) * D + d] = m ? g * gelu_erf_grad(acc) : 0.f;
+    }
+  }
+}
+
+__global__ void regs_fill_kernel(const float* __restrict__ reg, float* __restrict__ xs, int B, int Np, int R, int D) {
+  const long total = (long)B * R * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ((long)R * D));
+    const long rd = i - (long)b * R * D;
+    xs[(long)b * Np * D + rd] = reg[rd];
+  }
+}
+
+// de[b,n,d] = dxs[b,R+n,d] + m[b,n] * sum_k w[d][k] dpre[b, n-k+half, d]
+// wpart[chunk][d][k] = sum_{n in tile} dpre[b,n,d] * em[b, n+k-half, d] (k<ks) ; wpart[chunk][d][63] = sum dpre
+template <int KS>
+__global__ __launch_bounds__(256) void convpos_bwd_kernel(const float* __restrict__ e, const float* __restrict__ w,
+                                                          const uint8_t* __restrict__ mask, const float* __restrict__ dxs,
+                                                          const float* __restrict__ dpre, float* __restrict__ de,
+                                                          u16* __restrict__ deb, float* __restrict__ wpart, int N, int R,
+                                                          int D) {
+  extern __shared__ float sm[];  // e tile [rows][64], dpre tile [rows][64], reduce [4][64][64]
+  constexpr int ks = KS;
+  const int half = ks / 2;
+  const int rows = CT + ks - 1;
+  float* te = sm;
+  float* tp = sm + rows * 64;
+  float* red = tp + rows * 64;
+  const int n0 = blockIdx.x * CT, dbase = blockIdx.y * 64, b = blockIdx.z;
+  const int dl = threadIdx.x & 63, ng = threadIdx.x >> 6;
+  const int d = dbase + dl;
+  for (int r = ng; r < rows; r += 4) {
+    const int n = n0 + r - half;
+    float ve = 0.f, vp = 0.f;
+    if (n >= 0 && n < N && d < D) {
+      if (!mask || mask[(long)b * N + n]) ve = e[((long)b * N + n) * D + d];
+      vp = dpre[((long)b * N + n) * D + d];
+    }
+    te[r * 64 + dl] = ve;
+    tp[r * 64 + dl] = vp;
+  }
+  __syncthreads();
+  float wr[KS], wacc[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++) wacc[k] = 0.f;
+  if (d < D) {
+#pragma unroll
+    for (int k = 0; k < ks; k++) wr[k] = w[(long)d * ks + k];
+    const int Np = N + R;
+    for (int i = 0; i < 16; i++) {
+      const int nl = ng * 16 + i, n = n0 + nl;
+      if (n >= N) break;
+      // out position nl <-> tile row nl + half
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < ks; k++) acc += wr[k] * tp[(nl + 2 * half - k) * 64 + dl];  // dpre[n - k + half]
+      const bool m = !mask || mask[(long)b * N + n];
+      const float o = dxs[((long)b * Np + R + n) * D + d] + (m ? acc : 0.f);
+      de[((long)b * N + n) * D + d] = o;
+      if (deb) deb[((long)b * N + n) * D + d] = f32_to_bf16(o);
+      const float dp = tp[(nl + half) * 64 + dl];
+#pragma unroll
+      for (int k = 0; k < ks; k++) wacc[k] += dp * te[(nl + k) * 64 + dl];
+      wacc[63] += dp;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 64; k++) red[(ng * 64 + k) * 64 + dl] = wacc[k];
+  __syncthreads();
+  const long chunk = (long)b * gridDim.x + blockIdx.x;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int k = idx >> 6, c = idx & 63;
+    if (dbase + c < D) {
+      const float s = red[(0 * 64 + k) * 64 + c] + red[(1 * 64 + k) * 64 + c] + red[(2 * 64 + k) * 64 + c] +
+                      red[(3 * 64 + k) * 64 + c];
+      wpart[(chunk * D + dbase + c) * 64 + k] = s;
+    }
+  }
+}
+
+__global__ void dreg_kernel(const float* __restrict__ dxs, float* __restrict__ dreg, int B, int Np, int R, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; b++) s += dxs[(long)b * Np * D + i];
+  dreg[i] = s;
+}
+
+// ---------------------------------------------------------------- time embedding
+__global__ void time_four_kernel(const float* __restrict__ times, const float* __restrict__ wsin, float* __restrict__ four,
+                                 int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, j = i - b * D, hd = D / 2;
+  const int jj = j < hd ? j : j - hd;
+  float f = times[b] * wsin[jj];  // x * weights * 2 * pi  (voicebox_pytorch.py:165)
+  f = f * 2.0f;
+  f = f * 3.14159265358979323846f;
+  four[i] = j < hd ? sinf(f) : cosf(f);
+}
+// one wave per (b, i): pre = b1[i] + four[b,:] . W1[i,:]
+__global__ __launch_bounds__(256) void time_linear_kernel(const float* __restrict__ four, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, float* __restrict__ pre,
+                                                           float* __restrict__ temb, int B, int D, int Th) {
+  const int lane = threadIdx.x & 63;
+  const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long)B * Th) return;
+  const int b = (int)(o / Th), i = (int)(o - (long)b * Th);
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) s += four[(long)b * D + j] * w1[(long)i * D + j];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float p = s + b1[i];
+    pre[o] = p;
+    temb[o] = p / (1.0f + expf(-p));
+  }
+}
+VBX_DEV float silu_grad(float p) {
+  const float sg = 1.0f / (1.0f + expf(-p));
+  return sg * (1.0f + p * (1.0f - sg));
+}
+__global__ void time_bwd_w1_kernel(const float* __restrict__ four, const float* __restrict__ pre,
+                                   const float* __restrict__ dtemb, float* __restrict__ dw1, float* __restrict__ db1, int B,
+                                   int D, int Th) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)Th * D) return;
+  const int i = (int)(idx / D), j = (int)(idx - (long)i * D);
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float dp = dtemb[(long)b * Th + i] * silu_grad(pre[(long)b * Th + i]);
+    s += dp * four[(long)b * D + j];
+    sb += dp;
+  }
+  dw1[idx] = s;
+  if (j == 0) db1[i] = sb;
+}
+__global__ void time_bwd_four_kernel(const float* __restrict__ w1, const float* __restrict__ pre,
+                                     const float* __restrict__ dtemb, float* __restrict__ dfour, int B, int D, int Th) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * D) return;
+  const int b = idx / D, j = idx - b * D;
+  float s = 0.f;
+  for (int i = 0; i < Th; i++) s += dtemb[(long)b * Th + i] * silu_grad(pre[(long)b * Th + i]) * w1[(long)i * D + j];
+  dfour[idx] = s;
+}
+__global__ void time_bwd_wsin_kernel(const float* __restrict__ times, const float* __restrict__ four,
+                                     const float* __restrict__ dfour, float* __restrict__ dwsin, int B, int D) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, hd = D / 2;
+  if (j >= hd) return;
+  float s = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float tw = times[b] * 2.0f * 3.14159265358979323846f;
+    const float sn = four[(long)b * D + j], cs = four[(long)b * D + hd + j];
+    s += tw * (dfour[(long)b * D + j] * cs - dfour[(long)b * D + hd + j] * sn);
+  }
+  dwsin[j] = s;
+}
+
+// ---------------------------------------------------------------- adaLN projections (weight streaming, M = B)
+// block: 256 threads = 4 waves, 64 outputs (16 per wave); temb staged in LDS [bc][Th] fp32, bc <= 8.
+__global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict__ temb, const u16* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ ada, int B,
+                                                        int Th, int J, int bc) {
+  extern __shared__ __attribute__((aligned(16))) float st[];  // [bc][Th]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < B; b0 += bc) {
+    const int nb = min(bc, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * Th; i += 256) st[i] = temb[(long)b0 * Th + i];
+    __syncthreads();
+    for (int jj = 0; jj < 16; jj++) {
+      const int j = blockIdx.x * 64 + wave * 16 + jj;
+      if (j >= J) break;
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = 0.f;
+      for (int c = lane; c < Th / 8; c += 64) {
+        float wv[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(w + (long)j * Th + c * 8), wv);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (k < nb) {
+            const float4 t0 = *reinterpret_cast<const float4*>(st + k * Th + c * 8);
+            const float4 t1 = *reinterpret_cast<const float4*>(st + k * Th + c * 8 + 4);
+            acc[k] += wv[0] * t0.x + wv[1] * t0.y + wv[2] * t0.z + wv[3] * t0.w + wv[4] * t1.x + wv[5] * t1.y +
+                      wv[6] * t1.z + wv[7] * t1.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (k < nb) {
+          const float s = wave_sum(acc[k]);
+          if (lane == 0) ada[(long)(b0 + k) * J + j] = s + bias[j];
+        }
+      }
+    }
+  }
+}
+// dW[j][t] = sum_b dada[b][j] temb[b][t] ; dbias[j] = sum_b dada[b][j]
+__global__ void adaln_bwd_w_kernel(const float* __restrict__ temb, const float* __restrict__ dada, float* __restrict__ dw,
+                                   float* __restrict__ dbias, int B, int Th, int J) {
+  const int j = blockIdx.y;
+  const int t4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t4 * 4 >= Th) return;
+  float4 s = make_float4(0, 0, 0, 0);
+  float sb = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float g = dada[(long)b * J + j];
+    const float4 t = *reinterpret_cast<const float4*>(temb + (long)b * Th + t4 * 4);
+    s.x += g * t.x; s.y += g * t.y; s.z += g * t.z; s.w += g * t.w;
+    sb += g;
+  }
+  *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
+  if (t4 == 0) dbias[j] = sb;
+}
+// partial dtemb over a slice of j: scratch[slice][b][t]
+constexpr int ADA_SLICES = 128;
+__global__ __launch_bounds__(256) void adaln_bwd_t_kernel(const u16* __restrict__ w, const float* __restrict__ dada,
+                                                          float* __restrict__ scratch, int B, int Th, int J, int bc) {
+  const int slice = blockIdx.y;
+  const int per = (J + ADA_SLICES - 1) / ADA_SLICES;
+  const int jb = slice * per, je = min(J, jb + per);
+  const int t8 = blockIdx.x * blockDim.x + threadIdx.x;  // chunk of 8 t
+  if (t8 * 8 >= Th) return;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int nb = min(8, B - b0);
+    float acc[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+    for (int j = jb; j < je; j++) {
+      float wv[8];
+      unpack8_bf16(*reinterpret_cast<const uint4*>(w + (long)j * Th + t8 * 8), wv);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (k < nb) {
+          const float g = dada[(long)(b0 + k) * J + j];
+#pragma unroll
+          for (int i = 0; i < 8; i++) acc[k][i] += g * wv[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k < nb) {
+        float* o = scratch + ((long)slice * B + b0 + k) * Th + t8 * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+      }
+    }
+  }
+}
+
+// out[j] (+)= sum_i in[i*ld + j]
+__global__ void sum_rows_kernel(const float* __restrict__ in, long rows, long ld, float* __restrict__ out, long cols,
+                                int accumulate) {
+  const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (long i = 0; i < rows; i++) s += in[i * ld + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+// ---------------------------------------------------------------- GEGLU backward (interleaved layout)
+__global__ void geglu_bwd_kernel(const u16* __restrict__ h1, const u16* __restrict__ dg, u16* __restrict__ dh1, long M,
+                                 int Fp) {
+  const int cpr = Fp / 8;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int f = (int)(i - r * cpr) * 8;  // column in [0, Fp)
+    const int blk = f >> 6, c = f & 63;
+    const long xo = r * 2 * Fp + blk * 128 + c, go = xo + 64;
+    float xv[8], gv[8], dv[8], dx[8], dgt[8];
+    unpack8_bf16(*reinterpret_cast<const uint4*>(h1 + xo), xv);
+    unpack8_bf16(*reinterpret_cast<const uint4*>(h1 + go), gv);
+    unpack8_bf16(*reinterpret_cast<const uint4*>(dg + r * Fp + f), dv);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      dx[k] = dv[k] * gelu_erf(gv[k]);
+      dgt[k] = dv[k] * xv[k] * gelu_erf_grad(gv[k]);
+    }
+    *reinterpret_cast<uint4*>(dh1 + xo) = pack8(dx);
+    *reinterpret_cast<uint4*>(dh1 + go) = pack8(dgt);
+  }
+}
+
+// ---------------------------------------------------------------- column sums
+constexpr int CS_SLABS = 32;
+template <bool BF16>
+__global__ void colsum_stage1(const void* __restrict__ in, long M, int C, long ld, float* __restrict__ scratch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slab = blockIdx.y;
+  if (c >= C) return;
+  const long per = (M + CS_SLABS - 1) / CS_SLABS;
+  const long rb = slab * per, re = min(M, rb + per);
+  float s = 0.f;
+  for (long r = rb; r < re; r++)
+    s += BF16 ? bf16_to_f32(reinterpret_cast<const u16*>(in)[r * ld + c]) : reinterpret_cast<const float*>(in)[r * ld + c];
+  scratch[(long)slab * C + c] = s;
+}
+__global__ void colsum_stage2(const float* __restrict__ scratch, int C, float* __restrict__ out, int out_len, int rowmap,
+                              int F) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int dc = c;
+  if (rowmap == 1) dc = geglu_row_unmap(c, F);
+  if (dc < 0 || dc >= out_len) return;
+  float s = 0.f;
+  for (int k = 0; k < CS_SLABS; k++) s += scratch[(long)k * C + c];
+  out[dc] = s;
+}
+
+// ---------------------------------------------------------------- masked MSE
+// per_b[b] = sum_n mask * mean_d (p-t)^2 / max(count,1e-5) ; per_b[B+b] = den
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const uint8_t* __restrict__ lmask, float* __restrict__ per_b, int B,
+                                                       int N, int D) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f, cnt = 0.f;
+  for (int n = wave; n < N; n += 4) {
+    if (!lmask[(long)b * N + n]) continue;
+    const float4* p4 = reinterpret_cast<const float4*>(pred + ((long)b * N + n) * D);
+    const float4* t4 = reinterpret_cast<const float4*>(target + ((long)b * N + n) * D);
+    float s = 0.f;
+    for (int c = lane; c < D / 4; c += 64) {
+      const float4 p = p4[c], t = t4[c];
+      const float a0 = p.x - t.x, a1 = p.y - t.y, a2 = p.z - t.z, a3 = p.w - t.w;
+      s += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+    s = wave_sum(s);
+    acc += s / (float)D;
+    cnt += 1.f;
+  }
+  if (lane == 0) { red[wave] = acc; red[4 + wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float num = red[0] + red[1] + red[2] + red[3];
+    const float den = fmaxf(red[4] + red[5] + red[6] + red[7], 1e-5f);
+    per_b[b] = num / den;
+    per_b[B + b] = den;
+  }
+}
+__global__ void mse_mean_kernel(const float* __restrict__ per_b, float* __restrict__ loss, int B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; b++) s += per_b[b];
+    loss[0] = s / (float)B;
+  }
+}
+// dpred = gscale * 2 (p-t) / D * mask / (den[b] * B)
+__global__ void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                               const uint8_t* __restrict__ lmask, const float* __restrict__ per_b,
+                               const float* __restrict__ gscale, float* __restrict__ dpred, u16* __restrict__ dpb, int B,
+                               int N, int D) {
+  const long total = (long)B * N * D / 4;
+  const float gs = gscale ? gscale[0] : 1.0f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = (i * 4) / D;
+    const int b = (int)(row / N);
+    float4 o = make_float4(0, 0, 0, 0);
+    if (lmask[row]) {
+      const float k = gs * 2.0f / ((float)D * per_b[B + b] * (float)B);
+      const float4 p = reinterpret_cast<const float4*>(pred)[i], t = reinterpret_cast<const float4*>(target)[i];
+      o = make_float4(k * (p.x - t.x), k * (p.y - t.y), k * (p.z - t.z), k * (p.w - t.w));
+    }
+    if (dpred) reinterpret_cast<float4*>(dpred)[i] = o;
+    if (dpb) reinterpret_cast<uint2*>(dpb)[i] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+  }
+}
+
+// ---------------------------------------------------------------- CFM inputs / ODE axpy
+__global__ void cfm_inputs_kernel(const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ times,
+                                  float sigma, float* __restrict__ w, float* __restrict__ flow, int B, long per) {
+  const long total = (long)B * per;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float t = times[i / per];
+    const float a = x0[i], c = x1[i];
+    // w = (1 - (1 - sigma) t) x0 + t x1 ; flow = x1 - (1 - sigma) x0     (voicebox_pytorch.py:1408,1410)
+    w[i] = (1.0f - (1.0f - sigma) * t) * a + t * c;
+    flow[i] = c - (1.0f - sigma) * a;
+  }
+}
+__global__ void axpy_dev_kernel(const float* __restrict__ y, const float* __restrict__ f, const float* __restrict__ coef,
+                                int idx, float* __restrict__ out, long n4) {
+  const float a = coef[idx];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 yy = reinterpret_cast<const float4*>(y)[i], ff = reinterpret_cast<const float4*>(f)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(yy.x + ff.x * a, yy.y + ff.y * a, yy.z + ff.z * a, yy.w + ff.w * a);
+  }
+}
+
+// ---------------------------------------------------------------- weight packing
+__global__ void pack_weight_kernel(const float* __restrict__ src, int src_rows, int src_cols, u16* __restrict__ dst,
+                                   int dst_rows, int dst_cols, int rowmap, int F) {
+  const long total = (long)dst_rows * dst_cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i / dst_cols), c = (int)(i - (long)p * dst_cols);
+    int r = p;
+    if (rowmap == 1) r = geglu_row_unmap(p, F);
+    float v = 0.f;
+    if (r >= 0 && r < src_rows && c < src_cols) v = src[(long)r * src_cols + c];
+    dst[i] = f32_to_bf16(v);
+  }
+}
+__global__ void pack_bias_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int dst_n, int rowmap, int F) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= dst_n) return;
+  int r = p;
+  if (rowmap == 1) r = geglu_row_unmap(p, F);
+  dst[p] = (r >= 0 && r < n) ? src[r] : 0.f;
+}
+
+// ---------------------------------------------------------------- optimizer
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                            const float* __restrict__ gscale) {
+  const float gs = gscale ? gscale[0] : 1.0f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gs;
+    const float mm = b1 * m[i] + (1.0f - b1) * gr;
+    const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mm;
+    v[i] = vv;
+    // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * mm / denom;
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, long n, float* __restrict__ scratch) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_stage2(const float* __restrict__ scratch, int nb, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += scratch[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
+  // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max = 1)
+  const float nrm = sqrtf(sumsq[0]);
+  coef[0] = fminf(1.0f, max_norm / (nrm + 1e-6f));
+}
+
+// ---------------------------------------------------------------- probes (tests only)
+__global__ void probe_tr16_kernel(const u16* __restrict__ in, const int* __restrict__ off, u16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u16 lds[4096];
+  const int l = threadIdx.x;
+  for (int i = l; i < 4096; i += 64) lds[i] = in[i];
+  __syncthreads();
+  s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + off[l]));
+  for (int j = 0; j < 4; j++) out[l * 4 + j] = (u16)t[j];
+}
+__global__ void probe_mfma_kernel(int which, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c) {
+  const int l = threadIdx.x;
+  if (which == 0) {  // 16x16x32 bf16: a[16][32], b[32][16] -> c[16][16]
+    bf16x8 af, bf;
+    for (int i = 0; i < 8; i++) {
+      af[i] = (__bf16)a[(l & 15) * 32 + (l >> 4) * 8 + i];
+      bf[i] = (__bf16)b[((l >> 4) * 8 + i) * 16 + (l & 15)];
+    }
+    f32x4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+    for (int r = 0; r < 4; r++) c[((l >> 4) * 4 + r) * 16 + (l & 15)] = acc[r];
+  } else {  // 32x32x16: a[32][16], b[16][32] -> c[32][32]
+    f32x16 acc;
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    if (which == 1) {
+      bf16x8 af, bf;
+      for (int i = 0; i < 8; i++) {
+        af[i] = (__bf16)a[(l & 31) * 16 + (l >> 5) * 8 + i];
+        bf[i] = (__bf16)b[((l >> 5) * 8 + i) * 32 + (l & 31)];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    } else {
+      f16x8 af, bf;
+      for (int i = 0; i < 8; i++) {
+        af[i] = (_Float16)a[(l & 31) * 16 + (l >> 5) * 8 + i];
+        bf[i] = (_Float16)b[((l >> 5) * 8 + i) * 32 + (l & 31)];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 16; r++) c[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+  }
+}
+
+inline int grid_for(long n, int cap = 4096) {
+  long b = (n + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_bf16, int B, int N,
+                                    int D, void* stream) {
+  VBX_REQUIRE(x && cond && out_bf16 && D % 8 == 0, "vbx_pack_embed_input: bad args");
+  const long rows = (long)B * N;
+  hipLaunchKernelGGL(pack_embed_kernel, dim3(grid_for(rows * D / 4)), dim3(256), 0, ST, x, cond, cond_mask, (u16*)out_bf16,
+                     rows, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
+                               float* xs, int B, int N, int R, int D, int ksize, void* stream) {
+  VBX_REQUIRE(e && w && bias && xs, "vbx_convpos_fwd: null pointer");
+  VBX_REQUIRE(ksize == 31, "vbx_convpos_fwd: only conv_pos_embed_kernel_size == 31 is built (got %d)", ksize);
+  VBX_REQUIRE(R == 0 || reg, "vbx_convpos_fwd: register tokens missing");
+  dim3 grid(cdiv(N, CT), cdiv(D, 64), B);
+  hipLaunchKernelGGL((convpos_fwd_kernel<0, 31>), grid, dim3(256), (CT + ksize - 1) * 64 * sizeof(float), ST, e, w, bias, mask,
+                     (const float*)nullptr, xs, N, R, D);
+  VBX_LAUNCH_CHECK();
+  if (R > 0) {
+    hipLaunchKernelGGL(regs_fill_kernel, dim3(grid_for((long)B * R * D)), dim3(256), 0, ST, reg, xs, B, N + R, R, D);
+    VBX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int vbx_convpos_bwd_chunks(int B, int N) { return B * cdiv(N, CT); }
+
+extern "C" int vbx_convpos_bwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* dxs,
+                               float* dpre_tmp, float* de, void* de_bf16, float* wpart, float* dreg, int B, int N, int R,
+                               int D, int ksize, void* stream) {
+  VBX_REQUIRE(e && w && bias && dxs && dpre_tmp && de && wpart, "vbx_convpos_bwd: null pointer");
+  VBX_REQUIRE(ksize == 31, "vbx_convpos_bwd: only conv_pos_embed_kernel_size == 31 is built (got %d)", ksize);
+  dim3 grid(cdiv(N, CT), cdiv(D, 64), B);
+  const int rows = CT + ksize - 1;
+  hipLaunchKernelGGL((convpos_fwd_kernel<1, 31>), grid, dim3(256), rows * 64 * sizeof(float), ST, e, w, bias, mask, dxs, dpre_tmp,
+                     N, R, D);
+  VBX_LAUNCH_CHECK();
+  const size_t lds = (size_t)(2 * rows * 64 + 4 * 64 * 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_bwd_kernel<31>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(convpos_bwd_kernel<31>, grid, dim3(256), lds, ST, e, w, mask, dxs, dpre_tmp, de, (u16*)de_bf16, wpart, N, R,
+                     D);
+  VBX_LAUNCH_CHECK();
+  if (R > 0 && dreg) {
+    hipLaunchKernelGGL(dreg_kernel, dim3(cdiv((long)R * D, 256)), dim3(256), 0, ST, dxs, dreg, B, N + R, R, D);
+    VBX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, const float* b1, float* four,
+                                  float* pre, float* temb, int B, int D, int Th, void* stream) {
+  VBX_REQUIRE(times && w_sin && w1 && b1 && four && pre && temb && D % 2 == 0, "vbx_time_embed_fwd: bad args");
+  hipLaunchKernelGGL(time_four_kernel, dim3(cdiv((long)B * D, 256)), dim3(256), 0, ST, times, w_sin, four, B, D);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(time_linear_kernel, dim3(cdiv((long)B * Th, 4)), dim3(256), 0, ST, four, w1, b1, pre, temb, B, D, Th);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, const float* four,
+                                  const float* pre, const float* dtemb, float* dw_sin, float* dw1, float* db1,
+                                  float* scratch, int B, int D, int Th, void* stream) {
+  VBX_REQUIRE(times && w_sin && w1 && four && pre && dtemb && dw_sin && dw1 && db1 && scratch, "vbx_time_embed_bwd: null");
+  hipLaunchKernelGGL(time_bwd_w1_kernel, dim3(cdiv((long)Th * D, 256)), dim3(256), 0, ST, four, pre, dtemb, dw1, db1, B, D, Th);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(time_bwd_four_kernel, dim3(cdiv((long)B * D, 256)), dim3(256), 0, ST, w1, pre, dtemb, scratch, B, D, Th);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(time_bwd_wsin_kernel, dim3(cdiv(D / 2, 256)), dim3(256), 0, ST, times, four, scratch, dw_sin, B, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias, float* ada, int B, int Th, int J,
+                                  void* stream) {
+  VBX_REQUIRE(temb && w_bf16 && bias && ada && Th % 8 == 0, "vbx_adaln_proj_fwd: bad args");
+  int bc = B < 8 ? B : 8;
+  while ((size_t)bc * Th * sizeof(float) > 128 * 1024 && bc > 1) bc >>= 1;
+  const int lds = bc * Th * (int)sizeof(float);
+  VBX_REQUIRE(lds <= 128 * 1024, "vbx_adaln_proj_fwd: time_hidden_dim too large (%d)", Th);
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adaln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(adaln_fwd_kernel, dim3(cdiv(J, 64)), dim3(256), lds, ST, temb, (const u16*)w_bf16, bias, ada, B, Th, J, bc);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return ADA_SLICES * B * Th; }
+
+extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
+                                  float* dtemb, float* scratch, int B, int Th, int J, void* stream) {
+  VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
+  hipLaunchKernelGGL(adaln_bwd_w_kernel, dim3(cdiv(Th / 4, 256), J), dim3(256), 0, ST, temb, dada, dw, dbias, B, Th, J);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adaln_bwd_t_kernel, dim3(cdiv(Th / 8, 256), ADA_SLICES), dim3(256), 0, ST, (const u16*)w_bf16, dada,
+                     scratch, B, Th, J, 8);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 256)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
+                     (long)B * Th, dtemb, (long)B * Th, 0);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_sum_rows_f32(const float* in, long rows, long ld, float* out, long cols, int accumulate, void* stream) {
+  VBX_REQUIRE(in && out && rows > 0 && cols > 0, "vbx_sum_rows_f32: bad args");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, ST, in, rows, ld, out, cols, accumulate);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_geglu_bwd(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, void* stream) {
+  VBX_REQUIRE(h1_bf16 && dg_bf16 && dh1_bf16 && Fp % 64 == 0, "vbx_geglu_bwd: bad args (Fp must be a multiple of 64)");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((long)M * Fp / 8)), dim3(256), 0, ST, (const u16*)h1_bf16,
+                     (const u16*)dg_bf16, (u16*)dh1_bf16, (long)M, Fp);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_colsum_scratch_floats(int M, int C) { return CS_SLABS * C; }
+
+extern "C" int vbx_colsum_bf16(const void* in_bf16, int M, int C, int ld, float* out, int out_len, int rowmap, int F,
+                               float* scratch, void* stream) {
+  VBX_REQUIRE(in_bf16 && out && scratch, "vbx_colsum_bf16: null pointer");
+  hipLaunchKernelGGL(colsum_stage1<true>, dim3(cdiv(C, 256), CS_SLABS), dim3(256), 0, ST, in_bf16, (long)M, C, (long)ld, scratch);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, ST, scratch, C, out, out_len, rowmap, F);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_colsum_f32(const float* in, int M, int C, int ld, float* out, float* scratch, void* stream) {
+  VBX_REQUIRE(in && out && scratch, "vbx_colsum_f32: null pointer");
+  hipLaunchKernelGGL(colsum_stage1<false>, dim3(cdiv(C, 256), CS_SLABS), dim3(256), 0, ST, (const void*)in, (long)M, C,
+                     (long)ld, scratch);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, ST, scratch, C, out, C, 0, 0);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_masked_mse_fwd(const float* pred, const float* target, const uint8_t* loss_mask, float* per_b, float* loss,
+                                  int B, int N, int D, void* stream) {
+  VBX_REQUIRE(pred && target && loss_mask && per_b && loss && D % 4 == 0, "vbx_masked_mse_fwd: bad args");
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(B), dim3(256), 0, ST, pred, target, loss_mask, per_b, B, N, D);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mse_mean_kernel, dim3(1), dim3(64), 0, ST, per_b, loss, B);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_masked_mse_bwd(const float* pred, const float* target, const uint8_t* loss_mask, const float* per_b,
+                                  const float* gscale, float* dpred, void* dpred_bf16, int B, int N, int D, void* stream) {
+  VBX_REQUIRE(pred && target && loss_mask && per_b && (dpred || dpred_bf16) && D % 4 == 0, "vbx_masked_mse_bwd: bad args");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for((long)B * N * D / 4)), dim3(256), 0, ST, pred, target, loss_mask, per_b,
+                     gscale, dpred, (u16*)dpred_bf16, B, N, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_cfm_inputs(const float* x1, const float* x0, const float* times, float sigma, float* w, float* flow, int B,
+                              long per_batch, void* stream) {
+  VBX_REQUIRE(x1 && x0 && times && w && flow, "vbx_cfm_inputs: null pointer");
+  hipLaunchKernelGGL(cfm_inputs_kernel, dim3(grid_for((long)B * per_batch)), dim3(256), 0, ST, x1, x0, times, sigma, w, flow,
+                     B, per_batch);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_axpy_dev(const float* y, const float* f, const float* coef, int idx, float* out, long n, void* stream) {
+  VBX_REQUIRE(y && f && coef && out && n % 4 == 0, "vbx_axpy_dev: bad args");
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, y, f, coef, idx, out, n / 4);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, int dst_rows, int dst_cols,
+                               int rowmap, int F, void* stream) {
+  VBX_REQUIRE(src && dst_bf16, "vbx_pack_weight: null pointer");
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)dst_rows * dst_cols)), dim3(256), 0, ST, src, src_rows, src_cols,
+                     (u16*)dst_bf16, dst_rows, dst_cols, rowmap, F);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_pack_bias(const float* src, int n, float* dst, int dst_n, int rowmap, int F, void* stream) {
+  VBX_REQUIRE(src && dst, "vbx_pack_bias: null pointer");
+  hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(dst_n, 256)), dim3(256), 0, ST, src, n, dst, dst_n, rowmap, F);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, int step, const float* gscale, void* stream) {
+  VBX_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vbx_adam_step: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, bc1,
+                     sqrtf(bc2), gscale);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream) {
+  VBX_REQUIRE(x && out && scratch && n > 0, "vbx_sumsq: bad args");
+  const int nb = grid_for(n, 1024);
+  hipLaunchKernelGGL(sumsq_stage1, dim3(nb), dim3(256), 0, ST, x, n, scratch);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, ST, scratch, nb, out);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream) {
+  VBX_REQUIRE(sumsq && coef, "vbx_clip_coef: null pointer");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, sumsq, max_norm, coef);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_probe_tr16(const void* in_u16_4096, const int* lane_elem_off, void* out_u16_256, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, ST, (const u16*)in_u16_4096, lane_elem_off, (u16*)out_u16_256);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_probe_mfma(int which, const float* a, const float* b, float* c, void* stream) {
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, ST, which, a, b, c);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
