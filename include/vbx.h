@@ -131,6 +131,8 @@ int vbx_convpos_bwd(const float* e, const float* w, const float* bias, const uin
                     float* wpart /* [chunks][D][64]: k<ksize weight grads, [63] bias grad */, float* dreg, int B, int N,
                     int R, int D, int ksize, void* stream);
 int vbx_convpos_bwd_chunks(int B, int N);
+/* dw[d][k] = sum_chunks wpart[.][d][k], db[d] = sum_chunks wpart[.][d][63] */
+int vbx_conv_wgrad_finalize(const float* wpart, int chunks, int D, int ksize, float* dw, float* db, void* stream);
 /* time embedding: LearnedSinusoidalPosEmb -> Linear -> SiLU (voicebox_pytorch.py:163-167,916-920) */
 int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, const float* b1, float* four,
                        float* pre, float* temb, int B, int D, int Th, void* stream);
@@ -140,11 +142,11 @@ int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, 
 /* all adaLN projections at once: ada[b][j] = bias[j] + sum_t temb[b][t] * W[j][t],  W bf16 [J,Th]
  * (J = depth*2 norms*(gamma,beta)*D) (voicebox_pytorch.py:273). */
 int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias, float* ada, int B, int Th, int J,
-                       void* stream);
+                       int group /* output layout ada[j/group][b][j%group]; <=0 or J: plain [b][j] */, void* stream);
 /* dW[j][t] = sum_b dada[b][j]*temb[b][t] (fp32 [J,Th]), dbias[j] = sum_b dada[b][j],
  * dtemb[b][t] = sum_j dada[b][j] * W[j][t]. */
 int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias, float* dtemb,
-                       float* scratch, int B, int Th, int J, void* stream);
+                       float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream);
 int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J);
 /* reduce rmsnorm_bwd partials over chunks: out[b][2][D] = sum_chunk part[b][chunk][2][D] */
 int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D, int sum_batch,
@@ -171,6 +173,13 @@ int vbx_cfm_inputs(const float* x1, const float* x0, const float* times, float s
                    long per_batch, void* stream);
 /* y_out = y + coef[idx] * f   (ODE midpoint axpy; coef device-resident so graphs hold no host scalars) */
 int vbx_axpy_dev(const float* y, const float* f, const float* coef, int idx, float* out, long n, void* stream);
+/* hipGraph-replayable ODE step helpers (replace the host-side loop of torchdiffeq.odeint, call site
+ * voicebox_pytorch.py:1295): t and dt come from device tables [2*intervals] indexed by a device counter.
+ * table slot 0/1 of interval i at table[2*i + slot]. */
+int vbx_ode_set_time(float* times, int B, const float* table, const int* counter, int slot, void* stream);
+int vbx_axpy_ctr(const float* y, const float* f, const float* table, const int* counter, int slot, float* out, long n,
+                 void* stream);
+int vbx_counter_add(int* counter, int inc, void* stream);
 /* fp32 -> bf16 weight packing with optional row map / K padding:
  * dst[p][c] = (src row of p valid && c < src_cols) ? src[row][c] : 0 ; dst is [dst_rows, dst_cols] */
 int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, int dst_rows, int dst_cols,
@@ -184,6 +193,55 @@ int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
 int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
 /* clip coefficient: coef = min(1, max_norm / (sqrt(sumsq)+1e-6)) */
 int vbx_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+
+/* ------------------------------------------------------------------ stage-level runtime
+ * The whole VoiceBox forward / backward as native sequences of launches (no host sync, no allocation:
+ * hipGraph-capturable).  Replaces VoiceBox.forward (voicebox_pytorch.py:987-1115) incl.
+ * Transformer.forward (:412-479) and, for the backward entry points, their autograd graph.
+ * The caller (Python) owns three arenas: flat fp32 parameters (+ same-layout gradients), the packed
+ * bf16 weight arena and the activation arena (sizes from the *_bytes queries). */
+enum { VBX_P_SINW = 0, VBX_P_T1W, VBX_P_T1B, VBX_P_EMBW, VBX_P_EMBB, VBX_P_CONVW, VBX_P_CONVB, VBX_P_REG, VBX_P_FNG,
+       VBX_P_PREDW, VBX_NG };
+/* per layer; the four adaLN weights, and the four adaLN biases, must be contiguous in this order */
+enum { VBX_L_G1W = 0, VBX_L_B1W, VBX_L_G2W, VBX_L_B2W, VBX_L_G1B, VBX_L_B1B, VBX_L_G2B, VBX_L_B2B, VBX_L_QG, VBX_L_KG,
+       VBX_L_QKVW, VBX_L_OUTW, VBX_L_FF1W, VBX_L_FF1B, VBX_L_FF2W, VBX_L_FF2B, VBX_NL };
+
+typedef struct {
+  int B, N, R, D, H, F, Th, L, ksize;
+  int qk_norm;            /* attn_qk_norm (voicebox_pytorch.py:897) */
+  float attn_scale;       /* Attend scale: 10 with qk-norm, dim_head^-0.5 otherwise (:304, attend.py:111) */
+  int training;           /* 1: keep every activation needed by the backward entry points */
+  float* params;          /* flat fp32 master parameters */
+  float* grads;           /* flat fp32 gradients, same offsets (NULL in eval) */
+  const long* off;        /* HOST array [VBX_NG + L*VBX_NL] of offsets (in floats) into params/grads */
+  void* wpack;            /* packed bf16 weight arena */
+  void* act;              /* activation arena */
+  const float* rot_cos;   /* [N+R,32] host-built rotary tables (voicebox_pytorch.py:184-191,436-443) */
+  const float* rot_sin;
+} vbx_model;
+
+typedef struct {
+  const float* x;               /* [B,N,D]  (w in training, y in sampling) */
+  const float* cond;            /* [B,N,D] */
+  const uint8_t* cond_mask;     /* [B,N] 1 = frame is to be infilled (conditioning zeroed there, :1035) */
+  const uint8_t* attn_mask;     /* [B,N] self_attn_mask or NULL */
+  const uint8_t* attn_mask_p;   /* [B,N+R] = attn_mask left-padded with True for the registers (:428), or NULL */
+  const uint8_t* loss_mask;     /* [B,N] cond_mask & attn_mask (:1099); required when target is given */
+  const float* times;           /* [B] */
+  const float* target;          /* [B,N,D] or NULL */
+  float* pred;                  /* [B,N,D] output */
+  float* loss;                  /* [1] output when target != NULL */
+} vbx_io;
+
+size_t vbx_model_wpack_bytes(const vbx_model* m);
+size_t vbx_model_act_bytes(const vbx_model* m);
+int vbx_model_pack_weights(const vbx_model* m, void* stream);
+int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);
+/* backward: head (loss, to_pred, final norm) -> layers L-1..0 -> embed (conv, to_embed, time MLP).  Each call
+ * finishes the gradients of its own parameters, so the caller can all-reduce them while the next runs. */
+int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, const float* gscale, void* stream);
+int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, int layer, void* stream);
+int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream);
 
 /* ------------------------------------------------------------------ hardware probes (tests only) */
 int vbx_probe_tr16(const void* in_u16_4096, const int* lane_elem_off, void* out_u16_256, void* stream);

@@ -1,0 +1,188 @@
+"""GPU parity tests, model level: VoiceBox / ConditionalFlowMatcherWrapper through the public (reference)
+API against golden vectors produced by the UNMODIFIED reference (tests/golden/make_golden.py) and against
+the CPU oracle (oracle/restate.py) on the same seeded inputs.
+
+Stated tolerances (north_star): mask/index logic bit-exact; flow-matching loss within 1e-3 of the
+reference; sampled frames / predictions within the fp tolerance below (bf16 GEMM operands, fp32
+accumulation and residual stream, fp16 q/k for the attention logits).
+"""
+import pytest
+import torch
+
+from oracle import restate
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / ref.norm().clamp(min=1e-30))
+
+
+def build(cfg_dict, state):
+    import voicebox_pytorch_amd as vbx
+
+    vb = vbx.VoiceBox(dim=cfg_dict["dim"], num_cond_tokens=500, depth=cfg_dict["depth"], dim_head=64,
+                      heads=cfg_dict["heads"], condition_on_text=False)
+    missing = vb.load_state_dict(state, strict=False)
+    assert not missing.unexpected_keys and all("inv_freq" in k for k in missing.missing_keys)
+    vb = vb.to(dev)
+    return vbx, vb, vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+
+
+def test_masks_bit_exact_on_gpu(golden):
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("masks")
+    for n, expect in g["cases"].items():
+        with rng_override(rand=g["rand"]):
+            got = vbx.mask_from_frac_lengths(n, g["frac"].to(dev))
+        assert torch.equal(got.cpu(), expect), n
+    got = vbx.mask_from_start_end_indices(8, g["start"].to(dev), g["end"].to(dev))
+    assert torch.equal(got.cpu(), g["start_end_8"])
+
+
+def test_small_golden_loss_and_grads(golden):
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    vbx, vb, wrapper = build(g["cfg"], g["state"])
+    for mask_key, loss_key, grads_key in ((None, "loss", "grads"), ("mask", "loss_masked", "grads_masked")):
+        vb.zero_grad(set_to_none=True)
+        with rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+            loss = wrapper(g["x1"].to(dev), mask=g[mask_key].to(dev) if mask_key else None)
+        assert abs(float(loss) - float(g[loss_key])) < 1e-3, (float(loss), float(g[loss_key]))
+        loss.backward()
+        named = dict(vb.named_parameters())
+        worst = 0.0
+        for k, ref in g[grads_key].items():
+            got = named[k].grad
+            assert got is not None, k
+            r = rel(got, ref)
+            worst = max(worst, r)
+            # bf16 operands everywhere in the backward GEMMs: a few 1e-2 relative per tensor
+            assert r < 5e-2, (mask_key, k, r)
+        print("worst relative grad error", mask_key, worst)
+
+
+def test_small_golden_eval_and_sample(golden):
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    vbx, vb, wrapper = build(g["cfg"], g["state"])
+    vb.eval()
+    with torch.no_grad():
+        pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev),
+                  cond_mask=g["cond_mask"].to(dev), cond_drop_prob=0.0)
+        assert rel(pred, g["pred"]) < 1e-2, rel(pred, g["pred"])
+        pred_s = vb(g["x1"].to(dev), times=torch.tensor(0.5), cond_token_ids=None, cond=g["cond"].to(dev), cond_drop_prob=0.0)
+        assert rel(pred_s, g["pred_scalar_t"]) < 1e-2
+        # eval with cond_mask None: output must not depend on cond -- bit-exact
+        pred_z = vb(g["x1"].to(dev), times=torch.tensor(0.5), cond_token_ids=None, cond=torch.zeros_like(g["cond"]).to(dev),
+                    cond_drop_prob=0.0)
+        assert torch.equal(pred_s, pred_z)
+    for steps, key in ((3, "sample3"), (5, "sample5")):
+        for use_graph in (False, True):
+            with rng_override(y0=g["y0"]):
+                s = wrapper.sample(cond=g["cond"].to(dev), steps=steps, use_graph=use_graph)
+            assert s.shape == g[key].shape
+            assert rel(s, g[key]) < 1e-2, (key, use_graph, rel(s, g[key]))
+    # the captured graph must replay identically
+    with rng_override(y0=g["y0"]):
+        a = wrapper.sample(cond=g["cond"].to(dev), steps=5)
+    with rng_override(y0=g["y0"]):
+        b = wrapper.sample(cond=g["cond"].to(dev), steps=5)
+    assert torch.equal(a, b)
+
+
+def test_error_conventions(golden):
+    g = golden("small")
+    vbx, vb, wrapper = build(g["cfg"], g["state"])
+    with pytest.raises(AttributeError):  # default cond_drop_prob = 0.1 on an unconditional model
+        vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev))
+    with pytest.raises(AttributeError):
+        wrapper.sample(cond=g["cond"].to(dev), steps=3, cond_scale=1.3)
+    with pytest.raises(NotImplementedError):
+        vbx.VoiceBox(dim=64, num_cond_tokens=10, depth=2, heads=2)  # text conditioning is a "next" row
+
+
+def test_cfg1_loss_parity(golden):
+    """BASELINE config 1/2: dim 512, depth 2, heads 16, x = randn(2,1024,512): loss within 1e-3 of the reference CPU path."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg1")
+    cfg = restate.Cfg(dim=512, depth=2, heads=16, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=0)
+    vbx, vb, wrapper = build(dict(dim=512, depth=2, heads=16), state)
+    x1 = torch.randn(2, 1024, 512, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(1)
+    x0 = torch.randn_like(x1)
+    assert torch.equal(x0[0, 0, :4], g["x0_check"])
+    with rng_override(x0=x0, times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+        loss = wrapper(x1.to(dev))
+    print("cfg1 loss", float(loss), "reference", float(g["loss"]))
+    assert abs(float(loss) - float(g["loss"])) < 1e-3
+    loss.backward()
+    named = dict(vb.named_parameters())
+    worst = 0.0
+    for k, ref_norm in g["grad_norms"].items():
+        got = float(named[k].grad.norm())
+        r = abs(got - ref_norm) / max(ref_norm, 1e-12)
+        worst = max(worst, r)
+        assert r < 5e-2, (k, got, ref_norm)
+        sl = named[k].grad.flatten()[:16].cpu()
+        assert float((sl - g["grad_slices"][k]).abs().max()) < 5e-2 * float(g["grad_slices"][k].abs().max()) + 1e-7 * ref_norm, k
+    print("cfg1 worst grad-norm rel err", worst)
+    vb.eval()
+    with torch.no_grad():
+        pred = vb(x1.to(dev), times=torch.tensor(0.37), cond_token_ids=None, cond=x1.to(dev), cond_drop_prob=0.0)
+    assert abs(float(pred.norm()) - g["pred_norm"]) / g["pred_norm"] < 5e-3
+    assert rel(pred[:, :8, :32], g["pred_slice"]) < 2e-2
+
+
+def test_padded_batch_vs_oracle():
+    """key-padding mask + ragged batch, frames not a multiple of any tile size, against the CPU oracle."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    cfg = restate.Cfg(dim=128, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=3)
+    vbx, vb, wrapper = build(dict(dim=128, depth=2, heads=2), state)
+    B, N = 3, 203
+    gen = torch.Generator().manual_seed(11)
+    x1, x0 = torch.randn(B, N, 128, generator=gen), torch.randn(B, N, 128, generator=gen)
+    times, frac, rand = torch.rand(B, generator=gen), 0.7 + 0.3 * torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    mask[0, 150:] = False
+    mask[2, 77:] = False
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in state.items()}
+    ref = restate.cfm_loss(p, cfg, x1, x0, times, frac, rand, mask=mask)
+    ref.backward()
+    with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
+        loss = wrapper(x1.to(dev), mask=mask.to(dev))
+    assert abs(float(loss) - float(ref)) < 1e-3, (float(loss), float(ref))
+    loss.backward()
+    for k, prm in vb.named_parameters():
+        if prm.grad is None:
+            continue
+        assert rel(prm.grad, p[k].grad) < 5e-2, (k, rel(prm.grad, p[k].grad))
+
+
+def test_attend_module_matches_reference_math():
+    import voicebox_pytorch_amd as vbx
+
+    att = vbx.Attend(scale=10.0)
+    gen = torch.Generator().manual_seed(0)
+    q = torch.randn(2, 2, 90, 64, generator=gen)
+    k = torch.randn(2, 2, 90, 64, generator=gen)
+    q, k = q / q.norm(dim=-1, keepdim=True) * 8, k / k.norm(dim=-1, keepdim=True) * 8
+    v = torch.randn(2, 2, 90, 64, generator=gen)
+    mask = torch.ones(2, 90, dtype=torch.bool)
+    mask[1, 60:] = False
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = att(qd, kd, vd, mask=mask.to(dev))
+    ref = restate.attend(q.half().double(), k.half().double(), v.bfloat16().double(), mask=mask, scale=10.0)
+    assert rel(out, ref) < 6e-3
+    out.sum().backward()
+    assert qd.grad is not None and kd.grad.shape == k.shape and vd.grad.shape == v.shape

@@ -395,9 +395,10 @@ def test_convpos_fwd_bwd(L, masked):
     L.call("vbx_convpos_bwd", ed, wd, bd, md, dxs.to(dev), dpre, de, deb, wpart, dreg, Bsz, N, R, D, ks, st())
     assert rel_err(de, e.grad) < 1e-5
     assert rel_err(deb, e.grad) < 4e-3
-    wsum = wpart.sum(0)
-    assert rel_err(wsum[:, :ks], w.grad[:, 0]) < 1e-5
-    assert rel_err(wsum[:, 63], b.grad) < 1e-5
+    dw, db = torch.zeros(D, 1, ks, device=dev), torch.zeros(D, device=dev)
+    L.call("vbx_conv_wgrad_finalize", wpart, chunks, D, ks, dw, db, st())
+    assert rel_err(dw, w.grad) < 1e-5
+    assert rel_err(db, b.grad) < 1e-5
     assert rel_err(dreg, dxs[:, :R].sum(0)) < 1e-6
 
 
@@ -425,15 +426,18 @@ def test_time_embed_and_adaln(L):
     br = bias.double().requires_grad_(True)
     ada_ref = temb_ref @ Wr.t() + br
     ada = torch.empty(Bsz, J, device=dev)
-    L.call("vbx_adaln_proj_fwd", temb, Wb, bias.to(dev), ada, Bsz, Th, J, st())
+    L.call("vbx_adaln_proj_fwd", temb, Wb, bias.to(dev), ada, Bsz, Th, J, 0, st())
     assert rel_err(ada, ada_ref) < 1e-5
+    ada_g = torch.empty(J // 128, Bsz, 128, device=dev)  # grouped layout used by the runtime: [layer][b][4D]
+    L.call("vbx_adaln_proj_fwd", temb, Wb, bias.to(dev), ada_g, Bsz, Th, J, 128, st())
+    assert torch.equal(ada_g.permute(1, 0, 2).reshape(Bsz, J), ada)
     dada = torch.randn(Bsz, J, generator=g)
     ada_ref.backward(dada.double())
     dW = torch.empty(J, Th, device=dev)
     dbias = torch.empty(J, device=dev)
     dtemb = torch.empty(Bsz, Th, device=dev)
     scratch = torch.empty(L.lib().vbx_adaln_proj_bwd_scratch_floats(Bsz, Th, J), device=dev)
-    L.call("vbx_adaln_proj_bwd", temb, Wb, dada.to(dev), dW, dbias, dtemb, scratch, Bsz, Th, J, st())
+    L.call("vbx_adaln_proj_bwd", temb, Wb, dada.to(dev), dW, dbias, dtemb, scratch, Bsz, Th, J, 0, st())
     assert rel_err(dW, Wr.grad) < 1e-5 and rel_err(dbias, br.grad) < 1e-5
     # time-embedding backward from the oracle's d(temb)
     dtemb_ref = dada.double() @ Wr.detach()

@@ -41,10 +41,11 @@ _PROTOS = {
     "vbx_convpos_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd_chunks": [I, I],
+    "vbx_conv_wgrad_finalize": [P, I, I, I, P, P, P],
     "vbx_time_embed_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "vbx_time_embed_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
-    "vbx_adaln_proj_fwd": [P, P, P, P, I, I, I, P],
-    "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "vbx_adaln_proj_fwd": [P, P, P, P, I, I, I, I, P],
+    "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd_scratch_floats": [I, I, I],
     "vbx_reduce_norm_partials": [P, P, L, I, I, I, I, P],
     "vbx_geglu_bwd": [P, P, P, I, I, P],
@@ -56,6 +57,9 @@ _PROTOS = {
     "vbx_masked_mse_bwd": [P, P, P, P, P, P, P, I, I, I, P],
     "vbx_cfm_inputs": [P, P, P, F, P, P, I, L, P],
     "vbx_axpy_dev": [P, P, P, I, P, L, P],
+    "vbx_ode_set_time": [P, I, P, P, I, P],
+    "vbx_axpy_ctr": [P, P, P, P, I, P, L, P],
+    "vbx_counter_add": [P, I, P],
     "vbx_pack_weight": [P, I, I, P, I, I, I, I, P],
     "vbx_pack_bias": [P, I, P, I, I, I, P],
     "vbx_adam_step": [P, P, P, P, L, F, F, F, F, I, P, P],

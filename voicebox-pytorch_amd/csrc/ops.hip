@@ -160,6 +160,19 @@ __global__ __launch_bounds__(256) void convpos_bwd_kernel(const float* __restric
   }
 }
 
+// dw[d][k] = sum_chunk wpart[chunk][d][k] (k < ks) ; db[d] = sum_chunk wpart[chunk][d][63]
+__global__ void conv_wgrad_finalize_kernel(const float* __restrict__ wpart, int chunks, int D, int ks, float* __restrict__ dw,
+                                           float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * 64) return;
+  const int d = idx >> 6, k = idx & 63;
+  if (k >= ks && k != 63) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; c++) s += wpart[((long)c * D + d) * 64 + k];
+  if (k == 63) db[d] = s;
+  else dw[(long)d * ks + k] = s;
+}
+
 __global__ void dreg_kernel(const float* __restrict__ dxs, float* __restrict__ dreg, int B, int Np, int R, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R * D) return;
@@ -242,7 +255,7 @@ __global__ void time_bwd_wsin_kernel(const float* __restrict__ times, const floa
 // block: 256 threads = 4 waves, 64 outputs (16 per wave); temb staged in LDS [bc][Th] fp32, bc <= 8.
 __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict__ temb, const u16* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ ada, int B,
-                                                        int Th, int J, int bc) {
+                                                        int Th, int J, int bc, int group) {
   extern __shared__ __attribute__((aligned(16))) float st[];  // [bc][Th]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int b0 = 0; b0 < B; b0 += bc) {
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict_
       for (int k = 0; k < 8; k++) {
         if (k < nb) {
           const float s = wave_sum(acc[k]);
-          if (lane == 0) ada[(long)(b0 + k) * J + j] = s + bias[j];
+          if (lane == 0) ada[((long)(j / group) * B + (b0 + k)) * group + (j % group)] = s + bias[j];
         }
       }
     }
@@ -475,6 +488,25 @@ __global__ void axpy_dev_kernel(const float* __restrict__ y, const float* __rest
   }
 }
 
+// device-counter variants for the hipGraph-captured ODE step: the captured kernels read t / dt from
+// device tables indexed by a device counter, so one captured step replays for every interval.
+__global__ void ode_set_time_kernel(float* __restrict__ times, int B, const float* __restrict__ table,
+                                    const int* __restrict__ counter, int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) times[b] = table[2 * counter[0] + slot];
+}
+__global__ void axpy_ctr_kernel(const float* __restrict__ y, const float* __restrict__ f, const float* __restrict__ table,
+                                const int* __restrict__ counter, int slot, float* __restrict__ out, long n4) {
+  const float a = table[2 * counter[0] + slot];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 yy = reinterpret_cast<const float4*>(y)[i], ff = reinterpret_cast<const float4*>(f)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(yy.x + ff.x * a, yy.y + ff.y * a, yy.z + ff.z * a, yy.w + ff.w * a);
+  }
+}
+__global__ void counter_add_kernel(int* counter, int inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += inc;
+}
+
 // ---------------------------------------------------------------- weight packing
 __global__ void pack_weight_kernel(const float* __restrict__ src, int src_rows, int src_cols, u16* __restrict__ dst,
                                    int dst_rows, int dst_cols, int rowmap, int F) {
@@ -642,6 +674,13 @@ extern "C" int vbx_convpos_bwd(const float* e, const float* w, const float* bias
   return 0;
 }
 
+extern "C" int vbx_conv_wgrad_finalize(const float* wpart, int chunks, int D, int ksize, float* dw, float* db, void* stream) {
+  VBX_REQUIRE(wpart && dw && db && ksize < 63, "vbx_conv_wgrad_finalize: bad args");
+  hipLaunchKernelGGL(conv_wgrad_finalize_kernel, dim3(cdiv((long)D * 64, 256)), dim3(256), 0, ST, wpart, chunks, D, ksize, dw, db);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, const float* b1, float* four,
                                   float* pre, float* temb, int B, int D, int Th, void* stream) {
   VBX_REQUIRE(times && w_sin && w1 && b1 && four && pre && temb && D % 2 == 0, "vbx_time_embed_fwd: bad args");
@@ -666,8 +705,10 @@ extern "C" int vbx_time_embed_bwd(const float* times, const float* w_sin, const 
 }
 
 extern "C" int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias, float* ada, int B, int Th, int J,
-                                  void* stream) {
+                                  int group, void* stream) {
   VBX_REQUIRE(temb && w_bf16 && bias && ada && Th % 8 == 0, "vbx_adaln_proj_fwd: bad args");
+  if (group <= 0) group = J;
+  VBX_REQUIRE(J % group == 0, "vbx_adaln_proj_fwd: J must be a multiple of group");
   int bc = B < 8 ? B : 8;
   while ((size_t)bc * Th * sizeof(float) > 128 * 1024 && bc > 1) bc >>= 1;
   const int lds = bc * Th * (int)sizeof(float);
@@ -677,7 +718,7 @@ extern "C" int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adaln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(adaln_fwd_kernel, dim3(cdiv(J, 64)), dim3(256), lds, ST, temb, (const u16*)w_bf16, bias, ada, B, Th, J, bc);
+  hipLaunchKernelGGL(adaln_fwd_kernel, dim3(cdiv(J, 64)), dim3(256), lds, ST, temb, (const u16*)w_bf16, bias, ada, B, Th, J, bc, group);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -685,7 +726,7 @@ extern "C" int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const f
 extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return ADA_SLICES * B * Th; }
 
 extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
-                                  float* dtemb, float* scratch, int B, int Th, int J, void* stream) {
+                                  float* dtemb, float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream) {
   VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
   hipLaunchKernelGGL(adaln_bwd_w_kernel, dim3(cdiv(Th / 4, 256), J), dim3(256), 0, ST, temb, dada, dw, dbias, B, Th, J);
   VBX_LAUNCH_CHECK();
@@ -693,7 +734,7 @@ extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const f
                      scratch, B, Th, J, 8);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 256)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
-                     (long)B * Th, dtemb, (long)B * Th, 0);
+                     (long)B * Th, dtemb, (long)B * Th, accumulate_dtemb);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -764,6 +805,26 @@ extern "C" int vbx_cfm_inputs(const float* x1, const float* x0, const float* tim
 extern "C" int vbx_axpy_dev(const float* y, const float* f, const float* coef, int idx, float* out, long n, void* stream) {
   VBX_REQUIRE(y && f && coef && out && n % 4 == 0, "vbx_axpy_dev: bad args");
   hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, y, f, coef, idx, out, n / 4);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_ode_set_time(float* times, int B, const float* table, const int* counter, int slot, void* stream) {
+  VBX_REQUIRE(times && table && counter && (slot == 0 || slot == 1), "vbx_ode_set_time: bad args");
+  hipLaunchKernelGGL(ode_set_time_kernel, dim3(cdiv(B, 64)), dim3(64), 0, ST, times, B, table, counter, slot);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_axpy_ctr(const float* y, const float* f, const float* table, const int* counter, int slot, float* out,
+                            long n, void* stream) {
+  VBX_REQUIRE(y && f && table && counter && out && n % 4 == 0, "vbx_axpy_ctr: bad args");
+  hipLaunchKernelGGL(axpy_ctr_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, y, f, table, counter, slot, out, n / 4);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_counter_add(int* counter, int inc, void* stream) {
+  VBX_REQUIRE(counter, "vbx_counter_add: null");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ST, counter, inc);
   VBX_LAUNCH_CHECK();
   return 0;
 }

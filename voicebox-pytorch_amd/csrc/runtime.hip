@@ -1,0 +1,425 @@
+// Stage-level runtime: VoiceBox forward / backward as native launch sequences over caller-owned arenas.
+// Mirrors VoiceBox.forward (voicebox_pytorch.py:987-1115) + Transformer.forward (:412-479).
+//
+// HBM layout (all token-major, row r = b*Np + n, Np = N + R registers in place at rows n < R):
+//   residual stream   fp32 [M, D]    one snapshot per sub-layer in training (xs[0..2L]), 2 ping-pong buffers in eval
+//   normed inputs     bf16 [M, D]    hn1 / hn2 (GEMM A operands, kept for wgrad)
+//   q-hat, k-hat      fp16 [B,H,Np,64] (+ bf16 copies for the backward GEMMs), v bf16 [B,H,Np,64]
+//   attention out     bf16 [M, H*64], log2-LSE fp32 [B,H,Np]
+//   FF pre-activation bf16 [M, 2*Fp] (interleaved x|gate per 128 columns), GEGLU out bf16 [M, Fp], Fp = ceil64(F)
+#include "common.hpp"
+#include <vector>
+
+namespace {
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <class T>
+  T* take(size_t n) {
+    off = al256(off);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Dims {
+  int B, N, R, Np, D, H, I, F, Fp, Th, L, ks, J;
+  long M, M0;
+};
+Dims dims_of(const vbx_model* m) {
+  Dims d;
+  d.B = m->B; d.N = m->N; d.R = m->R; d.Np = m->N + m->R; d.D = m->D; d.H = m->H; d.I = m->H * 64;
+  d.F = m->F; d.Fp = ((m->F + 63) / 64) * 64; d.Th = m->Th; d.L = m->L; d.ks = m->ksize; d.J = m->L * 4 * m->D;
+  d.M = (long)d.B * d.Np; d.M0 = (long)d.B * d.N;
+  return d;
+}
+
+struct WLayer {
+  u16 *qkv, *out, *w1, *w2;
+  float* b1;
+};
+struct WPack {
+  u16 *emb, *pred, *ada;
+  float* bada;
+  std::vector<WLayer> layer;
+  size_t bytes;
+};
+void carve_wpack(const vbx_model* m, WPack& w) {
+  const Dims d = dims_of(m);
+  Carver c(m->wpack);
+  w.emb = c.take<u16>((size_t)d.D * 2 * d.D);
+  w.pred = c.take<u16>((size_t)d.D * d.D);
+  w.ada = c.take<u16>((size_t)d.J * d.Th);
+  w.bada = c.take<float>(d.J);
+  w.layer.resize(d.L);
+  for (int l = 0; l < d.L; l++) {
+    w.layer[l].qkv = c.take<u16>((size_t)3 * d.I * d.D);
+    w.layer[l].out = c.take<u16>((size_t)d.D * d.I);
+    w.layer[l].w1 = c.take<u16>((size_t)2 * d.Fp * d.D);
+    w.layer[l].b1 = c.take<float>(2 * d.Fp);
+    w.layer[l].w2 = c.take<u16>((size_t)d.D * d.Fp);
+  }
+  w.bytes = al256(c.off);
+}
+
+struct ALayer {
+  u16 *hn1, *q16, *k16, *qb, *kb, *v, *o, *hn2, *h1, *g;
+  float *qrn, *krn, *lse;
+};
+struct Acts {
+  u16* embed_in;
+  float *e, *four, *pre, *temb, *ada;
+  std::vector<float*> xs;  // residual snapshots
+  std::vector<ALayer> layer;
+  u16* hf;
+  float *pred, *per_b;
+  // backward scratch
+  float *dx, *dq, *dk, *delta, *slabs, *npart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
+      *tscratch;
+  u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb;
+  size_t slab_floats;
+  size_t bytes;
+};
+
+int wgrad_splits(long I, long J, long K) {
+  const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
+  long s = (768 + tiles - 1) / tiles;
+  const long smax = (K + 511) / 512;
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+void carve_acts(const vbx_model* m, Acts& a) {
+  const Dims d = dims_of(m);
+  Carver c(m->act);
+  const bool tr = m->training != 0;
+  a.embed_in = c.take<u16>((size_t)d.M0 * 2 * d.D);
+  a.e = c.take<float>((size_t)d.M0 * d.D);
+  a.four = c.take<float>((size_t)d.B * d.D);
+  a.pre = c.take<float>((size_t)d.B * d.Th);
+  a.temb = c.take<float>((size_t)d.B * d.Th);
+  a.ada = c.take<float>((size_t)d.B * d.J);
+  const int nxs = tr ? 2 * d.L + 1 : 2;
+  a.xs.resize(2 * d.L + 1);
+  std::vector<float*> bufs(nxs);
+  for (int i = 0; i < nxs; i++) bufs[i] = c.take<float>((size_t)d.M * d.D);
+  for (int i = 0; i <= 2 * d.L; i++) a.xs[i] = bufs[tr ? i : (i & 1)];
+  a.layer.resize(d.L);
+  const size_t hs = (size_t)d.B * d.H * d.Np * 64;
+  ALayer shared{};
+  for (int l = 0; l < d.L; l++) {
+    if (tr || l == 0) {
+      ALayer& y = a.layer[l];
+      y.hn1 = c.take<u16>((size_t)d.M * d.D);
+      y.q16 = c.take<u16>(hs);
+      y.k16 = c.take<u16>(hs);
+      y.qb = tr ? c.take<u16>(hs) : nullptr;
+      y.kb = tr ? c.take<u16>(hs) : nullptr;
+      y.v = c.take<u16>(hs);
+      y.qrn = tr ? c.take<float>((size_t)d.B * d.H * d.Np) : nullptr;
+      y.krn = tr ? c.take<float>((size_t)d.B * d.H * d.Np) : nullptr;
+      y.o = c.take<u16>((size_t)d.M * d.I);
+      y.lse = c.take<float>((size_t)d.B * d.H * d.Np);
+      y.hn2 = c.take<u16>((size_t)d.M * d.D);
+      y.h1 = tr ? c.take<u16>((size_t)d.M * 2 * d.Fp) : nullptr;
+      y.g = c.take<u16>((size_t)d.M * d.Fp);
+      shared = y;
+    } else {
+      a.layer[l] = shared;
+    }
+  }
+  a.hf = c.take<u16>((size_t)d.M0 * d.D);
+  a.pred = c.take<float>((size_t)d.M0 * d.D);
+  a.per_b = c.take<float>(2 * d.B + 1);
+  if (tr) {
+    a.dx = c.take<float>((size_t)d.M * d.D);
+    a.dxb = c.take<u16>((size_t)d.M * d.D);
+    a.dg = c.take<u16>((size_t)d.M * d.Fp);
+    a.dh1 = c.take<u16>((size_t)d.M * 2 * d.Fp);
+    a.dhn = c.take<u16>((size_t)d.M * d.D);
+    a.dO = c.take<u16>((size_t)d.M * d.I);
+    a.dqkv = c.take<u16>((size_t)d.M * 3 * d.I);
+    a.dq = c.take<float>(hs);
+    a.dk = c.take<float>(hs);
+    a.delta = c.take<float>((size_t)d.B * d.H * d.Np);
+    size_t sf = 0;
+    auto upd = [&](long I, long J, long K) {
+      const size_t n = (size_t)wgrad_splits(I, J, K) * I * J;
+      if (n > sf) sf = n;
+    };
+    upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
+    upd(d.D, 2 * d.D, d.M0); upd(d.D, d.D, d.M0);
+    a.slab_floats = sf;
+    a.slabs = c.take<float>(sf);
+    a.npart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * 2 * d.D);
+    a.dada = c.take<float>((size_t)d.B * d.J);
+    a.dtemb = c.take<float>((size_t)d.B * d.Th);
+    size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
+    a.cs_scratch = c.take<float>(cs);
+    a.gpart = c.take<float>((size_t)2 * vbx_qknorm_rope_bwd_gpart_rows(d.B) * d.H * 64);
+    a.tmp2d = c.take<float>(2 * d.D);
+    a.ada_scratch = c.take<float>((size_t)vbx_adaln_proj_bwd_scratch_floats(d.B, d.Th, 4 * d.D));
+    a.dpre = c.take<float>((size_t)d.M0 * d.D);
+    a.de = c.take<float>((size_t)d.M0 * d.D);
+    a.deb = c.take<u16>((size_t)d.M0 * d.D);
+    a.dpb = c.take<u16>((size_t)d.M0 * d.D);
+    a.wpart = c.take<float>((size_t)vbx_convpos_bwd_chunks(d.B, d.N) * d.D * 64);
+    a.tscratch = c.take<float>((size_t)d.B * d.D);
+  }
+  a.bytes = al256(c.off);
+}
+
+#define CK(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+int check_model(const vbx_model* m) {
+  VBX_REQUIRE(m && m->params && m->off && m->wpack && m->act && m->rot_cos && m->rot_sin, "vbx_model: null field");
+  VBX_REQUIRE(m->D % 64 == 0 && m->D <= 2048, "vbx_model: dim must be a multiple of 64 and <= 2048 (got %d)", m->D);
+  VBX_REQUIRE(m->H > 0 && m->H % 2 == 0, "vbx_model: heads must be even (dim_head is fixed at 64)");
+  VBX_REQUIRE(m->Th % 8 == 0 && m->L > 0 && m->B > 0 && m->N > 0 && m->R >= 0 && m->F > 0, "vbx_model: bad dims");
+  VBX_REQUIRE(m->ksize == 31, "vbx_model: conv_pos_embed_kernel_size must be 31");
+  const long DT = (long)m->D * m->Th;
+  for (int l = 0; l < m->L; l++) {
+    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    VBX_REQUIRE(o[VBX_L_B1W] == o[VBX_L_G1W] + DT && o[VBX_L_G2W] == o[VBX_L_B1W] + DT && o[VBX_L_B2W] == o[VBX_L_G2W] + DT,
+                "vbx_model: adaLN weights of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
+    VBX_REQUIRE(o[VBX_L_B1B] == o[VBX_L_G1B] + m->D && o[VBX_L_G2B] == o[VBX_L_B1B] + m->D && o[VBX_L_B2B] == o[VBX_L_G2B] + m->D,
+                "vbx_model: adaLN biases of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
+  }
+  return 0;
+}
+
+int gemm_nt(const u16* A, int lda, const u16* Bw, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
+            const float* resid, void* C2, hipStream_t st) {
+  vbx_gemm_desc g{};
+  g.mode = VBX_GEMM_NT; g.epilogue = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.A = A; g.B = Bw; g.C = C; g.bias = bias; g.resid = resid; g.C2 = C2;
+  return vbx_gemm(&g, st);
+}
+int gemm_nn_bf16(const u16* A, int lda, const u16* Bw, int ldb, int M, int N, int K, u16* C, int ldc, hipStream_t st) {
+  vbx_gemm_desc g{};
+  g.mode = VBX_GEMM_NN; g.epilogue = VBX_EPI_BF16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.A = A; g.B = Bw; g.C = C;
+  return vbx_gemm(&g, st);
+}
+// dW[I,J] = P[K,I]^T . Q[K,J]  -> grads (fp32, reference layout [dst_rows, dst_cols])
+int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, float* slabs, float* dst, int dst_rows,
+          int dst_cols, int rowmap, int F, hipStream_t st) {
+  vbx_gemm_desc g{};
+  const int splits = wgrad_splits(I, J, K);
+  g.mode = VBX_GEMM_TN; g.epilogue = VBX_EPI_SPLITK; g.M = I; g.N = J; g.K = (int)K; g.lda = ldp; g.ldb = ldq;
+  g.A = P; g.B = Q; g.C = slabs; g.splits = splits;
+  CK(vbx_gemm(&g, st));
+  return vbx_splitk_reduce(slabs, splits, I, J, dst, dst_rows, dst_cols, dst_cols, rowmap, F, 0, st);
+}
+
+}  // namespace
+
+extern "C" size_t vbx_model_wpack_bytes(const vbx_model* m) {
+  vbx_model t = *m;
+  t.wpack = nullptr;
+  WPack w;
+  carve_wpack(&t, w);
+  return w.bytes;
+}
+extern "C" size_t vbx_model_act_bytes(const vbx_model* m) {
+  vbx_model t = *m;
+  t.act = nullptr;
+  Acts a;
+  carve_acts(&t, a);
+  return a.bytes;
+}
+
+extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
+  CK(check_model(m));
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  const float* P = m->params;
+  const long* G = m->off;
+  CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, w.emb, d.D, 2 * d.D, 0, 0, stream));
+  CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, d.D, d.D, 0, 0, stream));
+  for (int l = 0; l < d.L; l++) {
+    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    CK(vbx_pack_weight(P + o[VBX_L_G1W], 4 * d.D, d.Th, w.ada + (size_t)l * 4 * d.D * d.Th, 4 * d.D, d.Th, 0, 0, stream));
+    CK(vbx_pack_bias(P + o[VBX_L_G1B], 4 * d.D, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, 3 * d.I, d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, d.D, d.I, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, 2 * d.Fp, d.D, 1, d.F, stream));
+    CK(vbx_pack_bias(P + o[VBX_L_FF1B], 2 * d.F, w.layer[l].b1, 2 * d.Fp, 1, d.F, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, d.D, d.Fp, 0, 0, stream));
+  }
+  return 0;
+}
+
+extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream) {
+  CK(check_model(m));
+  VBX_REQUIRE(io && io->x && io->cond && io->times, "vbx_model_forward: null io field");
+  VBX_REQUIRE(!io->target || (io->loss_mask && io->loss), "vbx_model_forward: target needs loss_mask and loss");
+  VBX_REQUIRE((io->attn_mask == nullptr) == (io->attn_mask_p == nullptr), "vbx_model_forward: attn_mask and attn_mask_p go together");
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  Acts a;
+  carve_acts(m, a);
+  const float* P = m->params;
+  const long* G = m->off;
+  const bool tr = m->training != 0;
+
+  // to_embed(cat(x, cond * ~cond_mask))   (voicebox_pytorch.py:1035,1075-1078)
+  CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_in, d.B, d.N, d.D, stream));
+  CK(gemm_nt(a.embed_in, 2 * d.D, w.emb, 2 * d.D, (int)d.M0, d.D, 2 * d.D, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
+             nullptr, st));
+  // conv_embed(x) + x, register tokens in place   (:1080, :422-425)
+  CK(vbx_convpos_fwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a.xs[0],
+                     d.B, d.N, d.R, d.D, d.ks, stream));
+  // time embedding + every adaLN projection of the stack   (:1082, :273)
+  CK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a.four, a.pre, a.temb, d.B, d.D,
+                        d.Th, stream));
+  CK(vbx_adaln_proj_fwd(a.temb, w.ada, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
+
+  for (int l = 0; l < d.L; l++) {
+    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    const ALayer& y = a.layer[l];
+    const float* ada_l = a.ada + (size_t)l * d.B * 4 * d.D;  // [B][g1|b1|g2|b2]
+    float* x_in = a.xs[2 * l];
+    float* x_mid = a.xs[2 * l + 1];
+    float* x_out = a.xs[2 * l + 2];
+    // attn_prenorm -> to_qkv (+qk-norm, rotary) -> Attend -> to_out + residual   (:468-469, :317-333)
+    CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, d.B, d.Np, 0, d.Np, d.D, stream));
+    vbx_gemm_desc g{};
+    g.mode = VBX_GEMM_NT; g.epilogue = VBX_EPI_QKV; g.M = (int)d.M; g.N = 3 * d.I; g.K = d.D; g.lda = d.D; g.ldb = d.D;
+    g.A = y.hn1; g.B = w.layer[l].qkv; g.Np = d.Np; g.H = d.H; g.qk_scale = m->qk_norm ? 8.0f : 0.0f;
+    g.q_gamma = m->qk_norm ? P + o[VBX_L_QG] : nullptr;
+    g.k_gamma = m->qk_norm ? P + o[VBX_L_KG] : nullptr;
+    g.rot_cos = m->rot_cos; g.rot_sin = m->rot_sin;
+    g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
+    CK(vbx_gemm(&g, stream));
+    CK(vbx_attn_fwd(y.q16, y.k16, y.v, io->attn_mask_p, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
+    CK(gemm_nt(y.o, d.I, w.layer[l].out, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, st));
+    // ff_prenorm -> FeedForward (GEGLU) + residual   (:471-472, :337-349)
+    CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(gemm_nt(y.hn2, d.D, w.layer[l].w1, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.g, d.Fp, w.layer[l].b1, nullptr,
+               tr ? y.h1 : nullptr, st));
+    CK(gemm_nt(y.g, d.Fp, w.layer[l].w2, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
+               st));
+  }
+  // strip registers, final RMSNorm, to_pred   (:476-479, :1092)
+  CK(vbx_rmsnorm_fwd(a.xs[2 * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, d.B, d.Np, d.R, d.N, d.D, stream));
+  float* pred = io->pred ? io->pred : a.pred;
+  CK(gemm_nt(a.hf, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, VBX_EPI_F32, pred, d.D, nullptr, nullptr, nullptr, st));
+  if (io->target) CK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a.per_b, io->loss, d.B, d.N, d.D, stream));
+  return 0;
+}
+
+extern "C" int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, const float* gscale, void* stream) {
+  CK(check_model(m));
+  VBX_REQUIRE(m->training && m->grads && io && io->target && io->loss_mask, "vbx_model_backward_head: needs a training forward");
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  Acts a;
+  carve_acts(m, a);
+  const float* P = m->params;
+  float* Gd = m->grads;
+  const long* G = m->off;
+  const float* pred = io->pred ? io->pred : a.pred;
+  CK(vbx_masked_mse_bwd(pred, io->target, io->loss_mask, a.per_b, gscale, nullptr, a.dpb, d.B, d.N, d.D, stream));
+  CK(wgrad(a.dpb, d.D, a.hf, d.D, d.D, d.D, d.M0, a.slabs, Gd + G[VBX_P_PREDW], d.D, d.D, 0, 0, st));
+  CK(gemm_nn_bf16(a.dpb, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, a.dhn, d.D, st));
+  // gradient wrt the last residual snapshot: zero at the register rows, final-norm backward elsewhere
+  if (hipMemsetAsync(a.dx, 0, (size_t)d.M * d.D * sizeof(float), st) != hipSuccess ||
+      hipMemsetAsync(a.dxb, 0, (size_t)d.M * d.D * sizeof(u16), st) != hipSuccess) {
+    vbx_set_error("vbx_model_backward_head: memset failed");
+    return VBX_EINVAL;
+  }
+  CK(vbx_rmsnorm_bwd(a.xs[2 * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, d.B, d.Np, d.R, d.N, d.D, stream));
+  CK(vbx_reduce_norm_partials(a.npart, a.tmp2d, 0, d.B, (d.N + 15) / 16, d.D, 1, stream));
+  CK(vbx_sum_rows_f32(a.tmp2d, 1, d.D, Gd + G[VBX_P_FNG], d.D, 0, stream));
+  return 0;
+}
+
+extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, int l, void* stream) {
+  CK(check_model(m));
+  VBX_REQUIRE(m->training && m->grads && l >= 0 && l < m->L, "vbx_model_backward_layer: bad layer / not training");
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  Acts a;
+  carve_acts(m, a);
+  const float* P = m->params;
+  float* Gd = m->grads;
+  const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+  const ALayer& y = a.layer[l];
+  const float* ada_l = a.ada + (size_t)l * d.B * 4 * d.D;
+  float* dada_l = a.dada + (size_t)l * d.B * 4 * d.D;
+  const int chunks = (d.Np + 15) / 16;
+  const int M = (int)d.M;
+
+  // ---- FeedForward
+  CK(vbx_colsum_f32(a.dx, M, d.D, d.D, Gd + o[VBX_L_FF2B], a.cs_scratch, stream));
+  CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
+  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st));
+  CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
+  CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
+  CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
+  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
+  CK(vbx_rmsnorm_bwd(a.xs[2 * l + 1], ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, d.B, d.Np, 0, d.Np, d.D, stream));
+  CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  // ---- Attention
+  CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
+  CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
+  CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.o, a.dO, y.lse, a.delta, a.dq, a.dk,
+                  a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, stream));
+  CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
+                         m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
+                         3 * d.I, a.gpart, d.B, d.H, d.Np, stream));
+  if (m->qk_norm) {
+    const int rows = vbx_qknorm_rope_bwd_gpart_rows(d.B);
+    CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
+    CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+  }
+  CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
+  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
+  CK(vbx_rmsnorm_bwd(a.xs[2 * l], ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, d.B, d.Np, 0, d.Np, d.D, stream));
+  CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
+  CK(vbx_adaln_proj_bwd(a.temb, w.ada + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
+                        a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));
+  return 0;
+}
+
+extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream) {
+  CK(check_model(m));
+  VBX_REQUIRE(m->training && m->grads && io && io->times, "vbx_model_backward_embed: needs a training forward");
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  Acts a;
+  carve_acts(m, a);
+  const float* P = m->params;
+  float* Gd = m->grads;
+  const long* G = m->off;
+  CK(vbx_convpos_bwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, a.dx, a.dpre, a.de, a.deb, a.wpart,
+                     d.R ? Gd + G[VBX_P_REG] : nullptr, d.B, d.N, d.R, d.D, d.ks, stream));
+  CK(vbx_conv_wgrad_finalize(a.wpart, vbx_convpos_bwd_chunks(d.B, d.N), d.D, d.ks, Gd + G[VBX_P_CONVW], Gd + G[VBX_P_CONVB], stream));
+  CK(wgrad(a.deb, d.D, a.embed_in, 2 * d.D, d.D, 2 * d.D, d.M0, a.slabs, Gd + G[VBX_P_EMBW], d.D, 2 * d.D, 0, 0, st));
+  CK(vbx_colsum_f32(a.de, (int)d.M0, d.D, d.D, Gd + G[VBX_P_EMBB], a.cs_scratch, stream));
+  CK(vbx_time_embed_bwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], a.four, a.pre, a.dtemb, Gd + G[VBX_P_SINW],
+                        Gd + G[VBX_P_T1W], Gd + G[VBX_P_T1B], a.tscratch, d.B, d.D, d.Th, stream));
+  return 0;
+}

@@ -1,0 +1,226 @@
+"""Host side of the native runtime: flat parameter storage, arenas, and the stage-level C-ABI calls
+(vbx_model_forward / vbx_model_backward_*).  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import P, I, F
+
+# enum mirrors of include/vbx.h
+G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW"]
+L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B"]
+NG, NL = len(G_NAMES), len(L_NAMES)
+
+
+class VbxModel(C.Structure):
+    _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
+                ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
+                ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P)]
+
+
+class VbxIO(C.Structure):
+    _fields_ = [("x", P), ("cond", P), ("cond_mask", P), ("attn_mask", P), ("attn_mask_p", P), ("loss_mask", P),
+                ("times", P), ("target", P), ("pred", P), ("loss", P)]
+
+
+_runtime_protos_done = False
+
+
+def _rt():
+    global _runtime_protos_done
+    l = _lib.lib()
+    if not _runtime_protos_done:
+        MP, IP = C.POINTER(VbxModel), C.POINTER(VbxIO)
+        l.vbx_model_wpack_bytes.argtypes = [MP]
+        l.vbx_model_wpack_bytes.restype = C.c_size_t
+        l.vbx_model_act_bytes.argtypes = [MP]
+        l.vbx_model_act_bytes.restype = C.c_size_t
+        for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
+                         ("vbx_model_backward_head", [MP, IP, P, P]), ("vbx_model_backward_layer", [MP, IP, I, P]),
+                         ("vbx_model_backward_embed", [MP, IP, P])):
+            fn = getattr(l, name)
+            fn.argtypes = at
+            fn.restype = I
+        _runtime_protos_done = True
+    return l
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise _lib.VbxError(f"{what} failed (rc={rc}): {_lib.lib().vbx_last_error().decode()}")
+
+
+def rotary_tables(n_frames, n_registers, dim_head, theta, device):
+    """cos/sin of the rotary angles, built with the reference's own torch ops on the host so the table
+    is bit-identical to RotaryEmbedding.forward (voicebox_pytorch.py:173-191; registers sit at position
+    -10000, :436-443).  freqs = cat(ang, ang) so only the first dim_head/2 columns are stored."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dim_head, 2).float() / dim_head))
+    if n_registers > 0:
+        pos = torch.cat((torch.full((n_registers,), -10000, dtype=torch.long), torch.arange(n_frames, dtype=torch.long)))
+    else:
+        pos = torch.arange(n_frames, dtype=torch.long)
+    ang = torch.einsum("i,j->ij", pos.type_as(inv_freq), inv_freq)
+    return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+
+
+class FlatParams:
+    """All trainable parameters of a VoiceBox as views into ONE flat fp32 buffer, ordered so that the
+    backward pass completes gradients front-to-back (head, layers L-1..0, embed/time): contiguous
+    ranges can be all-reduced while earlier layers are still computing."""
+
+    def __init__(self, named_slots, depth):
+        # named_slots: dict slot-name -> nn.Parameter ; slot names "PREDW", "L3.QKVW", ...
+        order = ["PREDW", "FNG"]
+        for l in reversed(range(depth)):
+            order += [f"L{l}.{n}" for n in L_NAMES if f"L{l}.{n}" in named_slots]
+        order += ["EMBW", "EMBB", "CONVW", "CONVB", "REG", "SINW", "T1W", "T1B"]
+        self.order = [s for s in order if s in named_slots]
+        self.slots = named_slots
+        self.depth = depth
+        self.offsets = {}
+        off = 0
+        for s in self.order:
+            self.offsets[s] = off
+            off += named_slots[s].numel()
+            off = (off + 63) // 64 * 64  # keep every slot 256-byte aligned (16-byte vector loads need 4)
+        self.numel = off
+        self.flat = None
+        # stage boundaries (in floats) for bucketed gradient exchange: [head][layer L-1]...[layer 0][embed]
+        self.stage_ranges = []
+        first_layer_slot = lambda l: next(s for s in self.order if s.startswith(f"L{l}."))
+        bounds = [0] + [self.offsets[first_layer_slot(l)] for l in reversed(range(depth))] + [self.offsets["EMBW"], off]
+        self.stage_ranges = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+
+    def is_current(self):
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        for s in self.order:
+            p = self.slots[s]
+            if p.data_ptr() != base + 4 * self.offsets[s] or p.dtype != torch.float32:
+                return False
+        return True
+
+    def flatten(self):
+        dev = self.slots[self.order[0]].device
+        flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for s in self.order:
+                p = self.slots[s]
+                o = self.offsets[s]
+                view = flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.to(device=dev, dtype=torch.float32))
+                p.data = view
+        self.flat = flat
+        return flat
+
+    def offset_table(self):
+        tab = (C.c_long * (NG + self.depth * NL))()
+        for i, n in enumerate(G_NAMES):
+            tab[i] = self.offsets.get(n, 0)
+        for l in range(self.depth):
+            for j, n in enumerate(L_NAMES):
+                tab[NG + l * NL + j] = self.offsets.get(f"L{l}.{n}", 0)
+        return tab
+
+    def grad_views(self, gflat):
+        return [gflat[self.offsets[s]:self.offsets[s] + self.slots[s].numel()].view(self.slots[s].shape) for s in self.order]
+
+
+class Engine:
+    """One (batch, frames, training) configuration of a VoiceBox on one GPU: owns the packed-weight and
+    activation arenas and issues the native stage calls on the current HIP stream."""
+
+    def __init__(self, cfg, flat: FlatParams, B, N, training, device):
+        self.cfg, self.fp, self.B, self.N, self.training, self.device = cfg, flat, B, N, bool(training), device
+        _lib.call("vbx_check_device", device.index if device.index is not None else torch.cuda.current_device())
+        l = _rt()
+        m = VbxModel()
+        m.B, m.N, m.R, m.D, m.H, m.F, m.Th, m.L, m.ksize = (B, N, cfg["R"], cfg["D"], cfg["H"], cfg["F"], cfg["Th"],
+                                                            cfg["L"], cfg["ksize"])
+        m.qk_norm = 1 if cfg["qk_norm"] else 0
+        m.attn_scale = float(cfg["attn_scale"])
+        m.training = 1 if training else 0
+        self.off_table = flat.offset_table()
+        m.off = C.cast(self.off_table, P)
+        self.rot_cos, self.rot_sin = rotary_tables(N, cfg["R"], 64, cfg["theta"], device)
+        m.rot_cos, m.rot_sin = self.rot_cos.data_ptr(), self.rot_sin.data_ptr()
+        self.m = m
+        self.wpack = torch.empty(l.vbx_model_wpack_bytes(C.byref(m)), dtype=torch.uint8, device=device)
+        self.act = torch.empty(l.vbx_model_act_bytes(C.byref(m)), dtype=torch.uint8, device=device)
+        m.wpack, m.act = self.wpack.data_ptr(), self.act.data_ptr()
+        self.packed_version = None
+        self.io = VbxIO()
+        self._keep = None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        self.generation = 0
+
+    # -- weights
+    def bind_params(self):
+        flat = self.fp.flat
+        self.m.params = flat.data_ptr()
+        key = (flat.data_ptr(), flat._version)
+        if key != self.packed_version:
+            _check(_rt().vbx_model_pack_weights(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights")
+            self.packed_version = key
+
+    # -- forward
+    def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None):
+        """All tensors on self.device, fp32 contiguous / bool.  Returns the loss tensor (1,) if target is given,
+        else the prediction (B,N,D)."""
+        self.bind_params()
+        B, N, D = self.B, self.N, self.cfg["D"]
+        x, cond = x.contiguous(), cond.contiguous()
+        cm = cond_mask.to(torch.uint8).contiguous()
+        am = amp = lm = None
+        if attn_mask is not None:
+            am = attn_mask.to(torch.uint8).contiguous()
+            R = self.cfg["R"]
+            amp = torch.cat((torch.ones(B, R, dtype=torch.uint8, device=am.device), am), dim=1).contiguous() if R else am
+        io = self.io
+        io.x, io.cond, io.cond_mask = x.data_ptr(), cond.data_ptr(), cm.data_ptr()
+        io.attn_mask = am.data_ptr() if am is not None else None
+        io.attn_mask_p = amp.data_ptr() if amp is not None else None
+        io.times = times.data_ptr()
+        if target is not None:
+            target = target.contiguous()
+            lm = loss_mask.to(torch.uint8).contiguous()
+            io.target, io.loss_mask, io.loss = target.data_ptr(), lm.data_ptr(), self.loss.data_ptr()
+            pred = None
+            io.pred = None
+        else:
+            io.target = io.loss_mask = io.loss = None
+            pred = pred_out if pred_out is not None else torch.empty(B, N, D, dtype=torch.float32, device=self.device)
+            io.pred = pred.data_ptr()
+        self._keep = (x, cond, cm, am, amp, lm, times, target, pred)  # keep inputs alive until backward
+        self.generation += 1
+        _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
+        return self.loss if target is not None else pred
+
+    def replay_forward(self):
+        """Re-issue the last forward with the same (static) buffers -- the body of the captured ODE step."""
+        _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(self.io), _lib.current_stream()), "vbx_model_forward")
+
+    # -- backward, stage by stage; `on_stage(i, (lo, hi))` fires after the gradients in flat range [lo,hi) are final
+    def backward(self, gflat, gscale=None, on_stage=None):
+        assert self.training
+        self.m.grads = gflat.data_ptr()
+        st = _lib.current_stream()
+        l = _rt()
+        ranges = self.fp.stage_ranges
+        _check(l.vbx_model_backward_head(C.byref(self.m), C.byref(self.io), gscale.data_ptr() if gscale is not None else None, st),
+               "vbx_model_backward_head")
+        if on_stage:
+            on_stage(0, ranges[0])
+        L = self.cfg["L"]
+        for i, layer in enumerate(reversed(range(L))):
+            _check(l.vbx_model_backward_layer(C.byref(self.m), C.byref(self.io), layer, st), "vbx_model_backward_layer")
+            if on_stage:
+                on_stage(1 + i, ranges[1 + i])
+        _check(l.vbx_model_backward_embed(C.byref(self.m), C.byref(self.io), st), "vbx_model_backward_embed")
+        if on_stage:
+            on_stage(1 + L, ranges[1 + L])
+        self.m.grads = None

@@ -1,0 +1,455 @@
+"""Drop-in model classes: same constructors, call signatures and state-dict layout as the reference
+(voicebox_pytorch.py:878-1427, attend.py:38-137), with the compute done by libvbx_hip.so.
+
+There is NO eager/PyTorch fallback for the compute: forward on a non-gfx950 device or without the
+shared library raises.  The sub-modules below (Linear, Conv1d, ...) only *hold* parameters so that
+`state_dict()` keys/shapes equal the reference's and checkpoints interchange.
+"""
+import math
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import _lib
+from .engine import Engine, FlatParams
+from .masks import mask_from_frac_lengths, prob_mask_like, reduce_masks_with_and, take_draw
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+# --------------------------------------------------------------------------------------- Attend
+class _AttendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        B, H, Np, dh = q.shape
+        dev = q.device
+        q16, k16 = q.to(torch.float16).contiguous(), k.to(torch.float16).contiguous()
+        vb = v.to(torch.bfloat16).contiguous()
+        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        out = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(B, H, Np, dtype=torch.float32, device=dev)
+        _lib.call("vbx_attn_fwd", q16, k16, vb, m8, out, lse, B, H, Np, float(scale), _lib.current_stream())
+        ctx.save_for_backward(q16, k16, vb, out, lse, m8 if m8 is not None else torch.empty(0, device=dev))
+        ctx.has_mask, ctx.scale, ctx.in_dtype = m8 is not None, float(scale), q.dtype
+        return out.view(B, Np, H, 64).permute(0, 2, 1, 3).to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q16, k16, vb, out, lse, m8 = ctx.saved_tensors
+        B, H, Np, _ = q16.shape
+        dev = q16.device
+        do = dout.permute(0, 2, 1, 3).reshape(B, Np, H * 64).to(torch.bfloat16).contiguous()
+        qb, kb = q16.to(torch.bfloat16), k16.to(torch.bfloat16)
+        delta = torch.empty(B, H, Np, dtype=torch.float32, device=dev)
+        dq = torch.empty(B, H, Np, 64, dtype=torch.float32, device=dev)
+        dk = torch.empty_like(dq)
+        dv = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
+        _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, do, lse, delta, dq, dk, dv,
+                  H * 64, B, H, Np, ctx.scale, _lib.current_stream())
+        dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
+        return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None
+
+
+class Attend(nn.Module):
+    """attend.py:38-137.  `flash` is accepted for API compatibility: both reference paths compute the same
+    function and this implementation is always the fused HIP kernel."""
+
+    def __init__(self, dropout=0., flash=False, scale=None):
+        super().__init__()
+        if dropout != 0.:
+            raise NotImplementedError("attention dropout > 0 is not implemented in the HIP path")
+        self.dropout, self.flash, self.scale = dropout, flash, scale
+
+    def forward(self, q, k, v, mask=None):
+        if q.shape[-1] != 64:
+            raise NotImplementedError("the HIP attention kernel is built for dim_head == 64")
+        if exists(mask) and mask.ndim != 2:
+            raise NotImplementedError("only (batch, keys) key-padding masks are supported")
+        scale = default(self.scale, q.shape[-1] ** -0.5)
+        return _AttendFn.apply(q, k, v, mask, scale)
+
+
+# --------------------------------------------------------------------------------------- parameter holders
+class LearnedSinusoidalPosEmb(nn.Module):  # voicebox_pytorch.py:154-167
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class RotaryEmbedding(nn.Module):  # voicebox_pytorch.py:172-191
+    def __init__(self, dim, theta=50000):
+        super().__init__()
+        self.theta = theta
+        self.register_buffer("inv_freq", 1.0 / (theta ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+class ConvPositionEmbed(nn.Module):  # voicebox_pytorch.py:203-233
+    def __init__(self, dim, *, kernel_size, groups=None):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        groups = default(groups, dim)
+        if groups != dim:
+            raise NotImplementedError("only the full depthwise conv positional embedding (groups == dim) is implemented")
+        self.dw_conv1d = nn.Sequential(nn.Conv1d(dim, dim, kernel_size, groups=groups, padding=kernel_size // 2), nn.GELU())
+
+
+class RMSNorm(nn.Module):  # voicebox_pytorch.py:237-247
+    def __init__(self, dim):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(dim))
+
+
+class AdaptiveRMSNorm(nn.Module):  # voicebox_pytorch.py:249-276
+    def __init__(self, dim, cond_dim=None):
+        super().__init__()
+        cond_dim = default(cond_dim, dim)
+        self.scale = dim ** 0.5
+        self.to_gamma = nn.Linear(cond_dim, dim)
+        self.to_beta = nn.Linear(cond_dim, dim)
+        nn.init.zeros_(self.to_gamma.weight)
+        nn.init.ones_(self.to_gamma.bias)
+        nn.init.zeros_(self.to_beta.weight)
+        nn.init.zeros_(self.to_beta.bias)
+
+
+class MultiheadRMSNorm(nn.Module):  # voicebox_pytorch.py:280-287
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(heads, 1, dim))
+
+
+class Attention(nn.Module):  # voicebox_pytorch.py:289-333
+    def __init__(self, dim, dim_head=64, heads=8, dropout=0, flash=False, qk_norm=False, qk_norm_scale=10):
+        super().__init__()
+        self.heads = heads
+        dim_inner = dim_head * heads
+        self.attend = Attend(dropout, flash=flash, scale=qk_norm_scale if qk_norm else None)
+        self.qk_norm = qk_norm
+        if qk_norm:
+            self.q_norm = MultiheadRMSNorm(dim_head, heads=heads)
+            self.k_norm = MultiheadRMSNorm(dim_head, heads=heads)
+        self.to_qkv = nn.Linear(dim, dim_inner * 3, bias=False)
+        self.to_out = nn.Linear(dim_inner, dim, bias=False)
+
+
+class GEGLU(nn.Module):  # voicebox_pytorch.py:337-340 (fused into the FF-in GEMM epilogue)
+    pass
+
+
+def FeedForward(dim, mult=4, dropout=0.):  # voicebox_pytorch.py:342-349
+    if dropout != 0.:
+        raise NotImplementedError("feed-forward dropout > 0 is not implemented in the HIP path")
+    dim_inner = int(dim * mult * 2 / 3)
+    return nn.Sequential(nn.Linear(dim, dim_inner * 2), GEGLU(), nn.Dropout(dropout), nn.Linear(dim_inner, dim))
+
+
+class Transformer(nn.Module):
+    """voicebox_pytorch.py:353-479.  Holds the stack's parameters with the reference's module tree.  The
+    compute runs inside VoiceBox (the native runtime fuses the whole stack); a standalone
+    Transformer.forward is a "next" row and raises for now."""
+
+    def __init__(self, dim, *, depth, dim_head=64, heads=8, ff_mult=4, attn_dropout=0., ff_dropout=0.,
+                 num_register_tokens=0., attn_flash=False, adaptive_rmsnorm=False, adaptive_rmsnorm_cond_dim_in=None,
+                 use_unet_skip_connection=False, skip_connect_scale=None, attn_qk_norm=False, use_gateloop_layers=False,
+                 gateloop_use_jax=False):
+        super().__init__()
+        assert depth % 2 == 0
+        if use_unet_skip_connection:
+            raise NotImplementedError("u-net skip connections are never enabled by VoiceBox (voicebox_pytorch.py:948-962)")
+        if use_gateloop_layers:
+            raise NotImplementedError("GateLoop layers (default off, voicebox_pytorch.py:898) are not built yet")
+        self.layers = nn.ModuleList([])
+        self.rotary_emb = RotaryEmbedding(dim=dim_head)
+        self.num_register_tokens = int(num_register_tokens)
+        self.has_register_tokens = num_register_tokens > 0
+        if self.has_register_tokens:
+            self.register_tokens = nn.Parameter(torch.randn(int(num_register_tokens), dim))
+        self.adaptive_rmsnorm = adaptive_rmsnorm
+        norm = (lambda: AdaptiveRMSNorm(dim, cond_dim=adaptive_rmsnorm_cond_dim_in)) if adaptive_rmsnorm else (lambda: RMSNorm(dim))
+        self.skip_connect_scale = default(skip_connect_scale, 2 ** -0.5)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                None, None, norm(),
+                Attention(dim=dim, dim_head=dim_head, heads=heads, dropout=attn_dropout, flash=attn_flash, qk_norm=attn_qk_norm),
+                norm(), FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout)]))
+        self.final_norm = RMSNorm(dim)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, x, mask=None, adaptive_rmsnorm_cond=None):
+        raise NotImplementedError("standalone Transformer.forward is not built yet; use VoiceBox (the stack runs fused "
+                                  "inside the native runtime)")
+
+
+# --------------------------------------------------------------------------------------- VoiceBox
+class _VoiceBoxLossFn(torch.autograd.Function):
+    """loss = VoiceBox(w, target=flow) as ONE autograd node: forward = vbx_model_forward, backward =
+    vbx_model_backward_{head,layer,embed} into a fresh flat gradient buffer whose views are returned per parameter."""
+
+    @staticmethod
+    def forward(ctx, vb, eng, x, cond, cond_mask, times, attn_mask, target, loss_mask, *params):
+        loss = eng.forward(x, cond, cond_mask, times, attn_mask=attn_mask, target=target, loss_mask=loss_mask)
+        ctx.vb, ctx.eng, ctx.gen = vb, eng, eng.generation
+        return loss.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        vb, eng = ctx.vb, ctx.eng
+        if eng.generation != ctx.gen:
+            raise RuntimeError("VoiceBox: another forward of the same (batch, frames) shape ran before this backward; the "
+                               "activation arena holds one training forward at a time")
+        gflat = torch.zeros(vb._flat.numel, dtype=torch.float32, device=eng.device)
+        gscale = gloss.detach().to(torch.float32).reshape(1).contiguous()
+        eng.backward(gflat, gscale=gscale)
+        return (None,) * 9 + tuple(vb._flat.grad_views(gflat))
+
+
+class VoiceBox(nn.Module):
+    def __init__(self, *, num_cond_tokens=None, audio_enc_dec=None, dim_in=None, dim_cond_emb=1024, dim=1024, depth=24,
+                 dim_head=64, heads=16, ff_mult=4, ff_dropout=0., time_hidden_dim=None, conv_pos_embed_kernel_size=31,
+                 conv_pos_embed_groups=None, attn_dropout=0, attn_flash=False, attn_qk_norm=True, use_gateloop_layers=False,
+                 num_register_tokens=16, p_drop_prob=0.3, frac_lengths_mask=(0.7, 1.), condition_on_text=True):
+        super().__init__()
+        dim_in = default(dim_in, dim)
+        time_hidden_dim = default(time_hidden_dim, dim * 4)
+        assert not (condition_on_text and not exists(num_cond_tokens)), \
+            'number of conditioning tokens must be specified (whether phonemes or semantic token ids) if training conditional voicebox'
+        if condition_on_text:
+            raise NotImplementedError("text conditioning (to_cond_emb / CFG) is a 'next' row (SURVEY 8(f) #2); "
+                                      "construct with condition_on_text = False")
+        if exists(audio_enc_dec):
+            raise NotImplementedError("audio codecs are out of scope of the hot path: feed latents directly")
+        if dim_in != dim:
+            raise NotImplementedError("dim_in != dim (proj_in) is not built")
+        if dim_head != 64:
+            raise NotImplementedError("the HIP kernels are built for dim_head == 64")
+        if dim % 64 != 0 or dim > 2048 or heads % 2 != 0:
+            raise NotImplementedError("dim must be a multiple of 64 (<= 2048) and heads even")
+        if conv_pos_embed_kernel_size != 31:
+            raise NotImplementedError("conv_pos_embed_kernel_size must be 31")
+        self.audio_enc_dec = None
+        self.proj_in = nn.Identity()
+        self.sinu_pos_emb = nn.Sequential(LearnedSinusoidalPosEmb(dim), nn.Linear(dim, time_hidden_dim), nn.SiLU())
+        self.dim_cond_emb = 0
+        self.condition_on_text = False
+        self.num_cond_tokens = num_cond_tokens
+        self.p_drop_prob = p_drop_prob
+        self.frac_lengths_mask = frac_lengths_mask
+        self.to_embed = nn.Linear(dim_in * 2, dim)
+        self.null_cond = nn.Parameter(torch.zeros(dim_in), requires_grad=False)
+        self.conv_embed = ConvPositionEmbed(dim=dim, kernel_size=conv_pos_embed_kernel_size, groups=conv_pos_embed_groups)
+        self.transformer = Transformer(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult,
+                                       ff_dropout=ff_dropout, attn_dropout=attn_dropout, attn_flash=attn_flash,
+                                       attn_qk_norm=attn_qk_norm, num_register_tokens=num_register_tokens,
+                                       adaptive_rmsnorm=True, adaptive_rmsnorm_cond_dim_in=time_hidden_dim,
+                                       use_gateloop_layers=use_gateloop_layers)
+        self.to_pred = nn.Linear(dim, dim_in, bias=False)
+        self._cfg = dict(D=dim, H=heads, L=depth, F=int(dim * ff_mult * 2 / 3), Th=time_hidden_dim,
+                         R=int(num_register_tokens), ksize=conv_pos_embed_kernel_size, qk_norm=bool(attn_qk_norm),
+                         attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0)
+        self._flat = None
+        self._engines = {}
+
+    # ---- native plumbing
+    def _slots(self):
+        t = self.transformer
+        s = {"SINW": self.sinu_pos_emb[0].weights, "T1W": self.sinu_pos_emb[1].weight, "T1B": self.sinu_pos_emb[1].bias,
+             "EMBW": self.to_embed.weight, "EMBB": self.to_embed.bias, "CONVW": self.conv_embed.dw_conv1d[0].weight,
+             "CONVB": self.conv_embed.dw_conv1d[0].bias, "FNG": t.final_norm.gamma, "PREDW": self.to_pred.weight}
+        if t.has_register_tokens:
+            s["REG"] = t.register_tokens
+        for l, layer in enumerate(t.layers):
+            _, _, n1, attn, n2, ff = layer
+            p = f"L{l}."
+            s[p + "G1W"], s[p + "G1B"] = n1.to_gamma.weight, n1.to_gamma.bias
+            s[p + "B1W"], s[p + "B1B"] = n1.to_beta.weight, n1.to_beta.bias
+            s[p + "G2W"], s[p + "G2B"] = n2.to_gamma.weight, n2.to_gamma.bias
+            s[p + "B2W"], s[p + "B2B"] = n2.to_beta.weight, n2.to_beta.bias
+            if attn.qk_norm:
+                s[p + "QG"], s[p + "KG"] = attn.q_norm.gamma, attn.k_norm.gamma
+            s[p + "QKVW"], s[p + "OUTW"] = attn.to_qkv.weight, attn.to_out.weight
+            s[p + "FF1W"], s[p + "FF1B"], s[p + "FF2W"], s[p + "FF2B"] = ff[0].weight, ff[0].bias, ff[3].weight, ff[3].bias
+        return s
+
+    def flat_params(self):
+        """Ensures every trainable parameter is a view into one flat fp32 buffer on the model's device."""
+        if self._flat is None:
+            self._flat = FlatParams(self._slots(), self._cfg["L"])
+        if not self._flat.is_current():
+            self._flat.slots = self._slots()
+            self._flat.flatten()
+            self._engines.clear()
+        return self._flat
+
+    def engine(self, B, N, training):
+        fp = self.flat_params()
+        dev = fp.flat.device
+        if dev.type != "cuda":
+            raise _lib.VbxError("VoiceBox compute runs only on an MI355X (gfx950) through libvbx_hip.so; "
+                                f"parameters are on '{dev}' and there is no CPU fallback")
+        key = (B, N, bool(training))
+        eng = self._engines.get(key)
+        if eng is None:
+            if len(self._engines) >= 4:  # arenas are large: keep a few shapes only
+                self._engines.pop(next(iter(self._engines)))
+            eng = Engine(self._cfg, fp, B, N, training, dev)
+            self._engines[key] = eng
+        return eng
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @torch.inference_mode()
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):  # voicebox_pytorch.py:972-985
+        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale == 1.:
+            return logits
+        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
+        return null_logits + (logits - null_logits) * cond_scale
+
+    def forward(self, x, *, times, cond_token_ids, self_attn_mask=None, cond_drop_prob=0.1, target=None, cond=None,
+                cond_mask=None):  # voicebox_pytorch.py:987-1115
+        cond = default(cond, target)  # :1003
+        assert exists(cond), "either cond or target must be given"
+        batch, seq_len, cond_dim = cond.shape
+        assert cond_dim == x.shape[-1]
+        dev = self.device
+        x, cond = x.to(dev, torch.float32), cond.to(dev, torch.float32)
+        times = torch.as_tensor(times, device=dev).to(torch.float32)
+        if times.ndim == 0:  # :1015-1019 (odeint hands a 0-dim time)
+            times = times.expand(batch)
+        if times.ndim == 1 and times.shape[0] == 1:
+            times = times.expand(batch)
+        times = times.contiguous()
+        if self.training:  # :1023-1029
+            if not exists(cond_mask):
+                frac = take_draw("frac_lengths")
+                if frac is None:
+                    frac = torch.zeros((batch,), device=dev).float().uniform_(*self.frac_lengths_mask)
+                cond_mask = mask_from_frac_lengths(seq_len, frac.to(dev))
+        elif not exists(cond_mask):
+            cond_mask = torch.ones((batch, seq_len), device=dev, dtype=torch.bool)
+        cond_mask = cond_mask.to(dev)
+        if cond_drop_prob > 0.:
+            # same failure as the reference on an unconditional model (:1050-1053)
+            raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
+        if exists(self_attn_mask):
+            self_attn_mask = self_attn_mask.to(dev)
+        if not exists(target):
+            eng = self.engine(batch, seq_len, training=False)
+            return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask)
+        target = target.to(dev, torch.float32)
+        loss_mask = reduce_masks_with_and(cond_mask, self_attn_mask)  # :1099
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            eng = self.engine(batch, seq_len, training=True)
+            fp = self._flat
+            params = [fp.slots[s] for s in fp.order]
+            return _VoiceBoxLossFn.apply(self, eng, x, cond, cond_mask, times, self_attn_mask, target, loss_mask, *params)
+        eng = self.engine(batch, seq_len, training=False)
+        return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask, target=target, loss_mask=loss_mask).clone().reshape(())
+
+
+# --------------------------------------------------------------------------------------- CFM wrapper
+def is_probably_audio_from_shape(t):  # voicebox_pytorch.py:1119-1120
+    return exists(t) and (t.ndim == 2 or (t.ndim == 3 and t.shape[1] == 1))
+
+
+class ConditionalFlowMatcherWrapper(nn.Module):
+    def __init__(self, voicebox, text_to_semantic=None, duration_predictor=None, sigma=0., ode_atol=1e-5, ode_rtol=1e-5,
+                 use_torchode=False, torchdiffeq_ode_method='midpoint', torchode_method_klass=None, cond_drop_prob=0.):
+        super().__init__()
+        assert isinstance(voicebox, VoiceBox)
+        self.sigma = sigma
+        self.voicebox = voicebox
+        self.condition_on_text = voicebox.condition_on_text
+        assert not (not self.condition_on_text and exists(text_to_semantic)), \
+            'TextToSemantic should not be passed in if not conditioning on text'
+        if exists(text_to_semantic) or exists(duration_predictor):
+            raise NotImplementedError("text front-ends are out of scope of the hot path")
+        if use_torchode:
+            raise NotImplementedError("the adaptive torchode/Tsit5 path is replaced by the built-in fixed-step midpoint solver")
+        if torchdiffeq_ode_method != 'midpoint':
+            raise NotImplementedError("only the fixed-grid midpoint method (the reference default) is built")
+        self.text_to_semantic = None
+        self.duration_predictor = None
+        self.cond_drop_prob = cond_drop_prob
+        self.use_torchode = False
+        self.odeint_kwargs = dict(atol=ode_atol, rtol=ode_rtol, method=torchdiffeq_ode_method)  # atol/rtol: unused by fixed grids
+        self._samplers = {}
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def load(self, path, strict=True):  # voicebox_pytorch.py:1167-1173
+        path = Path(path)
+        assert path.exists()
+        pkg = torch.load(str(path), map_location='cpu')
+        self.load_state_dict(pkg['model'], strict=strict)
+        return pkg
+
+    @torch.inference_mode()
+    def sample(self, *, cond=None, texts=None, text_token_ids=None, semantic_token_ids=None, phoneme_ids=None,
+               cond_mask=None, steps=3, cond_scale=1., decode_to_audio=True, decode_to_codes=False,
+               max_semantic_token_ids=2048, spec_decode=False, spec_decode_gamma=5, use_graph=True):
+        """voicebox_pytorch.py:1175-1330 with torchdiffeq's fixed-grid midpoint replaced by the built-in solver
+        (solver.py): `steps` time points on linspace(0,1,steps) -> 2*(steps-1) function evaluations."""
+        from .solver import MidpointSampler
+
+        if is_probably_audio_from_shape(cond):
+            raise NotImplementedError("raw-audio conditioning needs an audio codec (out of scope)")
+        num_cond_inputs = sum(map(exists, (texts, text_token_ids, semantic_token_ids, phoneme_ids)))
+        assert num_cond_inputs <= 1
+        assert num_cond_inputs == 0, 'no conditioning inputs should be given if not conditioning on text'
+        assert exists(cond), "cond (B, frames, dim) is required"
+        if cond_scale != 1.:
+            # reference: second pass with cond_drop_prob = 1 -> AttributeError on an unconditional model
+            raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
+        self.voicebox.eval()
+        dev = self.device
+        cond = cond.to(dev, torch.float32)
+        y0 = take_draw("y0")
+        y0 = torch.randn_like(cond) if y0 is None else y0.to(dev, torch.float32)
+        B, N, _ = cond.shape
+        key = (B, N, steps, bool(use_graph))
+        smp = self._samplers.get(key)
+        if smp is None:
+            if len(self._samplers) >= 2:
+                self._samplers.pop(next(iter(self._samplers)))
+            smp = MidpointSampler(self.voicebox, B, N, steps, use_graph=use_graph)
+            self._samplers[key] = smp
+        return smp.run(y0, cond, cond_mask)
+
+    def forward(self, x1, *, mask=None, semantic_token_ids=None, phoneme_ids=None, cond=None, cond_mask=None,
+                input_sampling_rate=None):  # voicebox_pytorch.py:1332-1427
+        if is_probably_audio_from_shape(x1) or is_probably_audio_from_shape(cond):
+            assert exists(self.voicebox.audio_enc_dec), 'audio_enc_dec must be set on VoiceBox to train directly on raw audio'
+        assert self.condition_on_text or not (exists(semantic_token_ids) or exists(phoneme_ids)), \
+            'semantic or phoneme ids should not be passed in if not conditioning on text'
+        dev = self.device
+        x1 = x1.to(dev, torch.float32).contiguous()
+        batch = x1.shape[0]
+        x0 = take_draw("x0")
+        x0 = torch.randn_like(x1) if x0 is None else x0.to(dev, torch.float32)  # :1399
+        times = take_draw("times")
+        times = torch.rand((batch,), dtype=x1.dtype, device=dev) if times is None else times.to(dev, torch.float32)  # :1403
+        w = torch.empty_like(x1)
+        flow = torch.empty_like(x1)
+        _lib.call("vbx_cfm_inputs", x1, x0.contiguous(), times.contiguous(), float(self.sigma), w, flow, batch,
+                  x1[0].numel(), _lib.current_stream())  # :1408-1410
+        self.voicebox.train()  # :1414
+        return self.voicebox(w, cond=cond, cond_mask=cond_mask, times=times, target=flow, self_attn_mask=mask,
+                             cond_token_ids=None, cond_drop_prob=self.cond_drop_prob)
