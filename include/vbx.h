@@ -74,6 +74,13 @@ typedef struct {
   void* qb;  void* kb;      /* bf16 [B,H,Np,64]  : backward operands (may be NULL in eval) */
   void* v;                  /* bf16 [B,H,Np,64] */
   float* q_rnorm; float* k_rnorm; /* fp32 [B,H,Np] 1/max(|t|,1e-12) (may be NULL in eval) */
+  int f16;                  /* 1: A and B hold fp16 (not bf16) -- NT mode only (the forward GEMMs).  Everything that
+                             * feeds the attention logits 10*q.k (|q|=|k|=8, std ~80) is precision critical: bf16
+                             * operands (2^-9) perturb the logits by ~0.2, fp16 (2^-11) by ~0.05 at the same MFMA
+                             * rate; the backward GEMMs keep bf16 (gradient range).  With f16=1 EPI_GEGLU writes
+                             * C as fp16. */
+  void* v16;                /* EPI_QKV: fp16 copy of v [B,H,Np,64] (forward P.V operand); v (bf16) may then be NULL */
+  void* C3;                 /* EPI_GEGLU: optional bf16 copy of C [M,ldc] (wgrad operand) */
 } vbx_gemm_desc;
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
@@ -90,6 +97,7 @@ int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, float* dst, 
  * Rows: for each batch b, rows n in [n0, n0+rows_per_batch) of x (row stride Np per batch);
  * output y is dense [B*rows_per_batch, D]. */
 int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
+                    void* y_f16 /* optional fp16 copy (same dense layout); y_bf16 may then be NULL */,
                     int B, int Np, int n0, int rows_per_batch, int D, void* stream);
 /* backward: dx_out = dx_in (or 0 if NULL) + d/dx ; partial dgamma/dbeta sums per 16-row chunk:
  * part[b][chunk][2][D] (chunk count = ceil(rows_per_batch/16)).  dy is dense bf16 [B*rows, D].
@@ -100,15 +108,17 @@ int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const vo
 
 /* ------------------------------------------------------------------ attention */
 /* Attend.forward math path (attend.py:121-135): softmax(scale * q k^T + key-pad mask) v, fused
- * flash-style (scores never materialised).  q16,k16 fp16 and v bf16 are [B,H,Np,64]; mask uint8
- * [B,Np] or NULL; out bf16 [B,Np,H*64]; lse fp32 [B,H,Np] in log2 units (m + log2 l). */
-int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, float* lse,
-                 int B, int H, int Np, float scale, void* stream);
+ * flash-style (scores never materialised).  q16,k16,v16 fp16 are [B,H,Np,64]; mask uint8
+ * [B,Np] or NULL; lse fp32 [B,H,Np] in log2 units (m + log2 l). */
+int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, const uint8_t* mask,
+                 void* out16 /* fp16 [B,Np,H*64] */, void* out_bf16 /* optional bf16 copy (backward operand) */,
+                 float* lse, int B, int H, int Np, float scale, void* stream);
 /* backward.  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
  * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d]. */
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
-                 const uint8_t* mask, const void* out, const void* dout, const float* lse, float* delta,
-                 float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale, void* stream);
+                 const uint8_t* mask, const void* out /* forward output [B,Np,H*64] */, int out_is_f16,
+                 const void* dout, const float* lse, float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H,
+                 int Np, float scale, void* stream);
 /* backward of MultiheadRMSNorm + rotary (voicebox_pytorch.py:286-287,199): consumes dq/dk fp32
  * [B,H,Np,64] and the saved q16/k16 + rnorm, writes d(raw q|k) bf16 into dqkv[(b*Np+n)*ld + which*H*64
  * + h*64 + d] and partial gamma grads gpart[2][vbx_qknorm_rope_bwd_gpart_rows(B)][H][64]. */
@@ -119,8 +129,8 @@ int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const
 
 /* ------------------------------------------------------------------ small / memory-bound ops */
 /* x_cat bf16 [B*N, 2*D] = (x, cond * ~cond_mask)   (voicebox_pytorch.py:1035,1075-1076) */
-int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_bf16, int B, int N,
-                         int D, void* stream);
+int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_f16,
+                         void* out_bf16 /* optional copy: wgrad operand */, int B, int N, int D, void* stream);
 /* ConvPositionEmbed + residual + register tokens (voicebox_pytorch.py:220-233,1080,422-425):
  * xs[b, R+n, :] = e[b,n,:] + mask*gelu(conv(mask*e)[b,n,:] + bias);  xs[b, r<R, :] = reg[r,:]. */
 int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
@@ -139,7 +149,7 @@ int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, 
 int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, const float* four, const float* pre,
                        const float* dtemb, float* dw_sin, float* dw1, float* db1, float* scratch /* B*D floats */, int B,
                        int D, int Th, void* stream);
-/* all adaLN projections at once: ada[b][j] = bias[j] + sum_t temb[b][t] * W[j][t],  W bf16 [J,Th]
+/* all adaLN projections at once: ada[b][j] = bias[j] + sum_t temb[b][t] * W[j][t],  W fp16 [J,Th]
  * (J = depth*2 norms*(gamma,beta)*D) (voicebox_pytorch.py:273). */
 int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias, float* ada, int B, int Th, int J,
                        int group /* output layout ada[j/group][b][j%group]; <=0 or J: plain [b][j] */, void* stream);
@@ -180,10 +190,10 @@ int vbx_ode_set_time(float* times, int B, const float* table, const int* counter
 int vbx_axpy_ctr(const float* y, const float* f, const float* table, const int* counter, int slot, float* out, long n,
                  void* stream);
 int vbx_counter_add(int* counter, int inc, void* stream);
-/* fp32 -> bf16 weight packing with optional row map / K padding:
+/* fp32 -> bf16 and/or fp16 weight packing with optional row map / K padding:
  * dst[p][c] = (src row of p valid && c < src_cols) ? src[row][c] : 0 ; dst is [dst_rows, dst_cols] */
-int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, int dst_rows, int dst_cols,
-                    int rowmap, int F, void* stream);
+int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16 /* or NULL */, void* dst_f16 /* or NULL */,
+                    int dst_rows, int dst_cols, int rowmap, int F, void* stream);
 int vbx_pack_bias(const float* src, int n, float* dst, int dst_n, int rowmap, int F, void* stream);
 /* fused Adam (torch.optim.Adam semantics, no weight decay/amsgrad) over a flat fp32 buffer; grads are
  * pre-multiplied by *gscale (device scalar, e.g. clip coefficient) if non-NULL. */
@@ -242,6 +252,9 @@ int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);
 int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, const float* gscale, void* stream);
 int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, int layer, void* stream);
 int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream);
+
+/* tests/debug only: device pointer of a named tensor inside the activation arena (NULL if unknown) */
+void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer);
 
 /* ------------------------------------------------------------------ hardware probes (tests only) */
 int vbx_probe_tr16(const void* in_u16_4096, const int* lane_elem_off, void* out_u16_256, void* stream);

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
         ("mode", I), ("epilogue", I), ("M", I), ("N", I), ("K", I), ("lda", I), ("ldb", I), ("ldc", I),
         ("A", P), ("B", P), ("C", P), ("bias", P), ("resid", P), ("C2", P), ("splits", I),
         ("Np", I), ("H", I), ("qk_scale", F), ("q_gamma", P), ("k_gamma", P), ("rot_cos", P), ("rot_sin", P),
-        ("q16", P), ("k16", P), ("qb", P), ("kb", P), ("v", P), ("q_rnorm", P), ("k_rnorm", P),
+        ("q16", P), ("k16", P), ("qb", P), ("kb", P), ("v", P), ("q_rnorm", P), ("k_rnorm", P), ("f16", I), ("v16", P), ("C3", P),
     ]
 
 
@@ -31,13 +31,13 @@ _PROTOS = {
     "vbx_check_device": [I],
     "vbx_gemm": [C.POINTER(GemmDesc), P],
     "vbx_splitk_reduce": [P, I, I, I, P, I, I, I, I, I, I, P],
-    "vbx_rmsnorm_fwd": [P, P, P, L, P, I, I, I, I, I, P],
+    "vbx_rmsnorm_fwd": [P, P, P, L, P, P, I, I, I, I, I, P],
     "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, I, I, I, I, I, P],
-    "vbx_attn_fwd": [P, P, P, P, P, P, I, I, I, F, P],
-    "vbx_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "vbx_attn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
+    "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P],
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
-    "vbx_pack_embed_input": [P, P, P, P, I, I, I, P],
+    "vbx_pack_embed_input": [P, P, P, P, P, I, I, I, P],
     "vbx_convpos_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd_chunks": [I, I],
@@ -60,7 +60,7 @@ _PROTOS = {
     "vbx_ode_set_time": [P, I, P, P, I, P],
     "vbx_axpy_ctr": [P, P, P, P, I, P, L, P],
     "vbx_counter_add": [P, I, P],
-    "vbx_pack_weight": [P, I, I, P, I, I, I, I, P],
+    "vbx_pack_weight": [P, I, I, P, P, I, I, I, I, P],
     "vbx_pack_bias": [P, I, P, I, I, I, P],
     "vbx_adam_step": [P, P, P, P, L, F, F, F, F, I, P, P],
     "vbx_sumsq": [P, L, P, P, P],

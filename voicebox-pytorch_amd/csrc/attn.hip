@@ -65,6 +65,12 @@ VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+VBX_DEV f16x8 pack_frag_f16(const f32x16& p, int t2) {
+  f16x8 r;
+#pragma unroll
+  for (int s = 0; s < 8; s++) r[s] = (_Float16)p[8 * t2 + s];
+  return r;
+}
 VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
   bf16x8 r;
 #pragma unroll
@@ -77,8 +83,8 @@ VBX_DEV int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * h
 // ============================================================================ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                           const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
-                                                          u16* __restrict__ out, float* __restrict__ lse, int H, int Np,
-                                                          float scale2) {
+                                                          u16* __restrict__ out, u16* __restrict__ outb,
+                                                          float* __restrict__ lse, int H, int Np, float scale2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -169,10 +175,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
         if (kb < nblk) {
 #pragma unroll
           for (int t2 = 0; t2 < 2; t2++) {
-            const bf16x8 pf = pack_frag(s[kb], t2);
+            const f16x8 pf = pack_frag_f16(s[kb], t2);
 #pragma unroll
             for (int db = 0; db < 2; db++)
-              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, kb * 32 + 16 * t2, db * 32, lane), pf, o[db], 0, 0, 0);
+              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                  __builtin_bit_cast(f16x8, tr_frag(Vt, kb * 32 + 16 * t2, db * 32, lane)), pf, o[db], 0, 0, 0);
           }
         }
       }
@@ -189,16 +196,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
     if (q < Np) {
-      u16* orow = out + ((long)b * Np + q) * (H * 64) + h * 64;
+      const long ro = ((long)b * Np + q) * (H * 64) + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; db++)
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
           const int d = db * 32 + 8 * g4 + 4 * hi;
-          uint2 pk;
-          pk.x = pack_bf16x2(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
-          pk.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-          *reinterpret_cast<uint2*>(orow + d) = pk;
+          const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
+                      v3 = o[db][4 * g4 + 3] * inv;
+          *reinterpret_cast<uint2*>(out + ro + d) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
+          if (outb) *reinterpret_cast<uint2*>(outb + ro + d) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       if (hi == 0) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
     }
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
 
 // ============================================================================ backward: delta
 // delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d]
+template <bool O_F16>
 __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
                                   int Np, long total_chunks) {
   const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one 8-element chunk per thread
@@ -217,8 +225,10 @@ __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restri
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    s += bf16_to_f32((u16)(aw[i] & 0xffff)) * bf16_to_f32((u16)(gw[i] & 0xffff));
-    s += bf16_to_f32((u16)(aw[i] >> 16)) * bf16_to_f32((u16)(gw[i] >> 16));
+    const float o0 = O_F16 ? f16_to_f32((u16)(aw[i] & 0xffff)) : bf16_to_f32((u16)(aw[i] & 0xffff));
+    const float o1 = O_F16 ? f16_to_f32((u16)(aw[i] >> 16)) : bf16_to_f32((u16)(aw[i] >> 16));
+    s += o0 * bf16_to_f32((u16)(gw[i] & 0xffff));
+    s += o1 * bf16_to_f32((u16)(gw[i] >> 16));
   }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
@@ -488,20 +498,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
 
 static const float LOG2E = 1.4426950408889634f;
 
-extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, float* lse,
-                            int B, int H, int Np, float scale, void* stream) {
+extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
+                            float* lse, int B, int H, int Np, float scale, void* stream) {
   VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
   dim3 grid(cdiv(Np, 128), H, B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                     (const u16*)v, mask, (u16*)out, lse, H, Np, scale * LOG2E);
+                     (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E);
   VBX_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
-                            const uint8_t* mask, const void* out, const void* dout, const float* lse, float* delta,
-                            float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale, void* stream) {
+                            const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
+                            float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
+                            void* stream) {
   VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 4 == 0, "vbx_attn_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
@@ -512,8 +523,12 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
     attr = true;
   }
   const long chunks = (long)B * Np * H * 8;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout, delta,
-                     H, Np, chunks);
+  if (out_is_f16)
+    hipLaunchKernelGGL(attn_delta_kernel<true>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
+                       delta, H, Np, chunks);
+  else
+    hipLaunchKernelGGL(attn_delta_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
+                       delta, H, Np, chunks);
   VBX_LAUNCH_CHECK();
   dim3 grid(cdiv(Np, 128), H, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,

@@ -89,7 +89,16 @@ struct GemmParams {
   int tiles_m;
 };
 
-template <int MA, int MB, class Epi>
+// 16x16x32 MFMA on raw 16-bit fragments: bf16 (default) or fp16 (the q/k projection: 11-bit mantissa)
+template <bool F16>
+VBX_DEV f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int MA, int MB, class Epi, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
     }
     if (more) {
       r2s<MA>(sa, TILE_A(cur ^ 1), tid);
@@ -245,7 +254,7 @@ struct EpiSplitK {
 // FeedForward[0] + GEGLU (voicebox_pytorch.py:338-340,345).  Weight rows are packed so that every
 // 128-column tile holds 64 "x" columns followed by their 64 "gate" columns.
 struct EpiGEGLU {
-  u16* G; long ldg; const float* bias; u16* H1; long ldh;
+  u16* G; long ldg; const float* bias; u16* H1; long ldh; u16* Gb; int g_f16;
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -261,7 +270,9 @@ struct EpiGEGLU {
           const float gv = g[i] + bias[n0 + 64 + cc * 8 + i];
           o[i] = gelu_erf(gv) * xv;
         }
-        *reinterpret_cast<uint4*>(G + (long)gr * ldg + (n0 >> 1) + cc * 8) = pack8_bf16(o);
+        const long go = (long)gr * ldg + (n0 >> 1) + cc * 8;
+        *reinterpret_cast<uint4*>(G + go) = g_f16 ? pack8_f16(o) : pack8_bf16(o);
+        if (Gb) *reinterpret_cast<uint4*>(Gb + go) = pack8_bf16(o);
       }
     }
     if (H1) {
@@ -286,7 +297,7 @@ struct EpiQKV {
   int Np, H;
   float qk_scale;
   const float* qg; const float* kg; const float* rc; const float* rs;
-  u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn;
+  u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn; u16* v16;
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
     const int I = H * 64;
     const int which = n0 / I;
@@ -304,7 +315,10 @@ struct EpiQKV {
       load8(Cs, row, cc, t);
       const long o = (((long)b * H + head) * Np + n) * 64 + d0;
       if (which == 2) {
-        if (valid) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
+        if (valid) {
+          if (v) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
+          if (v16) *reinterpret_cast<uint4*>(v16 + o) = pack8_f16(t);
+        }
         continue;
       }
       float ss = 0.f;
@@ -339,10 +353,10 @@ struct EpiQKV {
   }
 };
 
-template <int MA, int MB, class Epi>
+template <int MA, int MB, bool F16 = false, class Epi>
 int launch(const GemmParams& p, const Epi& epi, int splits, hipStream_t st) {
   static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
-  auto kern = gemm_kernel<MA, MB, Epi>;
+  auto kern = gemm_kernel<MA, MB, Epi, F16>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     attr_set = true;
@@ -394,6 +408,7 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
     case VBX_EPI_F32: {
       VBX_REQUIRE(d->C && d->ldc % 8 == 0, "vbx_gemm F32: bad C/ldc");
       EpiF32 e{(float*)d->C, d->ldc, d->bias, d->resid, (u16*)d->C2};
+      if (d->mode == VBX_GEMM_NT && d->f16) return launch<0, 0, true>(p, e, 1, st);
       if (d->mode == VBX_GEMM_NT) return launch<0, 0>(p, e, 1, st);
       if (d->mode == VBX_GEMM_NN) return launch<0, 1>(p, e, 1, st);
       break;
@@ -402,16 +417,18 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
       VBX_REQUIRE(d->mode == VBX_GEMM_NT, "vbx_gemm QKV: NT only");
       VBX_REQUIRE(d->H > 0 && d->H % 2 == 0 && d->N == 3 * d->H * 64, "vbx_gemm QKV: need even H and N == 3*H*64");
       VBX_REQUIRE(d->Np > 0 && d->M % d->Np == 0, "vbx_gemm QKV: M must be B*Np");
-      VBX_REQUIRE(d->q16 && d->k16 && d->v && d->rot_cos && d->rot_sin, "vbx_gemm QKV: null output/table");
+      VBX_REQUIRE(d->q16 && d->k16 && (d->v || d->v16) && d->rot_cos && d->rot_sin, "vbx_gemm QKV: null output/table");
       VBX_REQUIRE(d->qk_scale <= 0.f || (d->q_gamma && d->k_gamma), "vbx_gemm QKV: qk-norm needs gammas");
       EpiQKV e{d->Np, d->H, d->qk_scale, d->q_gamma, d->k_gamma, d->rot_cos, d->rot_sin,
-               (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm};
+               (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm, (u16*)d->v16};
+      if (d->f16) return launch<0, 0, true>(p, e, 1, st);
       return launch<0, 0>(p, e, 1, st);
     }
     case VBX_EPI_GEGLU: {
       VBX_REQUIRE(d->mode == VBX_GEMM_NT, "vbx_gemm GEGLU: NT only");
       VBX_REQUIRE(d->N % 128 == 0 && d->bias && d->C, "vbx_gemm GEGLU: N must be a multiple of 128, bias/C required");
-      EpiGEGLU e{(u16*)d->C, d->ldc, d->bias, (u16*)d->C2, d->N};
+      EpiGEGLU e{(u16*)d->C, d->ldc, d->bias, (u16*)d->C2, d->N, (u16*)d->C3, d->f16};
+      if (d->f16) return launch<0, 0, true>(p, e, 1, st);
       return launch<0, 0>(p, e, 1, st);
     }
     case VBX_EPI_SPLITK: {

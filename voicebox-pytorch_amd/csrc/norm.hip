@@ -10,7 +10,8 @@ constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
 // y = x / max(|x|, 1e-12) * sqrt(D) * gamma[b] (+ beta[b])        (voicebox_pytorch.py:246-247, 270-276)
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, long gb_stride,
-                                                           u16* __restrict__ y, int B, int Np, int n0, int rpb, int D) {
+                                                           u16* __restrict__ y, u16* __restrict__ y16, int B, int Np, int n0,
+                                                           int rpb, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     const float r = sqrtD / fmaxf(sqrtf(ss), 1e-12f);
     const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
     const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)b * gb_stride) : nullptr;
-    uint2* yr = reinterpret_cast<uint2*>(y + ri * D);
+    uint2* yr = y ? reinterpret_cast<uint2*>(y + ri * D) : nullptr;
+    uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + ri * D) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; i++) {
       const int c = lane + 64 * i;
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
           const float4 bb = b4[c];
           o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
         }
-        yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
       }
     }
   }
@@ -266,16 +269,16 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16, int B,
-                               int Np, int n0, int rows_per_batch, int D, void* stream) {
-  VBX_REQUIRE(x && gamma && y_bf16, "vbx_rmsnorm_fwd: null pointer");
+extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
+                               void* y_f16, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
+  VBX_REQUIRE(x && gamma && (y_bf16 || y_f16), "vbx_rmsnorm_fwd: null pointer");
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_fwd: bad row range");
   const long rows = (long)B * rows_per_batch;
   int blocks = cdiv(rows, 4);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                     (u16*)y_bf16, B, Np, n0, rows_per_batch, D);
+                     (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -13,13 +13,25 @@ VBX_DEV void unpack8_bf16(const uint4 p, float v[8]) {
     v[2 * i + 1] = bf16_to_f32((u16)(w[i] >> 16));
   }
 }
+VBX_DEV void unpack8_f16(const uint4 p, float v[8]) {
+  const unsigned w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = f16_to_f32((u16)(w[i] & 0xffff));
+    v[2 * i + 1] = f16_to_f32((u16)(w[i] >> 16));
+  }
+}
+VBX_DEV uint4 pack8_h(const float v[8]) {
+  return make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+}
 VBX_DEV uint4 pack8(const float v[8]) {
   return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
 // ---------------------------------------------------------------- embed input packing
 __global__ void pack_embed_kernel(const float* __restrict__ x, const float* __restrict__ cond,
-                                  const uint8_t* __restrict__ cmask, u16* __restrict__ out, long rows, int D) {
+                                  const uint8_t* __restrict__ cmask, u16* __restrict__ out, u16* __restrict__ outb,
+                                  long rows, int D) {
   const int cpr = D / 8;  // chunks per half row
   const long total = rows * 2 * cpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -34,7 +46,9 @@ __global__ void pack_embed_kernel(const float* __restrict__ x, const float* __re
 #pragma unroll
       for (int k = 0; k < 8; k++) v[k] = 0.f;
     }
-    *reinterpret_cast<uint4*>(out + row * 2 * D + (second ? D : 0) + d) = pack8(v);
+    const long oo = row * 2 * D + (second ? D : 0) + d;
+    *reinterpret_cast<uint4*>(out + oo) = pack8_h(v);
+    if (outb) *reinterpret_cast<uint4*>(outb + oo) = pack8(v);
   }
 }
 
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict_
       for (int k = 0; k < 8; k++) acc[k] = 0.f;
       for (int c = lane; c < Th / 8; c += 64) {
         float wv[8];
-        unpack8_bf16(*reinterpret_cast<const uint4*>(w + (long)j * Th + c * 8), wv);
+        unpack8_f16(*reinterpret_cast<const uint4*>(w + (long)j * Th + c * 8), wv);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           if (k < nb) {
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_t_kernel(const u16* __restrict_
       for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
     for (int j = jb; j < je; j++) {
       float wv[8];
-      unpack8_bf16(*reinterpret_cast<const uint4*>(w + (long)j * Th + t8 * 8), wv);
+      unpack8_f16(*reinterpret_cast<const uint4*>(w + (long)j * Th + t8 * 8), wv);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         if (k < nb) {
@@ -509,7 +523,7 @@ __global__ void counter_add_kernel(int* counter, int inc) {
 
 // ---------------------------------------------------------------- weight packing
 __global__ void pack_weight_kernel(const float* __restrict__ src, int src_rows, int src_cols, u16* __restrict__ dst,
-                                   int dst_rows, int dst_cols, int rowmap, int F) {
+                                   u16* __restrict__ dst16, int dst_rows, int dst_cols, int rowmap, int F) {
   const long total = (long)dst_rows * dst_cols;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int p = (int)(i / dst_cols), c = (int)(i - (long)p * dst_cols);
@@ -517,7 +531,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int src_rows, 
     if (rowmap == 1) r = geglu_row_unmap(p, F);
     float v = 0.f;
     if (r >= 0 && r < src_rows && c < src_cols) v = src[(long)r * src_cols + c];
-    dst[i] = f32_to_bf16(v);
+    if (dst) dst[i] = f32_to_bf16(v);
+    if (dst16) dst16[i] = f32_to_f16(v);
   }
 }
 __global__ void pack_bias_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int dst_n, int rowmap, int F) {
@@ -619,12 +634,12 @@ inline int grid_for(long n, int cap = 4096) {
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_bf16, int B, int N,
-                                    int D, void* stream) {
-  VBX_REQUIRE(x && cond && out_bf16 && D % 8 == 0, "vbx_pack_embed_input: bad args");
+extern "C" int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_mask, void* out_f16, void* out_bf16,
+                                    int B, int N, int D, void* stream) {
+  VBX_REQUIRE(x && cond && out_f16 && D % 8 == 0, "vbx_pack_embed_input: bad args");
   const long rows = (long)B * N;
-  hipLaunchKernelGGL(pack_embed_kernel, dim3(grid_for(rows * D / 4)), dim3(256), 0, ST, x, cond, cond_mask, (u16*)out_bf16,
-                     rows, D);
+  hipLaunchKernelGGL(pack_embed_kernel, dim3(grid_for(rows * D / 4)), dim3(256), 0, ST, x, cond, cond_mask, (u16*)out_f16,
+                     (u16*)out_bf16, rows, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -829,11 +844,11 @@ extern "C" int vbx_counter_add(int* counter, int inc, void* stream) {
   return 0;
 }
 
-extern "C" int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, int dst_rows, int dst_cols,
-                               int rowmap, int F, void* stream) {
-  VBX_REQUIRE(src && dst_bf16, "vbx_pack_weight: null pointer");
+extern "C" int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16, void* dst_f16, int dst_rows,
+                               int dst_cols, int rowmap, int F, void* stream) {
+  VBX_REQUIRE(src && (dst_bf16 || dst_f16), "vbx_pack_weight: null pointer");
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)dst_rows * dst_cols)), dim3(256), 0, ST, src, src_rows, src_cols,
-                     (u16*)dst_bf16, dst_rows, dst_cols, rowmap, F);
+                     (u16*)dst_bf16, (u16*)dst_f16, dst_rows, dst_cols, rowmap, F);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -3,11 +3,16 @@
 //
 // HBM layout (all token-major, row r = b*Np + n, Np = N + R registers in place at rows n < R):
 //   residual stream   fp32 [M, D]    one snapshot per sub-layer in training (xs[0..2L]), 2 ping-pong buffers in eval
-//   normed inputs     bf16 [M, D]    hn1 / hn2 (GEMM A operands, kept for wgrad)
-//   q-hat, k-hat      fp16 [B,H,Np,64] (+ bf16 copies for the backward GEMMs), v bf16 [B,H,Np,64]
-//   attention out     bf16 [M, H*64], log2-LSE fp32 [B,H,Np]
-//   FF pre-activation bf16 [M, 2*Fp] (interleaved x|gate per 128 columns), GEGLU out bf16 [M, Fp], Fp = ceil64(F)
+//   normed inputs     fp16 [M, D]    hn1 / hn2 (forward GEMM A operands)
+//   q-hat, k-hat, v   fp16 [B,H,Np,64]
+//   attention out     fp16 [M, H*64], log2-LSE fp32 [B,H,Np]
+//   FF pre-activation bf16 [M, 2*Fp] (interleaved x|gate per 128 columns, training only), GEGLU out fp16 [M, Fp], Fp = ceil64(F)
+// Precision contract: every FORWARD GEMM/attention operand is fp16 (fp32 accumulate): the qk-normed logits
+// 10*q.k have std ~80, so a 2^-9 (bf16) relative error anywhere upstream of q/k moves them by ~0.2 and the
+// prediction by ~5%; fp16 (2^-11) costs the same MFMA rate and brings that to ~1%.  Every BACKWARD GEMM operand
+// is bf16 (gradients need the exponent range), so in training each saved activation also has a bf16 copy.
 #include "common.hpp"
+#include <string>
 #include <vector>
 
 namespace {
@@ -39,12 +44,13 @@ Dims dims_of(const vbx_model* m) {
   return d;
 }
 
+// *h = fp16 copy (forward NT GEMMs), plain = bf16 copy (backward dgrad NN GEMMs)
 struct WLayer {
-  u16 *qkv, *out, *w1, *w2;
+  u16 *qkv, *qkvh, *out, *outh, *w1, *w1h, *w2, *w2h;
   float* b1;
 };
 struct WPack {
-  u16 *emb, *pred, *ada;
+  u16 *embh, *pred, *predh, *adah;
   float* bada;
   std::vector<WLayer> layer;
   size_t bytes;
@@ -52,31 +58,36 @@ struct WPack {
 void carve_wpack(const vbx_model* m, WPack& w) {
   const Dims d = dims_of(m);
   Carver c(m->wpack);
-  w.emb = c.take<u16>((size_t)d.D * 2 * d.D);
+  w.embh = c.take<u16>((size_t)d.D * 2 * d.D);
   w.pred = c.take<u16>((size_t)d.D * d.D);
-  w.ada = c.take<u16>((size_t)d.J * d.Th);
+  w.predh = c.take<u16>((size_t)d.D * d.D);
+  w.adah = c.take<u16>((size_t)d.J * d.Th);
   w.bada = c.take<float>(d.J);
   w.layer.resize(d.L);
   for (int l = 0; l < d.L; l++) {
     w.layer[l].qkv = c.take<u16>((size_t)3 * d.I * d.D);
+    w.layer[l].qkvh = c.take<u16>((size_t)3 * d.I * d.D);
     w.layer[l].out = c.take<u16>((size_t)d.D * d.I);
+    w.layer[l].outh = c.take<u16>((size_t)d.D * d.I);
     w.layer[l].w1 = c.take<u16>((size_t)2 * d.Fp * d.D);
+    w.layer[l].w1h = c.take<u16>((size_t)2 * d.Fp * d.D);
     w.layer[l].b1 = c.take<float>(2 * d.Fp);
     w.layer[l].w2 = c.take<u16>((size_t)d.D * d.Fp);
+    w.layer[l].w2h = c.take<u16>((size_t)d.D * d.Fp);
   }
   w.bytes = al256(c.off);
 }
 
 struct ALayer {
-  u16 *hn1, *q16, *k16, *qb, *kb, *v, *o, *hn2, *h1, *g;
+  u16 *hn1, *hn1h, *q16, *k16, *qb, *kb, *v, *vh, *o, *oh, *hn2, *hn2h, *h1, *g, *gh;
   float *qrn, *krn, *lse;
 };
 struct Acts {
-  u16* embed_in;
+  u16 *embed_in, *embed_inh;
   float *e, *four, *pre, *temb, *ada;
   std::vector<float*> xs;  // residual snapshots
   std::vector<ALayer> layer;
-  u16* hf;
+  u16 *hf, *hfh;
   float *pred, *per_b;
   // backward scratch
   float *dx, *dq, *dk, *delta, *slabs, *npart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
@@ -100,7 +111,8 @@ void carve_acts(const vbx_model* m, Acts& a) {
   const Dims d = dims_of(m);
   Carver c(m->act);
   const bool tr = m->training != 0;
-  a.embed_in = c.take<u16>((size_t)d.M0 * 2 * d.D);
+  a.embed_in = tr ? c.take<u16>((size_t)d.M0 * 2 * d.D) : nullptr;
+  a.embed_inh = c.take<u16>((size_t)d.M0 * 2 * d.D);
   a.e = c.take<float>((size_t)d.M0 * d.D);
   a.four = c.take<float>((size_t)d.B * d.D);
   a.pre = c.take<float>((size_t)d.B * d.Th);
@@ -117,25 +129,31 @@ void carve_acts(const vbx_model* m, Acts& a) {
   for (int l = 0; l < d.L; l++) {
     if (tr || l == 0) {
       ALayer& y = a.layer[l];
-      y.hn1 = c.take<u16>((size_t)d.M * d.D);
+      y.hn1 = tr ? c.take<u16>((size_t)d.M * d.D) : nullptr;  // bf16 copy: wgrad operand
+      y.hn1h = c.take<u16>((size_t)d.M * d.D);                  // fp16: A operand of the q/k/v projection
       y.q16 = c.take<u16>(hs);
       y.k16 = c.take<u16>(hs);
       y.qb = tr ? c.take<u16>(hs) : nullptr;
       y.kb = tr ? c.take<u16>(hs) : nullptr;
-      y.v = c.take<u16>(hs);
+      y.v = tr ? c.take<u16>(hs) : nullptr;
+      y.vh = c.take<u16>(hs);
       y.qrn = tr ? c.take<float>((size_t)d.B * d.H * d.Np) : nullptr;
       y.krn = tr ? c.take<float>((size_t)d.B * d.H * d.Np) : nullptr;
-      y.o = c.take<u16>((size_t)d.M * d.I);
+      y.o = tr ? c.take<u16>((size_t)d.M * d.I) : nullptr;
+      y.oh = c.take<u16>((size_t)d.M * d.I);
       y.lse = c.take<float>((size_t)d.B * d.H * d.Np);
-      y.hn2 = c.take<u16>((size_t)d.M * d.D);
+      y.hn2 = tr ? c.take<u16>((size_t)d.M * d.D) : nullptr;
+      y.hn2h = c.take<u16>((size_t)d.M * d.D);
       y.h1 = tr ? c.take<u16>((size_t)d.M * 2 * d.Fp) : nullptr;
-      y.g = c.take<u16>((size_t)d.M * d.Fp);
+      y.g = tr ? c.take<u16>((size_t)d.M * d.Fp) : nullptr;
+      y.gh = c.take<u16>((size_t)d.M * d.Fp);
       shared = y;
     } else {
       a.layer[l] = shared;
     }
   }
-  a.hf = c.take<u16>((size_t)d.M0 * d.D);
+  a.hf = tr ? c.take<u16>((size_t)d.M0 * d.D) : nullptr;
+  a.hfh = c.take<u16>((size_t)d.M0 * d.D);
   a.pred = c.take<float>((size_t)d.M0 * d.D);
   a.per_b = c.take<float>(2 * d.B + 1);
   if (tr) {
@@ -199,11 +217,12 @@ int check_model(const vbx_model* m) {
   return 0;
 }
 
+// forward GEMMs: fp16 operands
 int gemm_nt(const u16* A, int lda, const u16* Bw, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
-            const float* resid, void* C2, hipStream_t st) {
+            const float* resid, void* C2, void* C3, hipStream_t st) {
   vbx_gemm_desc g{};
   g.mode = VBX_GEMM_NT; g.epilogue = epi; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.A = A; g.B = Bw; g.C = C; g.bias = bias; g.resid = resid; g.C2 = C2;
+  g.A = A; g.B = Bw; g.C = C; g.bias = bias; g.resid = resid; g.C2 = C2; g.C3 = C3; g.f16 = 1;
   return vbx_gemm(&g, st);
 }
 int gemm_nn_bf16(const u16* A, int lda, const u16* Bw, int ldb, int M, int N, int K, u16* C, int ldc, hipStream_t st) {
@@ -247,17 +266,17 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
   carve_wpack(m, w);
   const float* P = m->params;
   const long* G = m->off;
-  CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, w.emb, d.D, 2 * d.D, 0, 0, stream));
-  CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, d.D, d.D, 0, 0, stream));
+  CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, d.D, 2 * d.D, 0, 0, stream));
+  CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, d.D, d.D, 0, 0, stream));
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
-    CK(vbx_pack_weight(P + o[VBX_L_G1W], 4 * d.D, d.Th, w.ada + (size_t)l * 4 * d.D * d.Th, 4 * d.D, d.Th, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, 4 * d.D, d.Th, 0, 0, stream));
     CK(vbx_pack_bias(P + o[VBX_L_G1B], 4 * d.D, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0, stream));
-    CK(vbx_pack_weight(P + o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, 3 * d.I, d.D, 0, 0, stream));
-    CK(vbx_pack_weight(P + o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, d.D, d.I, 0, 0, stream));
-    CK(vbx_pack_weight(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, 2 * d.Fp, d.D, 1, d.F, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, w.layer[l].qkvh, 3 * d.I, d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, w.layer[l].outh, d.D, d.I, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, w.layer[l].w1h, 2 * d.Fp, d.D, 1, d.F, stream));
     CK(vbx_pack_bias(P + o[VBX_L_FF1B], 2 * d.F, w.layer[l].b1, 2 * d.Fp, 1, d.F, stream));
-    CK(vbx_pack_weight(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, d.D, d.Fp, 0, 0, stream));
+    CK(vbx_pack_weight(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, w.layer[l].w2h, d.D, d.Fp, 0, 0, stream));
   }
   return 0;
 }
@@ -278,16 +297,16 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   const bool tr = m->training != 0;
 
   // to_embed(cat(x, cond * ~cond_mask))   (voicebox_pytorch.py:1035,1075-1078)
-  CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_in, d.B, d.N, d.D, stream));
-  CK(gemm_nt(a.embed_in, 2 * d.D, w.emb, 2 * d.D, (int)d.M0, d.D, 2 * d.D, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
-             nullptr, st));
+  CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
+  CK(gemm_nt(a.embed_inh, 2 * d.D, w.embh, 2 * d.D, (int)d.M0, d.D, 2 * d.D, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
+             nullptr, nullptr, st));
   // conv_embed(x) + x, register tokens in place   (:1080, :422-425)
   CK(vbx_convpos_fwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a.xs[0],
                      d.B, d.N, d.R, d.D, d.ks, stream));
   // time embedding + every adaLN projection of the stack   (:1082, :273)
   CK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a.four, a.pre, a.temb, d.B, d.D,
                         d.Th, stream));
-  CK(vbx_adaln_proj_fwd(a.temb, w.ada, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
+  CK(vbx_adaln_proj_fwd(a.temb, w.adah, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
 
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
@@ -297,28 +316,28 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     float* x_mid = a.xs[2 * l + 1];
     float* x_out = a.xs[2 * l + 2];
     // attn_prenorm -> to_qkv (+qk-norm, rotary) -> Attend -> to_out + residual   (:468-469, :317-333)
-    CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, y.hn1h, d.B, d.Np, 0, d.Np, d.D, stream));
     vbx_gemm_desc g{};
     g.mode = VBX_GEMM_NT; g.epilogue = VBX_EPI_QKV; g.M = (int)d.M; g.N = 3 * d.I; g.K = d.D; g.lda = d.D; g.ldb = d.D;
-    g.A = y.hn1; g.B = w.layer[l].qkv; g.Np = d.Np; g.H = d.H; g.qk_scale = m->qk_norm ? 8.0f : 0.0f;
+    g.A = y.hn1h; g.B = w.layer[l].qkvh; g.f16 = 1; g.Np = d.Np; g.H = d.H; g.qk_scale = m->qk_norm ? 8.0f : 0.0f;
     g.q_gamma = m->qk_norm ? P + o[VBX_L_QG] : nullptr;
     g.k_gamma = m->qk_norm ? P + o[VBX_L_KG] : nullptr;
     g.rot_cos = m->rot_cos; g.rot_sin = m->rot_sin;
-    g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
+    g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.v16 = y.vh; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
     CK(vbx_gemm(&g, stream));
-    CK(vbx_attn_fwd(y.q16, y.k16, y.v, io->attn_mask_p, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
-    CK(gemm_nt(y.o, d.I, w.layer[l].out, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, st));
+    CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
+    CK(gemm_nt(y.oh, d.I, w.layer[l].outh, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, nullptr, st));
     // ff_prenorm -> FeedForward (GEGLU) + residual   (:471-472, :337-349)
-    CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, d.B, d.Np, 0, d.Np, d.D, stream));
-    CK(gemm_nt(y.hn2, d.D, w.layer[l].w1, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.g, d.Fp, w.layer[l].b1, nullptr,
-               tr ? y.h1 : nullptr, st));
-    CK(gemm_nt(y.g, d.Fp, w.layer[l].w2, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
-               st));
+    CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(gemm_nt(y.hn2h, d.D, w.layer[l].w1h, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.gh, d.Fp, w.layer[l].b1, nullptr,
+               tr ? y.h1 : nullptr, y.g, st));
+    CK(gemm_nt(y.gh, d.Fp, w.layer[l].w2h, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
+               nullptr, st));
   }
   // strip registers, final RMSNorm, to_pred   (:476-479, :1092)
-  CK(vbx_rmsnorm_fwd(a.xs[2 * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, d.B, d.Np, d.R, d.N, d.D, stream));
+  CK(vbx_rmsnorm_fwd(a.xs[2 * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, a.hfh, d.B, d.Np, d.R, d.N, d.D, stream));
   float* pred = io->pred ? io->pred : a.pred;
-  CK(gemm_nt(a.hf, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, VBX_EPI_F32, pred, d.D, nullptr, nullptr, nullptr, st));
+  CK(gemm_nt(a.hfh, d.D, w.predh, d.D, (int)d.M0, d.D, d.D, VBX_EPI_F32, pred, d.D, nullptr, nullptr, nullptr, nullptr, st));
   if (io->target) CK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a.per_b, io->loss, d.B, d.N, d.D, stream));
   return 0;
 }
@@ -382,7 +401,7 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
   CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
-  CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.o, a.dO, y.lse, a.delta, a.dq, a.dk,
+  CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
                   a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, stream));
   CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                          m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
@@ -397,7 +416,7 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   CK(vbx_rmsnorm_bwd(a.xs[2 * l], ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, d.B, d.Np, 0, d.Np, d.D, stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
-  CK(vbx_adaln_proj_bwd(a.temb, w.ada + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
+  CK(vbx_adaln_proj_bwd(a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
                         a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));
   return 0;
 }
@@ -422,4 +441,25 @@ extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, vo
   CK(vbx_time_embed_bwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], a.four, a.pre, a.dtemb, Gd + G[VBX_P_SINW],
                         Gd + G[VBX_P_T1W], Gd + G[VBX_P_T1B], a.tscratch, d.B, d.D, d.Th, stream));
   return 0;
+}
+
+// Debug/introspection (tests only): device pointer of a named arena tensor.
+extern "C" void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer) {
+  Acts a;
+  carve_acts(m, a);
+  const std::string n(name);
+  const Dims d = dims_of(m);
+  if (layer >= 0 && layer < d.L) {
+    const ALayer& y = a.layer[layer];
+    if (n == "hn1") return y.hn1; if (n == "hn1h") return y.hn1h; if (n == "q16") return y.q16; if (n == "k16") return y.k16;
+    if (n == "qb") return y.qb; if (n == "kb") return y.kb; if (n == "v") return y.v; if (n == "vh") return y.vh;
+    if (n == "o") return y.o; if (n == "oh") return y.oh; if (n == "lse") return y.lse; if (n == "qrn") return y.qrn;
+    if (n == "krn") return y.krn; if (n == "hn2") return y.hn2; if (n == "h1") return y.h1; if (n == "g") return y.g;
+  }
+  if (n == "xs" && layer >= 0 && layer <= 2 * d.L) return a.xs[layer];
+  if (n == "dx") return a.dx; if (n == "dxb") return a.dxb; if (n == "dq") return a.dq; if (n == "dk") return a.dk;
+  if (n == "dqkv") return a.dqkv; if (n == "dO") return a.dO; if (n == "delta") return a.delta; if (n == "dhn") return a.dhn;
+  if (n == "e") return a.e; if (n == "temb") return a.temb; if (n == "ada") return a.ada; if (n == "pred") return a.pred;
+  if (n == "dada") return a.dada; if (n == "dtemb") return a.dtemb;
+  return nullptr;
 }

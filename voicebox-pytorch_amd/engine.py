@@ -204,6 +204,18 @@ class Engine:
         """Re-issue the last forward with the same (static) buffers -- the body of the captured ODE step."""
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(self.io), _lib.current_stream()), "vbx_model_forward")
 
+    def debug_tensor(self, name, layer, shape, dtype):
+        """tests/debug: view of a named arena tensor."""
+        l = _rt()
+        l.vbx_model_debug_ptr.argtypes = [C.POINTER(VbxModel), C.c_char_p, I]
+        l.vbx_model_debug_ptr.restype = C.c_void_p
+        p = l.vbx_model_debug_ptr(C.byref(self.m), name.encode(), layer)
+        if not p:
+            raise KeyError(name)
+        off = p - self.act.data_ptr()
+        n = int(torch.tensor(shape).prod()) * torch.empty(0, dtype=dtype).element_size()
+        return self.act[off:off + n].view(dtype).view(*shape)
+
     # -- backward, stage by stage; `on_stage(i, (lo, hi))` fires after the gradients in flat range [lo,hi) are final
     def backward(self, gflat, gscale=None, on_stage=None):
         assert self.training

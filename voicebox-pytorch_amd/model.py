@@ -31,14 +31,15 @@ class _AttendFn(torch.autograd.Function):
         B, H, Np, dh = q.shape
         dev = q.device
         q16, k16 = q.to(torch.float16).contiguous(), k.to(torch.float16).contiguous()
+        v16 = v.to(torch.float16).contiguous()
         vb = v.to(torch.bfloat16).contiguous()
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
-        out = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
+        out16 = torch.empty(B, Np, H * 64, dtype=torch.float16, device=dev)
         lse = torch.empty(B, H, Np, dtype=torch.float32, device=dev)
-        _lib.call("vbx_attn_fwd", q16, k16, vb, m8, out, lse, B, H, Np, float(scale), _lib.current_stream())
-        ctx.save_for_backward(q16, k16, vb, out, lse, m8 if m8 is not None else torch.empty(0, device=dev))
+        _lib.call("vbx_attn_fwd", q16, k16, v16, m8, out16, None, lse, B, H, Np, float(scale), _lib.current_stream())
+        ctx.save_for_backward(q16, k16, vb, out16, lse, m8 if m8 is not None else torch.empty(0, device=dev))
         ctx.has_mask, ctx.scale, ctx.in_dtype = m8 is not None, float(scale), q.dtype
-        return out.view(B, Np, H, 64).permute(0, 2, 1, 3).to(q.dtype)
+        return out16.view(B, Np, H, 64).permute(0, 2, 1, 3).to(q.dtype)
 
     @staticmethod
     def backward(ctx, dout):
@@ -51,7 +52,7 @@ class _AttendFn(torch.autograd.Function):
         dq = torch.empty(B, H, Np, 64, dtype=torch.float32, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
-        _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, do, lse, delta, dq, dk, dv,
+        _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
                   H * 64, B, H, Np, ctx.scale, _lib.current_stream())
         dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
         return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None
