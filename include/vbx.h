@@ -201,8 +201,10 @@ int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
                   int step, const float* gscale, void* stream);
 /* sum of squares of a flat buffer -> out[0] (two-stage, deterministic) ; scratch >= 1024 floats */
 int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
-/* clip coefficient: coef = min(1, max_norm / (sqrt(sumsq)+1e-6)) */
-int vbx_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+/* gradient-clip coefficient for a buffer holding the SUM over `world` ranks (inv_world = 1/world):
+ * norm = sqrt(sumsq)*inv_world; coef[0] = min(1, max_norm/(norm+1e-6)) * inv_world (max_norm <= 0: no clipping);
+ * coef[1] = norm.  (accelerator.clip_grad_norm_, trainer.py:274-275) */
+int vbx_clip_coef(const float* sumsq, float max_norm, float inv_world, float* coef /* [2] */, void* stream);
 
 /* ------------------------------------------------------------------ stage-level runtime
  * The whole VoiceBox forward / backward as native sequences of launches (no host sync, no allocation:

@@ -537,7 +537,7 @@ def test_adam_sumsq_clip(L):
     ref_p = torch.nn.Parameter(p.clone())
     opt = torch.optim.Adam([ref_p], lr=3e-4, betas=(0.9, 0.99), eps=1e-8)
     pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    ss, coef, scratch = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1024, device=dev)
+    ss, coef, scratch = torch.zeros(1, device=dev), torch.zeros(2, device=dev), torch.zeros(1024, device=dev)
     for step, gr in enumerate(grads, 1):
         ref_p.grad = gr.clone()
         torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
@@ -545,6 +545,6 @@ def test_adam_sumsq_clip(L):
         gd = gr.to(dev)
         L.call("vbx_sumsq", gd, n, ss, scratch, st())
         assert abs(float(ss) - float(gr.double().pow(2).sum())) < 1e-4 * float(ss)
-        L.call("vbx_clip_coef", ss, 0.5, coef, st())
+        L.call("vbx_clip_coef", ss, 0.5, 1.0, coef, st())
         L.call("vbx_adam_step", pd, gd, m, v, n, 3e-4, 0.9, 0.99, 1e-8, step, coef, st())
     assert max_err(pd, ref_p.detach()) < 2e-6

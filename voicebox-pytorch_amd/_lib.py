@@ -64,7 +64,7 @@ _PROTOS = {
     "vbx_pack_bias": [P, I, P, I, I, I, P],
     "vbx_adam_step": [P, P, P, P, L, F, F, F, F, I, P, P],
     "vbx_sumsq": [P, L, P, P, P],
-    "vbx_clip_coef": [P, F, P, P],
+    "vbx_clip_coef": [P, F, F, P, P],
     "vbx_probe_tr16": [P, P, P, P],
     "vbx_probe_mfma": [I, P, P, P, P],
 }

@@ -577,10 +577,13 @@ __global__ void sumsq_stage2(const float* __restrict__ scratch, int nb, float* _
   __syncthreads();
   if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
-  // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max = 1)
-  const float nrm = sqrtf(sumsq[0]);
-  coef[0] = fminf(1.0f, max_norm / (nrm + 1e-6f));
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float inv_world, float* __restrict__ coef) {
+  // gradients in the buffer are SUMS over `world` ranks: g = buf * inv_world.
+  // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max = 1); coef[0] also folds 1/world.
+  const float nrm = sqrtf(sumsq[0]) * inv_world;
+  const float c = (max_norm > 0.f) ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
+  coef[0] = c * inv_world;
+  coef[1] = nrm;
 }
 
 // ---------------------------------------------------------------- probes (tests only)
@@ -879,9 +882,9 @@ extern "C" int vbx_sumsq(const float* x, long n, float* out, float* scratch, voi
   VBX_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int vbx_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream) {
+extern "C" int vbx_clip_coef(const float* sumsq, float max_norm, float inv_world, float* coef, void* stream) {
   VBX_REQUIRE(sumsq && coef, "vbx_clip_coef: null pointer");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, sumsq, max_norm, coef);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, sumsq, max_norm, inv_world, coef);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,129 @@
+"""Data-parallel CFM training step: one process per GPU, replicated weights, batch sharded across ranks,
+flat fp32 gradient buffer all-reduced over RCCL/xGMI in stage-sized buckets while the backward of earlier
+layers is still running, then global-norm clip + fused Adam on the flat buffers.
+
+Semantics to match (VoiceBoxTrainer.train_step, trainer.py:237-313): each rank's loss is
+the mean over its local batch; gradients are averaged over ranks (DDP), clipped to max_grad_norm = 0.5
+(trainer.py:274-275), then Adam(lr, betas=(0.9, 0.99)) (optimizer.py:10-35, wd = 0 default trainer.py:74).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .masks import mask_from_frac_lengths, take_draw
+
+
+class GradBucketReducer:
+    """All-reduce(sum) of a flat gradient buffer in contiguous buckets as backward stages complete.
+    Device-agnostic (gloo on CPU in tests, RCCL on GPUs).  xGMI is point-to-point (ring all-reduce is per-link
+    bound) so buckets are large: whole backward stages are merged until `bucket_bytes` is reached."""
+
+    def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None):
+        self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm_stream = comm_stream
+        self.pending_lo = None
+        self.pending_hi = None
+        self.works = []
+        self.buckets_launched = []
+
+    def _launch(self, lo, hi):
+        if hi <= lo:
+            return
+        self.buckets_launched.append((lo, hi))
+        if self.world == 1:
+            return
+        view = self.g[lo:hi]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def stage_done(self, i, rng=None):
+        lo, hi = rng if rng is not None else self.ranges[i]
+        if self.pending_lo is None:
+            self.pending_lo, self.pending_hi = lo, hi
+        else:
+            assert lo == self.pending_hi, "stages must complete in flat-buffer order"
+            self.pending_hi = hi
+        if (self.pending_hi - self.pending_lo) * self.g.element_size() >= self.bucket_bytes:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = None
+
+    def finish(self):
+        if self.pending_lo is not None:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = None
+        for w in self.works:
+            w.wait()  # makes the current stream wait for the collective
+        self.works = []
+
+
+class TrainStep:
+    def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
+                 bucket_bytes=64 << 20, broadcast_params=True):
+        self.wrapper, self.vb = wrapper, wrapper.voicebox
+        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.fp = self.vb.flat_params()
+        flat = self.fp.flat
+        dev = flat.device
+        if self.distributed and self.world > 1 and broadcast_params:
+            dist.broadcast(flat, src=0, group=group)  # DDP's initial parameter broadcast (trainer.py:159)
+            self._dirty()
+        self.gflat = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.sumsq = torch.zeros(1, device=dev)
+        self.coef = torch.zeros(2, device=dev)
+        self.scratch = torch.zeros(1024, device=dev)
+        self.steps = 0
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        self.bucket_bytes = bucket_bytes
+
+    def _dirty(self):
+        for eng in self.vb._engines.values():
+            eng.packed_version = None
+
+    def step(self, x1, mask=None, lr=None):
+        """x1: (B_local, frames, dim) on this rank's GPU.  Returns the (un-synchronised) local loss tensor."""
+        vb, w = self.vb, self.wrapper
+        dev = self.fp.flat.device
+        st = _lib.current_stream
+        x1 = x1.to(dev, torch.float32).contiguous()
+        B, N, _ = x1.shape
+        # --- ConditionalFlowMatcherWrapper.forward, same RNG draw order (voicebox_pytorch.py:1399,1403,1025,146)
+        x0 = take_draw("x0")
+        x0 = torch.randn_like(x1) if x0 is None else x0.to(dev, torch.float32)
+        times = take_draw("times")
+        times = torch.rand((B,), dtype=torch.float32, device=dev) if times is None else times.to(dev, torch.float32)
+        wt, flow = torch.empty_like(x1), torch.empty_like(x1)
+        _lib.call("vbx_cfm_inputs", x1, x0.contiguous(), times.contiguous(), float(w.sigma), wt, flow, B, x1[0].numel(), st())
+        vb.train()
+        frac = take_draw("frac_lengths")
+        if frac is None:
+            frac = torch.zeros((B,), device=dev).float().uniform_(*vb.frac_lengths_mask)
+        cond_mask = mask_from_frac_lengths(N, frac.to(dev))
+        loss_mask = cond_mask if mask is None else (cond_mask & mask.to(dev))
+        eng = vb.engine(B, N, training=True)
+        loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask)
+        # --- backward with overlapped gradient exchange
+        red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
+                                comm_stream=self.comm_stream)
+        eng.backward(self.gflat, gscale=None, on_stage=red.stage_done if self.world > 1 else None)
+        red.finish()
+        # --- clip (global norm of the rank-averaged gradient) + Adam, all on device, no host sync
+        n = self.gflat.numel()
+        self.steps += 1
+        _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
+        _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
+        _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
+                  float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
+        self._dirty()
+        return loss
