@@ -146,8 +146,9 @@ int vbx_conv_wgrad_finalize(const float* wpart, int chunks, int D, int ksize, fl
 /* time embedding: LearnedSinusoidalPosEmb -> Linear -> SiLU (voicebox_pytorch.py:163-167,916-920) */
 int vbx_time_embed_fwd(const float* times, const float* w_sin, const float* w1, const float* b1, float* four,
                        float* pre, float* temb, int B, int D, int Th, void* stream);
+int vbx_time_embed_bwd_scratch_floats(int B, int D);
 int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, const float* four, const float* pre,
-                       const float* dtemb, float* dw_sin, float* dw1, float* db1, float* scratch /* B*D floats */, int B,
+                       const float* dtemb, float* dw_sin, float* dw1, float* db1, float* scratch /* vbx_time_embed_bwd_scratch_floats */, int B,
                        int D, int Th, void* stream);
 /* all adaLN projections at once: ada[b][j] = bias[j] + sum_t temb[b][t] * W[j][t],  W fp16 [J,Th]
  * (J = depth*2 norms*(gamma,beta)*D) (voicebox_pytorch.py:273). */
@@ -172,7 +173,9 @@ int vbx_colsum_scratch_floats(int M, int C);
 int vbx_sum_rows_f32(const float* in, long rows, long ld, float* out, long cols, int accumulate, void* stream);
 /* rows of the gpart buffer of vbx_qknorm_rope_bwd per `which`: gpart is [2][rows][H][64] */
 int vbx_qknorm_rope_bwd_gpart_rows(int B);
-/* masked MSE (voicebox_pytorch.py:1099-1115): loss scalar fp32; per_b: 2*B floats (per-sample loss, denominators). */
+/* masked MSE (voicebox_pytorch.py:1099-1115): loss scalar fp32; per_b: vbx_masked_mse_scratch_floats(B) floats
+ * ([0,B) per-sample loss, [B,2B) denominators, then partial sums). */
+int vbx_masked_mse_scratch_floats(int B);
 int vbx_masked_mse_fwd(const float* pred, const float* target, const uint8_t* loss_mask, float* per_b, float* loss,
                        int B, int N, int D, void* stream);
 int vbx_masked_mse_bwd(const float* pred, const float* target, const uint8_t* loss_mask, const float* per_b,

@@ -459,7 +459,7 @@ def test_time_embed_and_adaln(L):
     dws = torch.empty(D // 2, device=dev)
     dw1 = torch.empty(Th, D, device=dev)
     db1 = torch.empty(Th, device=dev)
-    sc = torch.empty(Bsz * D, device=dev)
+    sc = torch.empty(L.lib().vbx_time_embed_bwd_scratch_floats(Bsz, D), device=dev)
     L.call("vbx_time_embed_bwd", times.to(dev), pd["sinu_pos_emb.0.weights"], pd["sinu_pos_emb.1.weight"], four, pre,
            dtemb, dws, dw1, db1, sc, Bsz, D, Th, st())
     assert rel_err(dw1, pr["sinu_pos_emb.1.weight"].grad) < 1e-4
@@ -489,6 +489,11 @@ def test_geglu_bwd_and_colsum(L):
     exp = torch.cat((cs[:, 0].reshape(-1)[:Fd], cs[:, 1].reshape(-1)[:Fd]))
     assert rel_err(out, exp) < 1e-5
     x32 = torch.randn(M, 96, generator=g)
+    big = bf(torch.randn(8320, 2816, generator=g))  # the FeedForward bias-grad shape of the benchmark config
+    ob = torch.zeros(2816, device=dev)
+    scb = torch.empty(L.lib().vbx_colsum_scratch_floats(8320, 2816), device=dev)
+    L.call("vbx_colsum_bf16", big.to(dev), 8320, 2816, 2816, ob, 2816, 0, 0, scb, st())
+    assert rel_err(ob, big.double().sum(0)) < 1e-5
     o2 = torch.zeros(96, device=dev)
     sc2 = torch.empty(L.lib().vbx_colsum_scratch_floats(M, 96), device=dev)
     L.call("vbx_colsum_f32", x32.to(dev), M, 96, 96, o2, sc2, st())
@@ -505,7 +510,7 @@ def test_masked_mse_cfm_axpy(L):
     per = ((pred - target) ** 2).mean(-1).masked_fill(~lm, 0.0)
     ref = (per.sum(-1) / lm.sum(-1).clamp(min=1e-5)).mean()
     ref.backward()
-    per_b = torch.zeros(2 * Bsz, device=dev)
+    per_b = torch.zeros(L.lib().vbx_masked_mse_scratch_floats(Bsz), device=dev)
     loss = torch.zeros(1, device=dev)
     pd, td, ld = pred.detach().float().to(dev), target.float().to(dev), lm.to(dev)
     L.call("vbx_masked_mse_fwd", pd, td, ld, per_b, loss, Bsz, N, D, st())

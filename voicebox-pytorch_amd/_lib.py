@@ -43,6 +43,8 @@ _PROTOS = {
     "vbx_convpos_bwd_chunks": [I, I],
     "vbx_conv_wgrad_finalize": [P, I, I, I, P, P, P],
     "vbx_time_embed_fwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "vbx_time_embed_bwd_scratch_floats": [I, I],
+    "vbx_masked_mse_scratch_floats": [I],
     "vbx_time_embed_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "vbx_adaln_proj_fwd": [P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],

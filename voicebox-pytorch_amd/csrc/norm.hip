@@ -152,20 +152,28 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 }
 
 // out[b][which][d] = sum_chunk part[b][chunk][which][d]   (optionally also summed over b)
-__global__ void reduce_norm_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long out_b_stride,
-                                            int B, int chunks, int D, int sum_batch) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*D
-  if (idx >= 2 * D) return;
-  if (sum_batch) {
-    float s = 0.f;
-    for (int b = 0; b < B; b++)
-      for (int c = 0; c < chunks; c++) s += part[((long)b * chunks + c) * 2 * D + idx];
-    out[idx] = s;
-  } else {
-    const int b = blockIdx.y;
-    float s = 0.f;
-    for (int c = 0; c < chunks; c++) s += part[((long)b * chunks + c) * 2 * D + idx];
-    out[(long)b * out_b_stride + idx] = s;
+// block = 64 idx x 4 chunk lanes; grid (2D/64, sum_batch ? 1 : B)
+__global__ __launch_bounds__(256) void reduce_norm_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                    long out_b_stride, int B, int chunks, int D, int sum_batch) {
+  __shared__ float red[4][64];
+  const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + il;
+  float s = 0.f;
+  if (idx < 2 * D) {
+    if (sum_batch) {
+      const long total = (long)B * chunks;
+      for (long c = cl; c < total; c += 4) s += part[c * 2 * D + idx];
+    } else {
+      const int b = blockIdx.y;
+      for (int c = cl; c < chunks; c += 4) s += part[((long)b * chunks + c) * 2 * D + idx];
+    }
+  }
+  red[cl][il] = s;
+  __syncthreads();
+  if (cl == 0 && idx < 2 * D) {
+    const float t = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+    if (sum_batch) out[idx] = t;
+    else out[(long)blockIdx.y * out_b_stride + idx] = t;
   }
 }
 
@@ -299,7 +307,7 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
 extern "C" int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D,
                                         int sum_batch, void* stream) {
   VBX_REQUIRE(part && out && B > 0 && chunks > 0 && D > 0, "vbx_reduce_norm_partials: bad args");
-  dim3 grid(cdiv(2 * D, 256), sum_batch ? 1 : B);
+  dim3 grid(cdiv(2 * D, 64), sum_batch ? 1 : B);
   hipLaunchKernelGGL(reduce_norm_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, out_b_stride, B,
                      chunks, D, sum_batch);
   VBX_LAUNCH_CHECK();

@@ -243,14 +243,17 @@ __global__ void time_bwd_w1_kernel(const float* __restrict__ four, const float* 
   dw1[idx] = s;
   if (j == 0) db1[i] = sb;
 }
+// partial[slice][b][j] = sum_{i in slice} dtemb[b,i] silu'(pre[b,i]) W1[i,j]; grid (D/64, B, TB_SLICES), 64 threads
+constexpr int TB_SLICES = 32;
 __global__ void time_bwd_four_kernel(const float* __restrict__ w1, const float* __restrict__ pre,
-                                     const float* __restrict__ dtemb, float* __restrict__ dfour, int B, int D, int Th) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * D) return;
-  const int b = idx / D, j = idx - b * D;
+                                     const float* __restrict__ dtemb, float* __restrict__ partial, int B, int D, int Th) {
+  const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, sl = blockIdx.z;
+  if (j >= D) return;
+  const int per = (Th + TB_SLICES - 1) / TB_SLICES;
+  const int ib = sl * per, ie = min(Th, ib + per);
   float s = 0.f;
-  for (int i = 0; i < Th; i++) s += dtemb[(long)b * Th + i] * silu_grad(pre[(long)b * Th + i]) * w1[(long)i * D + j];
-  dfour[idx] = s;
+  for (int i = ib; i < ie; i++) s += dtemb[(long)b * Th + i] * silu_grad(pre[(long)b * Th + i]) * w1[(long)i * D + j];
+  partial[((long)sl * B + b) * D + j] = s;
 }
 __global__ void time_bwd_wsin_kernel(const float* __restrict__ times, const float* __restrict__ four,
                                      const float* __restrict__ dfour, float* __restrict__ dwsin, int B, int D) {
@@ -363,13 +366,21 @@ __global__ __launch_bounds__(256) void adaln_bwd_t_kernel(const u16* __restrict_
 }
 
 // out[j] (+)= sum_i in[i*ld + j]
-__global__ void sum_rows_kernel(const float* __restrict__ in, long rows, long ld, float* __restrict__ out, long cols,
-                                int accumulate) {
-  const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (j >= cols) return;
+// block = 64 columns x 4 row lanes (launch with 256 threads, grid = cdiv(cols, 64))
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, long rows, long ld, float* __restrict__ out,
+                                                        long cols, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long j = blockIdx.x * 64L + cl;
   float s = 0.f;
-  for (long i = 0; i < rows; i++) s += in[i * ld + j];
-  out[j] = accumulate ? out[j] + s : s;
+  if (j < cols)
+    for (long i = rl; i < rows; i += 4) s += in[i * ld + j];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && j < cols) {
+    const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    out[j] = accumulate ? out[j] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------- GEGLU backward (interleaved layout)
@@ -397,18 +408,41 @@ __global__ void geglu_bwd_kernel(const u16* __restrict__ h1, const u16* __restri
 }
 
 // ---------------------------------------------------------------- column sums
-constexpr int CS_SLABS = 32;
+// stage 1: block = 64 column groups (16 B each) x 4 row lanes over one of CS_SLABS row slabs -> scratch[slab][C]
+constexpr int CS_SLABS = 128;
 template <bool BF16>
-__global__ void colsum_stage1(const void* __restrict__ in, long M, int C, long ld, float* __restrict__ scratch) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_stage1(const void* __restrict__ in, long M, int C, long ld, float* __restrict__ scratch) {
+  constexpr int W = BF16 ? 8 : 4;  // columns per 16-byte load
+  __shared__ float red[4][64][W];
+  const int cgi = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + cgi) * W;
   const int slab = blockIdx.y;
-  if (c >= C) return;
   const long per = (M + CS_SLABS - 1) / CS_SLABS;
   const long rb = slab * per, re = min(M, rb + per);
-  float s = 0.f;
-  for (long r = rb; r < re; r++)
-    s += BF16 ? bf16_to_f32(reinterpret_cast<const u16*>(in)[r * ld + c]) : reinterpret_cast<const float*>(in)[r * ld + c];
-  scratch[(long)slab * C + c] = s;
+  float acc[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) acc[i] = 0.f;
+  if (c0 < C) {
+    for (long r = rb + rl; r < re; r += 4) {
+      if (BF16) {
+        float v[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(in) + r * ld + c0), v);
+#pragma unroll
+        for (int i = 0; i < W; i++) acc[i] += v[i % 8];
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + r * ld + c0);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < W; i++) red[rl][cgi][i] = acc[i];
+  __syncthreads();
+  if (rl == 0 && c0 < C) {
+#pragma unroll
+    for (int i = 0; i < W; i++)
+      scratch[(long)slab * C + c0 + i] = red[0][cgi][i] + red[1][cgi][i] + red[2][cgi][i] + red[3][cgi][i];
+  }
 }
 __global__ void colsum_stage2(const float* __restrict__ scratch, int C, float* __restrict__ out, int out_len, int rowmap,
                               int F) {
@@ -424,13 +458,14 @@ __global__ void colsum_stage2(const float* __restrict__ scratch, int C, float* _
 
 // ---------------------------------------------------------------- masked MSE
 // per_b[b] = sum_n mask * mean_d (p-t)^2 / max(count,1e-5) ; per_b[B+b] = den
+constexpr int MSE_SPLITS = 16;
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                        const uint8_t* __restrict__ lmask, float* __restrict__ per_b, int B,
                                                        int N, int D) {
   __shared__ float red[8];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, sp = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.f, cnt = 0.f;
-  for (int n = wave; n < N; n += 4) {
+  for (int n = sp * 4 + wave; n < N; n += 4 * MSE_SPLITS) {
     if (!lmask[(long)b * N + n]) continue;
     const float4* p4 = reinterpret_cast<const float4*>(pred + ((long)b * N + n) * D);
     const float4* t4 = reinterpret_cast<const float4*>(target + ((long)b * N + n) * D);
@@ -447,16 +482,25 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ 
   if (lane == 0) { red[wave] = acc; red[4 + wave] = cnt; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float num = red[0] + red[1] + red[2] + red[3];
-    const float den = fmaxf(red[4] + red[5] + red[6] + red[7], 1e-5f);
-    per_b[b] = num / den;
-    per_b[B + b] = den;
+    float* part = per_b + 2 * B + ((long)b * MSE_SPLITS + sp) * 2;
+    part[0] = red[0] + red[1] + red[2] + red[3];
+    part[1] = red[4] + red[5] + red[6] + red[7];
   }
 }
-__global__ void mse_mean_kernel(const float* __restrict__ per_b, float* __restrict__ loss, int B) {
+__global__ void mse_mean_kernel(float* __restrict__ per_b, float* __restrict__ loss, int B) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
-    for (int b = 0; b < B; b++) s += per_b[b];
+    for (int b = 0; b < B; b++) {
+      float num = 0.f, cnt = 0.f;
+      for (int k = 0; k < MSE_SPLITS; k++) {
+        num += per_b[2 * B + ((long)b * MSE_SPLITS + k) * 2];
+        cnt += per_b[2 * B + ((long)b * MSE_SPLITS + k) * 2 + 1];
+      }
+      const float den = fmaxf(cnt, 1e-5f);
+      per_b[b] = num / den;
+      per_b[B + b] = den;
+      s += num / den;
+    }
     loss[0] = s / (float)B;
   }
 }
@@ -709,13 +753,20 @@ extern "C" int vbx_time_embed_fwd(const float* times, const float* w_sin, const 
   return 0;
 }
 
+extern "C" int vbx_time_embed_bwd_scratch_floats(int B, int D) { return (1 + TB_SLICES) * B * D; }
+
 extern "C" int vbx_time_embed_bwd(const float* times, const float* w_sin, const float* w1, const float* four,
                                   const float* pre, const float* dtemb, float* dw_sin, float* dw1, float* db1,
                                   float* scratch, int B, int D, int Th, void* stream) {
   VBX_REQUIRE(times && w_sin && w1 && four && pre && dtemb && dw_sin && dw1 && db1 && scratch, "vbx_time_embed_bwd: null");
   hipLaunchKernelGGL(time_bwd_w1_kernel, dim3(cdiv((long)Th * D, 256)), dim3(256), 0, ST, four, pre, dtemb, dw1, db1, B, D, Th);
   VBX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(time_bwd_four_kernel, dim3(cdiv((long)B * D, 256)), dim3(256), 0, ST, w1, pre, dtemb, scratch, B, D, Th);
+  // scratch: [0, B*D) d(four) ; [B*D, (1+TB_SLICES)*B*D) partials
+  hipLaunchKernelGGL(time_bwd_four_kernel, dim3(cdiv(D, 64), B, TB_SLICES), dim3(64), 0, ST, w1, pre, dtemb, scratch + (long)B * D,
+                     B, D, Th);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * D, 64)), dim3(256), 0, ST, scratch + (long)B * D, (long)TB_SLICES,
+                     (long)B * D, scratch, (long)B * D, 0);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(time_bwd_wsin_kernel, dim3(cdiv(D / 2, 256)), dim3(256), 0, ST, times, four, scratch, dw_sin, B, D);
   VBX_LAUNCH_CHECK();
@@ -751,7 +802,7 @@ extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const f
   hipLaunchKernelGGL(adaln_bwd_t_kernel, dim3(cdiv(Th / 8, 256), ADA_SLICES), dim3(256), 0, ST, (const u16*)w_bf16, dada,
                      scratch, B, Th, J, 8);
   VBX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 256)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 64)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
                      (long)B * Th, dtemb, (long)B * Th, accumulate_dtemb);
   VBX_LAUNCH_CHECK();
   return 0;
@@ -759,7 +810,7 @@ extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const f
 
 extern "C" int vbx_sum_rows_f32(const float* in, long rows, long ld, float* out, long cols, int accumulate, void* stream) {
   VBX_REQUIRE(in && out && rows > 0 && cols > 0, "vbx_sum_rows_f32: bad args");
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, ST, in, rows, ld, out, cols, accumulate);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, ST, in, rows, ld, out, cols, accumulate);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -777,7 +828,8 @@ extern "C" int vbx_colsum_scratch_floats(int M, int C) { return CS_SLABS * C; }
 extern "C" int vbx_colsum_bf16(const void* in_bf16, int M, int C, int ld, float* out, int out_len, int rowmap, int F,
                                float* scratch, void* stream) {
   VBX_REQUIRE(in_bf16 && out && scratch, "vbx_colsum_bf16: null pointer");
-  hipLaunchKernelGGL(colsum_stage1<true>, dim3(cdiv(C, 256), CS_SLABS), dim3(256), 0, ST, in_bf16, (long)M, C, (long)ld, scratch);
+  VBX_REQUIRE(C % 8 == 0 && ld % 8 == 0, "vbx_colsum_bf16: C and ld must be multiples of 8");
+  hipLaunchKernelGGL(colsum_stage1<true>, dim3(cdiv(C, 64 * 8), CS_SLABS), dim3(256), 0, ST, in_bf16, (long)M, C, (long)ld, scratch);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, ST, scratch, C, out, out_len, rowmap, F);
   VBX_LAUNCH_CHECK();
@@ -785,7 +837,8 @@ extern "C" int vbx_colsum_bf16(const void* in_bf16, int M, int C, int ld, float*
 }
 extern "C" int vbx_colsum_f32(const float* in, int M, int C, int ld, float* out, float* scratch, void* stream) {
   VBX_REQUIRE(in && out && scratch, "vbx_colsum_f32: null pointer");
-  hipLaunchKernelGGL(colsum_stage1<false>, dim3(cdiv(C, 256), CS_SLABS), dim3(256), 0, ST, (const void*)in, (long)M, C,
+  VBX_REQUIRE(C % 4 == 0 && ld % 4 == 0, "vbx_colsum_f32: C and ld must be multiples of 4");
+  hipLaunchKernelGGL(colsum_stage1<false>, dim3(cdiv(C, 64 * 4), CS_SLABS), dim3(256), 0, ST, (const void*)in, (long)M, C,
                      (long)ld, scratch);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 256)), dim3(256), 0, ST, scratch, C, out, C, 0, 0);
@@ -793,10 +846,12 @@ extern "C" int vbx_colsum_f32(const float* in, int M, int C, int ld, float* out,
   return 0;
 }
 
+extern "C" int vbx_masked_mse_scratch_floats(int B) { return 2 * B + 2 * MSE_SPLITS * B; }
+
 extern "C" int vbx_masked_mse_fwd(const float* pred, const float* target, const uint8_t* loss_mask, float* per_b, float* loss,
                                   int B, int N, int D, void* stream) {
   VBX_REQUIRE(pred && target && loss_mask && per_b && loss && D % 4 == 0, "vbx_masked_mse_fwd: bad args");
-  hipLaunchKernelGGL(mse_fwd_kernel, dim3(B), dim3(256), 0, ST, pred, target, loss_mask, per_b, B, N, D);
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(MSE_SPLITS, B), dim3(256), 0, ST, pred, target, loss_mask, per_b, B, N, D);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(mse_mean_kernel, dim3(1), dim3(64), 0, ST, per_b, loss, B);
   VBX_LAUNCH_CHECK();

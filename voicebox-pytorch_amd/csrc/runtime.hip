@@ -155,7 +155,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
   a.hf = tr ? c.take<u16>((size_t)d.M0 * d.D) : nullptr;
   a.hfh = c.take<u16>((size_t)d.M0 * d.D);
   a.pred = c.take<float>((size_t)d.M0 * d.D);
-  a.per_b = c.take<float>(2 * d.B + 1);
+  a.per_b = c.take<float>(vbx_masked_mse_scratch_floats(d.B));
   if (tr) {
     a.dx = c.take<float>((size_t)d.M * d.D);
     a.dxb = c.take<u16>((size_t)d.M * d.D);
@@ -189,7 +189,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.deb = c.take<u16>((size_t)d.M0 * d.D);
     a.dpb = c.take<u16>((size_t)d.M0 * d.D);
     a.wpart = c.take<float>((size_t)vbx_convpos_bwd_chunks(d.B, d.N) * d.D * 64);
-    a.tscratch = c.take<float>((size_t)d.B * d.D);
+    a.tscratch = c.take<float>((size_t)vbx_time_embed_bwd_scratch_floats(d.B, d.D));
   }
   a.bytes = al256(c.off);
 }
