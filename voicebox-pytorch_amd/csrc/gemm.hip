@@ -103,7 +103,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Give every
+  // XCD one CONTIGUOUS chunk of the tile sequence (n fastest), so the ~64 tiles an XCD runs concurrently share a few
+  // A row-panels and the B panels they stream stay in that XCD's L2.  Bijective for any tile count.
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int split = blockIdx.y;
   const int kbeg = split * p.kchunk;
