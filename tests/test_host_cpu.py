@@ -1,0 +1,129 @@
+"""CPU (-m "not gpu"): host logic of the product package -- no compute calls.
+ * the C-ABI library loads and exports every symbol include/vbx.h declares;
+ * mask helpers are bit-exact with the reference's golden vectors;
+ * state-dict layout equals the reference's (keys, shapes) and parameters flatten into one buffer;
+ * the product path FAILS LOUDLY without a GPU (no CPU fallback).
+"""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "vbx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vbx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    from voicebox_pytorch_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) > 40
+    missing = [s for s in syms if not hasattr(l, s)]
+    assert not missing, missing
+    bound = _lib.lib()  # binds prototypes for everything the host calls
+    assert bound.vbx_version() == 1
+    assert set(_lib.exported_symbols()) <= set(syms) | {"vbx_last_error"}
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate arguments on the host before any launch: callable without a GPU."""
+    from voicebox_pytorch_amd import _lib
+
+    l = _lib.lib()
+    d = _lib.GemmDesc()
+    assert l.vbx_gemm(d, None) != 0
+    assert b"null operand" in l.vbx_last_error()
+    with pytest.raises(_lib.VbxError):
+        _lib.call("vbx_rmsnorm_fwd", None, None, None, 0, None, None, 1, 1, 0, 1, 64, None)
+
+
+def test_masks_bit_exact(golden):
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("masks")
+    for n, expect in g["cases"].items():
+        with rng_override(rand=g["rand"]):
+            assert torch.equal(vbx.mask_from_frac_lengths(n, g["frac"]), expect), n
+    assert torch.equal(vbx.mask_from_start_end_indices(8, g["start"], g["end"]), g["start_end_8"])
+    torch.manual_seed(11)  # un-injected path draws from the global generator exactly like the reference (:146)
+    assert torch.equal(vbx.mask_from_frac_lengths(1024, g["frac"]), g["frac_helper_1024"])
+    assert vbx.prob_mask_like((3,), 1, "cpu").all() and not vbx.prob_mask_like((3,), 0, "cpu").any()
+    a, b = torch.tensor([True, False, True]), torch.tensor([True, True, False])
+    assert torch.equal(vbx.reduce_masks_with_and(a, None, b), a & b) and vbx.reduce_masks_with_and(None) is None
+
+
+def test_state_dict_layout_matches_reference(golden):
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("small")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    sd = vb.state_dict()
+    assert set(sd) == set(g["state"])
+    assert all(sd[k].shape == g["state"][k].shape for k in sd)
+    w = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    assert set(w.state_dict()) == {"voicebox." + k for k in sd}
+    fp = vb.flat_params()
+    assert fp.is_current() and fp.numel >= sum(p.numel() for p in vb.parameters() if p.requires_grad)
+    vb.load_state_dict(g["state"])
+    assert fp.is_current()
+    assert torch.equal(vb.to_pred.weight, g["state"]["to_pred.weight"])
+    # gradients complete front-to-back: stage ranges tile the flat buffer contiguously
+    lo = 0
+    for a, b in fp.stage_ranges:
+        assert a == lo and b > a
+        lo = b
+    assert lo == fp.numel
+    # reference parameter count for the benchmark architectures
+    n = lambda **kw: sum(p.numel() for p in vbx.VoiceBox(num_cond_tokens=1, dim_head=64, heads=16, condition_on_text=False, **kw).parameters())
+    assert n(dim=512, depth=2) == 18654292
+
+
+def test_no_cpu_fallback(golden):
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd import _lib
+
+    g = golden("small")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    w = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    if not torch.cuda.is_available():
+        with pytest.raises((_lib.VbxError, RuntimeError, AssertionError)):
+            w(g["x1"])
+        with pytest.raises((_lib.VbxError, RuntimeError, AssertionError)):
+            w.sample(cond=g["cond"], steps=3)
+
+
+def test_unsupported_configurations_raise():
+    import voicebox_pytorch_amd as vbx
+
+    for kw in (dict(dim_head=32), dict(use_gateloop_layers=True), dict(attn_dropout=0.1), dict(ff_dropout=0.1),
+               dict(conv_pos_embed_kernel_size=15), dict(dim=100)):
+        base = dict(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        base.update(kw)
+        with pytest.raises((NotImplementedError, AssertionError)):
+            vbx.VoiceBox(**base)
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    with pytest.raises(NotImplementedError):
+        vbx.ConditionalFlowMatcherWrapper(voicebox=vb, use_torchode=True)
+
+
+def test_midpoint_tables_match_oracle_grid():
+    """dt_i = t[i+1]-t[i] from the same fp32 linspace as the oracle: linspace(0,1,64) has several distinct dt."""
+    t = torch.linspace(0, 1, 64)
+    dt = t[1:] - t[:-1]
+    assert len(set(dt.tolist())) > 1
+    t65 = torch.linspace(0, 1, 65)
+    assert len(set((t65[1:] - t65[:-1]).tolist())) == 1  # 64 intervals: dt = 1/64 exactly
