@@ -6,6 +6,7 @@
 // hardware transpose read ds_read_b64_tr_b16, so no transposed copies of weights or activations
 // ever exist in HBM.  The fp32 C tile is staged through LDS so every epilogue stores 16/32 B per lane.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -176,7 +177,173 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
         Cs[row * CS_LD + col] = acc[i][j][r];
       }
   __syncthreads();
-  epi(Cs, m0, n0, tid, split, p.M, p.N);
+  epi(Cs, m0, n0, tid, split, p.M, p.N, 128);
+}
+
+
+// =====================================================================================================
+// v2 main loop: LDS-DMA (global_load_lds, 16 B/lane) into a 4-stage ring of 128x128x32 k-tiles.
+// Up to 3 stages (48 KiB per workgroup, 2 workgroups per CU) are in flight while a stage is consumed, which is
+// what hides the ~1.5 us loaded-memory latency the 1-deep register-staged loop exposed (14-18 % MFMA utilisation
+// measured).  The DMA destination is lane-linear, so bank-conflict-free layouts are obtained by permuting the
+// per-lane SOURCE address and applying the same permutation on the fragment read.  Fragment reads are inline asm:
+// hipcc would otherwise drain vmcnt(0) before every compiler-visible ds_read while a DMA is in flight.
+// =====================================================================================================
+constexpr int BK2 = 32, NST = 3;
+constexpr int OP_BYTES = 8192;             // one operand stage: [128][32] or [32][128] 16-bit
+constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A | B
+constexpr int GEMM2_LDS = NST * STAGE_BYTES;  // 48 KiB -> 3 workgroups per CU; also holds a 64-row fp32 C half tile
+static_assert(GEMM2_LDS >= 64 * CS_LD * 4, "half C tile must fit");
+
+__device__ uint4 g_zero_page[4];  // source of out-of-range lanes (K tail, ragged M/N)
+
+VBX_DEV unsigned lds_addr(const char* p) { return (unsigned)(size_t)LDS_PTR(char, p); }
+
+// KC stage layout: rows 2p,2p+1 share a 128-byte line; 16-byte slot (c + 4*(r&1)) ^ (p&7)
+// KS stage layout: 256-byte k-rows; 32-byte pair index P ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2
+VBX_DEV int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <int MODE, int OUTER>  // OUTER = rows (MODE 0) / columns (MODE 1) of the operand stage: 128 or 64 (MODE 0 only)
+VBX_DEV void dma_stage(char* dst, const u16* __restrict__ X, long ld, int o0, int olim, int k0, int kend, int tid) {
+  static_assert(MODE == 0 || OUTER == 128, "K-strided stages are 128 wide");
+#pragma unroll
+  for (int i = 0; i < OUTER / 64; i++) {
+    const int s = i * 256 + tid;  // 16-byte slot inside the operand stage (lane-linear: slot = base + lane)
+    const u16* src;
+    if (MODE == 0) {
+      const int p = s >> 3, x = (s & 7) ^ (p & 7);
+      const int r = 2 * p + (x >> 2), c = x & 3;
+      const int go = o0 + r, gk = k0 + c * 8;
+      src = (go < olim && gk < kend) ? X + (long)go * ld + gk : reinterpret_cast<const u16*>(g_zero_page);
+    } else {
+      const int kr = s >> 4, pc = s & 15;
+      const int P = (pc >> 1) ^ ks_f(kr);
+      const int col = (2 * P + (pc & 1)) * 8;
+      const int gk = k0 + kr, go = o0 + col;
+      src = (gk < kend && go < olim) ? X + (long)gk * ld + go : reinterpret_cast<const u16*>(g_zero_page);
+    }
+    char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;  // wave-uniform; the DMA adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
+  }
+}
+
+// fragment for outer indices [woff + s*16, +16), the stage's single 32-deep k-step
+template <int MODE>
+VBX_DEV void frag2_issue(bf16x8& out, s16x4& lo, s16x4& hi, const char* st, int woff, int s, int lane) {
+  if (MODE == 0) {
+    const int r = woff + s * 16 + (lane & 15), c = lane >> 4, p = r >> 1;
+    const unsigned a = lds_addr(st + p * 128 + (((c + 4 * (r & 1)) ^ (p & 7)) << 4));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(out) : "v"(a) : "memory");
+  } else {
+    const int g = lane >> 4, a16 = lane & 15;
+    const int kr = g * 8 + (a16 >> 2);
+    const int col = woff + s * 16 + 4 * (a16 & 3);
+    const int ch = col >> 3;
+    const unsigned a = lds_addr(st + kr * 256 + ((((ch >> 1) ^ ks_f(kr)) * 2 + (ch & 1)) << 4) + (col & 7) * 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");  // k + 4 (same f(k))
+  }
+}
+
+// BM_ = 128: 2x2 waves of 64x64.  BM_ = 64 (MA == 0 only): 1x4 waves of 64x32 -- twice the workgroups for the
+// N = dim GEMMs (out-proj, ff-out, dgrads into the residual width) that would otherwise fill half the chip.
+template <int MA, int MB, class Epi, bool F16, int BM_>
+__global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WM = BM_ / 64, NT_ = (WM == 2) ? 4 : 2;
+  constexpr int DMAS = BM_ / 64 + 2;  // LDS-DMA instructions per thread per stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * BM_, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nt = (kend - kbeg + BK2 - 1) / BK2;
+
+  f32x4 acc[4][NT_];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < NT_; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; s++) {
+    if (s < nt) {
+      dma_stage<MA, BM_>(smem + s * STAGE_BYTES, p.A, p.lda, m0, p.M, kbeg + s * BK2, kend, tid);
+      dma_stage<MB, 128>(smem + s * STAGE_BYTES + OP_BYTES, p.B, p.ldb, n0, p.N, kbeg + s * BK2, kend, tid);
+    }
+  }
+
+  for (int t = 0; t < nt; t++) {
+    // this thread's DMAs of tile t have landed once at most NST-2 younger stages (DMAS instructions each) are pending
+    const int younger = nt - 1 - t;
+    if (younger >= NST - 2) {
+      if (DMAS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; everyone is done reading tile t-1
+    if (t + NST - 1 < nt) {
+      char* dst = smem + ((t + NST - 1) % NST) * STAGE_BYTES;  // the stage tile t-1 occupied
+      dma_stage<MA, BM_>(dst, p.A, p.lda, m0, p.M, kbeg + (t + NST - 1) * BK2, kend, tid);
+      dma_stage<MB, 128>(dst + OP_BYTES, p.B, p.ldb, n0, p.N, kbeg + (t + NST - 1) * BK2, kend, tid);
+    }
+    const char* sa = smem + (t % NST) * STAGE_BYTES;
+    const char* sb = sa + OP_BYTES;
+    bf16x8 af[4], bfr[NT_];
+    s16x4 alo[4], ahi[4], blo[NT_], bhi[NT_];
+#pragma unroll
+    for (int s = 0; s < 4; s++) frag2_issue<MA>(af[s], alo[s], ahi[s], sa, wm * 64, s, lane);
+#pragma unroll
+    for (int s = 0; s < NT_; s++) frag2_issue<MB>(bfr[s], blo[s], bhi[s], sb, wn * NT_ * 16, s, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (MA == 1) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        s16x8 v = {alo[s][0], alo[s][1], alo[s][2], alo[s][3], ahi[s][0], ahi[s][1], ahi[s][2], ahi[s][3]};
+        af[s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+    if (MB == 1) {
+#pragma unroll
+      for (int s = 0; s < NT_; s++) {
+        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
+        bfr[s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NT_; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+  }
+  // ---- epilogue: the fp32 C tile goes through LDS in 64-row halves (keeps the footprint at 48 KiB)
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int h = 0; h < WM; h++) {
+    __syncthreads();  // ring (h = 0) / previous half (h = 1) no longer read
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NT_; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int row = i * 16 + (lane >> 4) * 4 + rr;
+            const int col = wn * NT_ * 16 + j * 16 + (lane & 15);
+            Cs[row * CS_LD + col] = acc[i][j][rr];
+          }
+    }
+    __syncthreads();
+    epi(Cs, m0 + h * 64, n0, tid, split, p.M, p.N, 64);
+  }
 }
 
 VBX_DEV void load8(const float* Cs, int row, int cc, float v[8]) {
@@ -194,9 +361,8 @@ VBX_DEV uint4 pack8_f16(const float v[8]) {
 // ------------------------------------------------------------------------------- epilogues
 struct EpiBF16 {
   u16* C; long ldc; const float* bias;
-  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
+    for (int it = 0; it < rows / 16; it++) {
       const int row = it * 16 + (tid >> 4), cc = tid & 15;
       const int gr = m0 + row, gc = n0 + cc * 8;
       if (gr < M && gc < N) {
@@ -214,9 +380,8 @@ struct EpiBF16 {
 
 struct EpiF32 {
   float* C; long ldc; const float* bias; const float* resid; u16* C2;
-  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
+    for (int it = 0; it < rows / 16; it++) {
       const int row = it * 16 + (tid >> 4), cc = tid & 15;
       const int gr = m0 + row, gc = n0 + cc * 8;
       if (gr < M && gc < N) {
@@ -242,9 +407,8 @@ struct EpiF32 {
 
 struct EpiSplitK {
   float* C;
-  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int split, int M, int N) const {
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int split, int M, int N, int rows) const {
+    for (int it = 0; it < rows / 16; it++) {
       const int row = it * 16 + (tid >> 4), cc = tid & 15;
       const int gr = m0 + row, gc = n0 + cc * 8;
       if (gr < M && gc < N) {
@@ -262,9 +426,8 @@ struct EpiSplitK {
 // 128-column tile holds 64 "x" columns followed by their 64 "gate" columns.
 struct EpiGEGLU {
   u16* G; long ldg; const float* bias; u16* H1; long ldh; u16* Gb; int g_f16;
-  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
+    for (int it = 0; it < rows / 32; it++) {
       const int row = it * 32 + (tid >> 3), cc = tid & 7;
       const int gr = m0 + row;
       if (gr < M) {
@@ -283,8 +446,7 @@ struct EpiGEGLU {
       }
     }
     if (H1) {
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
+      for (int it = 0; it < rows / 16; it++) {
         const int row = it * 16 + (tid >> 4), cc = tid & 15;
         const int gr = m0 + row, gc = n0 + cc * 8;
         if (gr < M) {
@@ -305,12 +467,11 @@ struct EpiQKV {
   float qk_scale;
   const float* qg; const float* kg; const float* rc; const float* rs;
   u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn; u16* v16;
-  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N) const {
+  VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
     const int I = H * 64;
     const int which = n0 / I;
     const int hbase = (n0 % I) >> 6;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
+    for (int it = 0; it < rows / 16; it++) {
       const int row = it * 16 + (tid >> 4), cc = tid & 15;
       const int gr = m0 + row;
       const bool valid = gr < M;
@@ -361,15 +522,38 @@ struct EpiQKV {
 };
 
 template <int MA, int MB, bool F16 = false, class Epi>
-int launch(const GemmParams& p, const Epi& epi, int splits, hipStream_t st) {
-  static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
+int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
+  static bool attr_set = false;  // >48 KiB dynamic LDS needs the opt-in once per kernel
+  static const bool legacy = getenv("VBX_GEMM_LEGACY") != nullptr;  // A/B switch: 1-deep register-staged main loop
   auto kern = gemm_kernel<MA, MB, Epi, F16>;
+  auto kern128 = gemm_kernel_v2<MA, MB, Epi, F16, 128>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern128), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), GEMM_LDS, st, p, epi);
+  const int tiles_n = cdiv(p.N, BN);
+  if (legacy) {
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM_LDS, st, p, epi);
+  } else {
+    bool small = false;
+    if constexpr (MA == 0 && MB == 1) {
+      // dgrad into the residual width (N = dim): fewer than ~1.5 workgroups per CU with 128-row tiles -> halve the
+      // tile height (64x128) to fill the chip (measured +11 % on the dim-512 dgrads; NT forward GEMMs lose 10 %)
+      small = (long)p.tiles_m * tiles_n * splits < 384;
+      if (small) {
+        static bool attr64 = false;
+        auto kern64 = gemm_kernel_v2<MA, MB, Epi, F16, 64>;
+        if (!attr64) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern64), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
+          attr64 = true;
+        }
+        p.tiles_m = cdiv(p.M, 64);
+        hipLaunchKernelGGL(kern64, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM2_LDS, st, p, epi);
+      }
+    }
+    if (!small) hipLaunchKernelGGL(kern128, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM2_LDS, st, p, epi);
+  }
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -106,8 +106,9 @@ class FlatParams:
 
     def flatten(self):
         dev = self.slots[self.order[0]].device
-        flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        with torch.no_grad():
+        # may be reached from sample() (inference_mode): the flat buffer must be a normal tensor (version counter)
+        with torch.inference_mode(False), torch.no_grad():
+            flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
             for s in self.order:
                 p = self.slots[s]
                 o = self.offsets[s]
