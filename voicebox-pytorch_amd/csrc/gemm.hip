@@ -7,6 +7,7 @@
 // ever exist in HBM.  The fp32 C tile is staged through LDS so every epilogue stores 16/32 B per lane.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -88,6 +89,7 @@ struct GemmParams {
   long lda, ldb;
   int kchunk;  // K range handled by one blockIdx.y (multiple of BK); == K when not split
   int tiles_m;
+  int abl;     // timing ablations (tools only; results are wrong when != 0): 1 no DMA, 2 no LDS reads, 4 no barrier
 };
 
 // 16x16x32 MFMA on raw 16-bit fragments: bf16 (default) or fp16 (the q/k projection: 11-bit mantissa)
@@ -203,51 +205,86 @@ VBX_DEV unsigned lds_addr(const char* p) { return (unsigned)(size_t)LDS_PTR(char
 // KS stage layout: 256-byte k-rows; 32-byte pair index P ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2
 VBX_DEV int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-template <int MODE, int OUTER>  // OUTER = rows (MODE 0) / columns (MODE 1) of the operand stage: 128 or 64 (MODE 0 only)
-VBX_DEV void dma_stage(char* dst, const u16* __restrict__ X, long ld, int o0, int olim, int k0, int kend, int tid) {
+// Per-thread, loop-invariant description of the LDS-DMA pieces of one operand (hoisted out of the k-loop: the 8192^3
+// profile of the first version showed 3 non-MFMA VALU instructions per MFMA, almost all address arithmetic).
+template <int MODE, int OUTER>
+struct DmaPlan {
   static_assert(MODE == 0 || OUTER == 128, "K-strided stages are 128 wide");
+  static constexpr int N = OUTER / 64;  // DMA instructions per thread per stage
+  const u16* base[N];                   // source of k-tile 0
+  int kq[N];                            // MODE 0: k offset of the piece inside the tile; MODE 1: k row of the piece
+  bool ok[N];                           // outer index in range
+  long kstride;                         // elements per unit of k: 1 (k contiguous) or ld (k strided)
+  VBX_DEV void init(const u16* __restrict__ X, long ld, int o0, int olim, int tid) {
+    kstride = (MODE == 0) ? 1 : ld;
 #pragma unroll
-  for (int i = 0; i < OUTER / 64; i++) {
-    const int s = i * 256 + tid;  // 16-byte slot inside the operand stage (lane-linear: slot = base + lane)
-    const u16* src;
-    if (MODE == 0) {
-      const int p = s >> 3, x = (s & 7) ^ (p & 7);
-      const int r = 2 * p + (x >> 2), c = x & 3;
-      const int go = o0 + r, gk = k0 + c * 8;
-      src = (go < olim && gk < kend) ? X + (long)go * ld + gk : reinterpret_cast<const u16*>(g_zero_page);
-    } else {
-      const int kr = s >> 4, pc = s & 15;
-      const int P = (pc >> 1) ^ ks_f(kr);
-      const int col = (2 * P + (pc & 1)) * 8;
-      const int gk = k0 + kr, go = o0 + col;
-      src = (gk < kend && go < olim) ? X + (long)gk * ld + go : reinterpret_cast<const u16*>(g_zero_page);
+    for (int i = 0; i < N; i++) {
+      const int s = i * 256 + tid;  // 16-byte slot inside the operand stage (lane-linear: slot = base + lane)
+      if (MODE == 0) {
+        const int p = s >> 3, x = (s & 7) ^ (p & 7);
+        const int r = 2 * p + (x >> 2);
+        kq[i] = (x & 3) * 8;
+        ok[i] = (o0 + r) < olim;
+        base[i] = X + (long)(o0 + r) * ld + kq[i];
+      } else {
+        const int kr = s >> 4, pc = s & 15;
+        const int P = (pc >> 1) ^ ks_f(kr);
+        const int col = (2 * P + (pc & 1)) * 8;
+        kq[i] = kr;
+        ok[i] = (o0 + col) < olim;
+        base[i] = X + (long)kr * ld + o0 + col;
+      }
     }
-    char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;  // wave-uniform; the DMA adds lane*16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
   }
-}
+  // issue the DMAs of the k-tile starting at k0 into the operand stage at LDS byte address `dst` (wave-uniform part)
+  VBX_DEV void issue(char* dst, int k0, int kend, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const bool in = ok[i] && (k0 + kq[i] < kend);
+      const u16* src = in ? base[i] + (long)k0 * kstride : reinterpret_cast<const u16*>(g_zero_page);
+      char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;  // the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
+    }
+  }
+};
 
-// fragment for outer indices [woff + s*16, +16), the stage's single 32-deep k-step
+// Fragment reads with compile-time stage/operand offsets folded into the DS immediate.
+// MODE 0: the lane's address for sub-tile s is addr0 + s*1024 (8 row-pairs further, same swizzle phase).
+// MODE 1: the 32-byte pair swizzle is not linear in s -> four precomputed lane addresses.
 template <int MODE>
-VBX_DEV void frag2_issue(bf16x8& out, s16x4& lo, s16x4& hi, const char* st, int woff, int s, int lane) {
-  if (MODE == 0) {
-    const int r = woff + s * 16 + (lane & 15), c = lane >> 4, p = r >> 1;
-    const unsigned a = lds_addr(st + p * 128 + (((c + 4 * (r & 1)) ^ (p & 7)) << 4));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(out) : "v"(a) : "memory");
-  } else {
-    const int g = lane >> 4, a16 = lane & 15;
-    const int kr = g * 8 + (a16 >> 2);
-    const int col = woff + s * 16 + 4 * (a16 & 3);
-    const int ch = col >> 3;
-    const unsigned a = lds_addr(st + kr * 256 + ((((ch >> 1) ^ ks_f(kr)) * 2 + (ch & 1)) << 4) + (col & 7) * 2);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");  // k + 4 (same f(k))
+struct FragPlan {
+  unsigned a[MODE == 0 ? 1 : 4];
+  VBX_DEV void init(const char* smem, int woff, int lane) {
+    if (MODE == 0) {
+      const int r = woff + (lane & 15), c = lane >> 4, p = r >> 1;
+      a[0] = lds_addr(smem + p * 128 + (((c + 4 * (r & 1)) ^ (p & 7)) << 4));
+    } else {
+      const int g = lane >> 4, a16 = lane & 15;
+      const int kr = g * 8 + (a16 >> 2);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int col = woff + s * 16 + 4 * (a16 & 3);
+        const int ch = col >> 3;
+        a[s] = lds_addr(smem + kr * 256 + ((((ch >> 1) ^ ks_f(kr)) * 2 + (ch & 1)) << 4) + (col & 7) * 2);
+      }
+    }
   }
-}
+  template <int OFF, int S>  // OFF: byte offset of the operand stage inside the ring
+  VBX_DEV void read(bf16x8& out, s16x4& lo, s16x4& hi) const {
+    if (MODE == 0) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(a[0]), "i"(OFF + S * 1024) : "memory");
+    } else {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a[MODE == 0 ? 0 : S]), "i"(OFF) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a[MODE == 0 ? 0 : S]), "i"(OFF + 1024) : "memory");
+    }
+  }
+};
 
 // BM_ = 128: 2x2 waves of 64x64.  BM_ = 64 (MA == 0 only): 1x4 waves of 64x32 -- twice the workgroups for the
-// N = dim GEMMs (out-proj, ff-out, dgrads into the residual width) that would otherwise fill half the chip.
+// N = dim dgrads that would otherwise fill half the chip.
+// Timing ablations on 8192^3 (VBX_GEMM_ABL, tools only): full 690 TF; no LDS reads 691; no barrier 706; no DMA 1350;
+// neither DMA nor LDS reads 2080 (83 % of peak) -> the L2->LDS operand stream of 128x128 tiles (64 FLOP/B) is the limiter.
 template <int MA, int MB, class Epi, bool F16, int BM_>
 __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -266,6 +303,15 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg + BK2 - 1) / BK2;
 
+  DmaPlan<MA, BM_> da;
+  DmaPlan<MB, 128> db;
+  da.init(p.A, p.lda, m0, p.M, tid);
+  db.init(p.B, p.ldb, n0, p.N, tid);
+  FragPlan<MA> fa;
+  FragPlan<MB> fb;
+  fa.init(smem, wm * 64, lane);
+  fb.init(smem, wn * NT_ * 16, lane);
+
   f32x4 acc[4][NT_];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -275,34 +321,48 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
 #pragma unroll
   for (int s = 0; s < NST - 1; s++) {
     if (s < nt) {
-      dma_stage<MA, BM_>(smem + s * STAGE_BYTES, p.A, p.lda, m0, p.M, kbeg + s * BK2, kend, tid);
-      dma_stage<MB, 128>(smem + s * STAGE_BYTES + OP_BYTES, p.B, p.ldb, n0, p.N, kbeg + s * BK2, kend, tid);
+      da.issue(smem + s * STAGE_BYTES, kbeg + s * BK2, kend, tid);
+      db.issue(smem + s * STAGE_BYTES + OP_BYTES, kbeg + s * BK2, kend, tid);
     }
   }
 
-  for (int t = 0; t < nt; t++) {
+  // one k-tile; STG (the ring slot of tile t) is a compile-time constant so every LDS offset is an immediate
+  auto step = [&](auto stg_c, int t) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int NXT = (STG + NST - 1) % NST;  // slot of tile t-1 == slot tile t+NST-1 will use
     // this thread's DMAs of tile t have landed once at most NST-2 younger stages (DMAS instructions each) are pending
-    const int younger = nt - 1 - t;
-    if (younger >= NST - 2) {
+    if (nt - 1 - t >= NST - 2) {
       if (DMAS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; everyone is done reading tile t-1
-    if (t + NST - 1 < nt) {
-      char* dst = smem + ((t + NST - 1) % NST) * STAGE_BYTES;  // the stage tile t-1 occupied
-      dma_stage<MA, BM_>(dst, p.A, p.lda, m0, p.M, kbeg + (t + NST - 1) * BK2, kend, tid);
-      dma_stage<MB, 128>(dst + OP_BYTES, p.B, p.ldb, n0, p.N, kbeg + (t + NST - 1) * BK2, kend, tid);
+    if (!(p.abl & 4)) __builtin_amdgcn_s_barrier();  // tile t visible to all waves; everyone is done reading tile t-1
+    if (t + NST - 1 < nt && !(p.abl & 1)) {
+      da.issue(smem + NXT * STAGE_BYTES, kbeg + (t + NST - 1) * BK2, kend, tid);
+      db.issue(smem + NXT * STAGE_BYTES + OP_BYTES, kbeg + (t + NST - 1) * BK2, kend, tid);
     }
-    const char* sa = smem + (t % NST) * STAGE_BYTES;
-    const char* sb = sa + OP_BYTES;
-    bf16x8 af[4], bfr[NT_];
-    s16x4 alo[4], ahi[4], blo[NT_], bhi[NT_];
+    bf16x8 af[4], bfr[4];
+    s16x4 alo[4], ahi[4], blo[4], bhi[4];
+    if ((p.abl & 2) && t > 0) {  // ablation: skip the LDS fragment reads (registers keep whatever they hold)
 #pragma unroll
-    for (int s = 0; s < 4; s++) frag2_issue<MA>(af[s], alo[s], ahi[s], sa, wm * 64, s, lane);
+      for (int s = 0; s < 4; s++) { asm volatile("" : "=v"(af[s])); asm volatile("" : "=v"(bfr[s])); }
 #pragma unroll
-    for (int s = 0; s < NT_; s++) frag2_issue<MB>(bfr[s], blo[s], bhi[s], sb, wn * NT_ * 16, s, lane);
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NT_; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+      return;
+    }
+    fa.template read<STG * STAGE_BYTES, 0>(af[0], alo[0], ahi[0]);
+    fa.template read<STG * STAGE_BYTES, 1>(af[1], alo[1], ahi[1]);
+    fa.template read<STG * STAGE_BYTES, 2>(af[2], alo[2], ahi[2]);
+    fa.template read<STG * STAGE_BYTES, 3>(af[3], alo[3], ahi[3]);
+    fb.template read<STG * STAGE_BYTES + OP_BYTES, 0>(bfr[0], blo[0], bhi[0]);
+    fb.template read<STG * STAGE_BYTES + OP_BYTES, 1>(bfr[1], blo[1], bhi[1]);
+    if (NT_ == 4) {
+      fb.template read<STG * STAGE_BYTES + OP_BYTES, 2>(bfr[2], blo[2], bhi[2]);
+      fb.template read<STG * STAGE_BYTES + OP_BYTES, 3>(bfr[3], blo[3], bhi[3]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (MA == 1) {
@@ -323,6 +383,12 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < NT_; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+  };
+  static_assert(NST == 3, "the k-loop below is unrolled for a 3-slot ring");
+  for (int t = 0; t < nt; t += 3) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
   }
   // ---- epilogue: the fp32 C tile goes through LDS in 64-row halves (keeps the footprint at 48 KiB)
   float* Cs = reinterpret_cast<float*>(smem);
@@ -537,10 +603,12 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM_LDS, st, p, epi);
   } else {
     bool small = false;
-    if constexpr (MA == 0 && MB == 1) {
-      // dgrad into the residual width (N = dim): fewer than ~1.5 workgroups per CU with 128-row tiles -> halve the
-      // tile height (64x128) to fill the chip (measured +11 % on the dim-512 dgrads; NT forward GEMMs lose 10 %)
-      small = (long)p.tiles_m * tiles_n * splits < 384;
+    if constexpr (MA == 0) {
+      // N = dim GEMMs (out-proj, ff-out, dgrads into the residual width): fewer than ~1.5 workgroups per CU with
+      // 128-row tiles -> halve the tile height (64x128) to fill the chip.  VBX_GEMM_BM64=0/1 forces it (A/B runs).
+      static const char* force = getenv("VBX_GEMM_BM64");
+      // measured (same run): NN dgrads 410 -> 500 TF, NT out-proj (K=1024) +8 %, NT ff-out (K=1408) -5 %
+      small = force ? (atoi(force) != 0) : ((long)p.tiles_m * tiles_n * splits < 384 && (MB == 1 || p.K <= 1024));
       if (small) {
         static bool attr64 = false;
         auto kern64 = gemm_kernel_v2<MA, MB, Epi, F16, 64>;
@@ -585,6 +653,8 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   p.A = (const u16*)d->A; p.B = (const u16*)d->B;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
   p.kchunk = d->K; p.tiles_m = cdiv(d->M, BM);
+  static const int abl = getenv("VBX_GEMM_ABL") ? atoi(getenv("VBX_GEMM_ABL")) : 0;
+  p.abl = abl;
   if (d->mode == VBX_GEMM_NT) VBX_REQUIRE(d->K % 8 == 0, "vbx_gemm NT: K must be a multiple of 8");
   if (d->mode == VBX_GEMM_TN) VBX_REQUIRE(d->M % 8 == 0, "vbx_gemm TN: M must be a multiple of 8");
 
