@@ -11,6 +11,7 @@
 // and the P^T accumulator registers are already the B operand of the next MFMA (slot s of half hi <->
 // key (s&3) + 8*(s>>2) + 4*hi inside each 16-key group; the V^T fragment uses the same key order).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -78,13 +79,30 @@ VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
   return r;
 }
 
+VBX_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// P^T (or dS^T) accumulator registers 8*t2 .. 8*t2+7 -> fp16 MFMA operand; v_cvt_pkrtz packs two conversions per
+// instruction (round toward zero: a 2^-12 relative bias on softmax weights that sum to 1 -- far below the fp16 noise)
+VBX_DEV f16x8 pack_frag_f16_fast(const f32x16& p, int t2) {
+  typedef __attribute__((ext_vector_type(2))) __fp16 h2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const h2 a = __builtin_amdgcn_cvt_pkrtz(p[8 * t2 + 0], p[8 * t2 + 1]);
+  const h2 b = __builtin_amdgcn_cvt_pkrtz(p[8 * t2 + 2], p[8 * t2 + 3]);
+  const h2 c = __builtin_amdgcn_cvt_pkrtz(p[8 * t2 + 4], p[8 * t2 + 5]);
+  const h2 d = __builtin_amdgcn_cvt_pkrtz(p[8 * t2 + 6], p[8 * t2 + 7]);
+  const u32x4 w = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                   __builtin_bit_cast(unsigned, d)};
+  return __builtin_bit_cast(f16x8, w);
+}
+
 VBX_DEV int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
 
 // ============================================================================ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                           const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                           u16* __restrict__ out, u16* __restrict__ outb,
-                                                          float* __restrict__ lse, int H, int Np, float scale2) {
+                                                          float* __restrict__ lse, int H, int Np, float scale2, int abl) {
+  // abl: timing ablations (tools only, results wrong): 1 no K/V staging after tile 0, 2 no softmax math, 4 no P.V, 8 no Q.K
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
     const char* Kt = smem + (kt & 1) * 2 * TILE16;
     const char* Vt = Kt + TILE16;
     const bool more = kt + 1 < ntiles;
-    if (more) {
+    if (more && !(abl & 1)) {
       tile_g2r(sk, kbase, 64, (kt + 1) * 64, Np, false, tid);
       tile_g2r(sv, vbase, 64, (kt + 1) * 64, Np, false, tid);
     }
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
       for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[kb][i] = 0.f;
-        if (kb < nblk) {
+        if (kb < nblk && !(abl & 8)) {
 #pragma unroll
           for (int t = 0; t < 4; t++)
             s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Kt, kb, t, lane), qf[t], s[kb], 0, 0, 0);
@@ -148,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
             if (!ok) s[kb][r] = NEG_INF;
           }
       }
+      if (!(abl & 2)) {
       float mx = NEG_INF;
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
@@ -156,13 +175,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx * scale2);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_use);
+      const float alpha = fast_exp2(m_run - m_use);
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const float p = exp2f(fmaf(s[kb][r], scale2, -m_use));
+          const float p = fast_exp2(fmaf(s[kb][r], scale2, -m_use));
           s[kb][r] = p;
           psum += p;
         }
@@ -170,12 +189,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
       m_run = m_new;
 #pragma unroll
       for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; kb++) {
-        if (kb < nblk) {
+        if (kb < nblk && !(abl & 4)) {
 #pragma unroll
           for (int t2 = 0; t2 < 2; t2++) {
-            const f16x8 pf = pack_frag_f16(s[kb], t2);
+            const f16x8 pf = pack_frag_f16_fast(s[kb], t2);
 #pragma unroll
             for (int db = 0; db < 2; db++)
               o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
         }
       }
     }
-    if (more) {
+    if (more && !(abl & 1)) {
       char* Kn = smem + ((kt + 1) & 1) * 2 * TILE16;
       tile_r2s(sk, Kn, tid);
       tile_r2s(sv, Kn + TILE16, tid);
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<bf16x8>(Vt, kb, t, lane), dof[t], dp, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            float p = exp2f(fmaf(s[r], scale2, -L2));
+            float p = fast_exp2(fmaf(s[r], scale2, -L2));
             if (need_mask) {
               const int kg = k0 + kb * 32 + acc_row(r, hi);
               bool ok = kg < Np;
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int r = 4 * g4 + j;
-              float p = exp2f(fmaf(s[r], scale2, -lv[j]));
+              float p = fast_exp2(fmaf(s[r], scale2, -lv[j]));
               if (!kvalid) p = 0.f;
               s[r] = p;
               dp[r] = p * (dp[r] - dv4[j]);
@@ -503,8 +523,9 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
   dim3 grid(cdiv(Np, 128), H, B);
+  static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                     (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E);
+                     (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl);
   VBX_LAUNCH_CHECK();
   return 0;
 }
