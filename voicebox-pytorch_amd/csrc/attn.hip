@@ -212,22 +212,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
     __syncthreads();
   }
 
+  // ---- epilogue.  O^T sits in registers as (lane = query, 4 consecutive d per register group): storing that
+  // directly is 16 8-byte stores per lane to 128-byte-strided rows -- store-ISSUE bound (27 us of the 83 us kernel were
+  // fixed cost).  Stage each wave's 32x64 tile through LDS ([q][d], 16-byte chunks XOR-swizzled by q&7) and write
+  // whole 128-byte rows with 16-byte stores: 4 per lane per output, fully coalesced.
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (active && hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
+  char* ost = smem + wave * 8192;  // 32 rows x 128 B fp16 | 32 rows x 128 B bf16 (the K/V ring is dead after the loop's last barrier)
   if (active) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-    if (q < Np) {
-      const long ro = ((long)b * Np + q) * (H * 64) + h * 64;
+    const int ql = lane & 31;
 #pragma unroll
-      for (int db = 0; db < 2; db++)
+    for (int db = 0; db < 2; db++)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-          const int d = db * 32 + 8 * g4 + 4 * hi;
-          const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
-                      v3 = o[db][4 * g4 + 3] * inv;
-          *reinterpret_cast<uint2*>(out + ro + d) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
-          if (outb) *reinterpret_cast<uint2*>(outb + ro + d) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-        }
-      if (hi == 0) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
+                    v3 = o[db][4 * g4 + 3] * inv;
+        const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
+        *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
+        if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (active) {
+    // wave-private staging: only this wave's lanes touch ost, the DS queue is in order -> no block barrier needed
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int qq = q0 + row;
+      if (qq < Np) {
+        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+        const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
+        *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
+        if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
+      }
     }
   }
 }

@@ -12,6 +12,7 @@
 // prediction by ~5%; fp16 (2^-11) costs the same MFMA rate and brings that to ~1%.  Every BACKWARD GEMM operand
 // is bf16 (gradients need the exponent range), so in training each saved activation also has a bf16 copy.
 #include "common.hpp"
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -99,7 +100,8 @@ struct Acts {
 
 int wgrad_splits(long I, long J, long K) {
   const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
-  long s = (768 + tiles - 1) / tiles;
+  static const long target = getenv("VBX_WGRAD_TARGET") ? atol(getenv("VBX_WGRAD_TARGET")) : 384;  // 384 measured best (768: +0.35 ms of slab traffic per step)  // workgroups wanted
+  long s = (target + tiles - 1) / tiles;
   const long smax = (K + 511) / 512;
   if (s > smax) s = smax;
   if (s > 16) s = 16;
