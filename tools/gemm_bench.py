@@ -86,3 +86,23 @@ if __name__ == "__main__":
         qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
         sec = timeit(lambda: L.call("vbx_attn_bwd", q, k, qb, kb, vb, None, out, 1, do, lse, delta, dq, dk, dv, H * 64, B, H, Np, 10.0, st))
         print(f"attn bwd  {sec*1e6:8.1f} us  {2.5*fl/sec/1e12:7.1f} TF/s (algorithmic 2.5x fwd)")
+
+
+def gemm_padded(M, N, K, pad, name=""):
+    """NT fp16 GEMM with row strides K+pad (channel-conflict experiment)."""
+    A = torch.randn(M, K + pad, device=dev).half()
+    B = torch.randn(N, K + pad, device=dev).half()
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    d = L.GemmDesc()
+    d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb = L.VBX_GEMM_NT, L.VBX_EPI_BF16, M, N, K, K + pad, K + pad
+    d.A, d.B, d.f16, d.C, d.ldc = A.data_ptr(), B.data_ptr(), 1, C.data_ptr(), N
+    sec = timeit(lambda: lib.vbx_gemm(d, st))
+    tf = 2.0 * M * N * K / sec / 1e12
+    print(f"{name:28s} M={M:5d} N={N:5d} K={K:5d} pad={pad:3d} {sec*1e6:8.1f} us  {tf:7.1f} TF/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pad":
+    for pad in (0, 8, 32, 64, 72, 0):
+        gemm_padded(8320, 3072, 512, pad, "NT bf16-out qkv shape")
+    for pad in (0, 64, 72):
+        gemm_padded(8192, 8192, 8192, pad, "NT bf16-out 8192^3")
