@@ -97,6 +97,30 @@ VBX_DEV f16x8 pack_frag_f16_fast(const f32x16& p, int t2) {
 
 VBX_DEV int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
 
+// Epilogue helper for the backward kernels: a wave's two f32x16 accumulators hold X^T[d][row] (lane = row, 4 consecutive d
+// per register group).  Stage them as row-major [32 rows][64 fp32] in the wave's private LDS area (16-byte chunks XOR-
+// swizzled by row&15) and write each 256-byte row with coalesced 16-byte stores: 8 stores per lane instead of 16 scattered.
+VBX_DEV void store_rows_f32(char* wst, const f32x16 (&acc)[2], float scale, float* __restrict__ gbase, int row0, int row_lim,
+                            int lane) {
+  const int rl = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int c = (db * 32 + 8 * g4 + 4 * hi) >> 2;
+      *reinterpret_cast<float4*>(wst + rl * 256 + ((c ^ (rl & 15)) << 4)) =
+          make_float4(acc[db][4 * g4] * scale, acc[db][4 * g4 + 1] * scale, acc[db][4 * g4 + 2] * scale, acc[db][4 * g4 + 3] * scale);
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int row = it * 4 + (lane >> 4), ch = lane & 15;
+    if (row0 + row < row_lim)
+      *reinterpret_cast<float4*>(gbase + (long)(row0 + row) * 64 + ch * 4) =
+          *reinterpret_cast<const float4*>(wst + row * 256 + ((ch ^ (row & 15)) << 4));
+  }
+}
+
 // ============================================================================ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                           const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
@@ -382,17 +406,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
     __syncthreads();
   }
 
-  if (active && q < Np) {
-    float* drow = dq + (bh * Np + q) * 64;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int d = db * 32 + 8 * g4 + 4 * hi;
-        *reinterpret_cast<float4*>(drow + d) = make_float4(acc[db][4 * g4] * scale, acc[db][4 * g4 + 1] * scale,
-                                                           acc[db][4 * g4 + 2] * scale, acc[db][4 * g4 + 3] * scale);
-      }
-  }
+  // the tile ring is dead after the loop's last barrier: each wave stages its 32x64 fp32 block in its own 8 KiB
+  if (active) store_rows_f32(smem + wave * 8192, acc, scale, dq + bh * Np * 64, q0, Np, lane);
 }
 
 // ============================================================================ backward: dk, dv
@@ -515,21 +530,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
     __syncthreads();
   }
 
-  if (active && key < Np) {
-    float* krow = dk + (bh * Np + key) * 64;
-    u16* vrow = dv + ((long)b * Np + key) * dv_ld + h * 64;
+  if (active) {
+    char* wst = smem + wave * 12288;  // 8 KiB fp32 dk block | 4 KiB bf16 dv block (ring is dead after the last barrier)
+    store_rows_f32(wst, adk, scale, dk + bh * Np * 64, key0, Np, lane);
+    char* vst = wst + 8192;
+    const int kl = lane & 31;
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         const int d = db * 32 + 8 * g4 + 4 * hi;
-        *reinterpret_cast<float4*>(krow + d) = make_float4(adk[db][4 * g4] * scale, adk[db][4 * g4 + 1] * scale,
-                                                           adk[db][4 * g4 + 2] * scale, adk[db][4 * g4 + 3] * scale);
-        uint2 pk;
-        pk.x = pack_bf16x2(adv[db][4 * g4 + 0], adv[db][4 * g4 + 1]);
-        pk.y = pack_bf16x2(adv[db][4 * g4 + 2], adv[db][4 * g4 + 3]);
-        *reinterpret_cast<uint2*>(vrow + d) = pk;
+        *reinterpret_cast<uint2*>(vst + kl * 128 + (((d >> 3) ^ (kl & 7)) << 4) + (d & 7) * 2) =
+            make_uint2(pack_bf16x2(adv[db][4 * g4 + 0], adv[db][4 * g4 + 1]), pack_bf16x2(adv[db][4 * g4 + 2], adv[db][4 * g4 + 3]));
       }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      if (key0 + row < Np)
+        *reinterpret_cast<uint4*>(dv + ((long)b * Np + key0 + row) * dv_ld + h * 64 + ch * 8) =
+            *reinterpret_cast<const uint4*>(vst + row * 128 + ((ch ^ (row & 7)) << 4));
+    }
   }
 }
 
@@ -554,7 +575,7 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
                             float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
                             void* stream) {
   VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
-  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 4 == 0, "vbx_attn_bwd: bad dims");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {

@@ -56,12 +56,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // u = x/|x| ; y = sqrt(D) u*gamma + beta
 // dgamma[b] += sqrt(D) u*dy ; dbeta[b] += dy ; du = sqrt(D) gamma*dy ; dx = (du - u (u.du)) / |x|
 // grid (chunks, B); each block handles 16 rows of one batch; partials -> part[b][chunk][2][D]
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+constexpr int NB_WAVES = 8;  // waves per block of the backward kernel (16-row chunk -> 2 rows per wave)
+__global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            long gb_stride, const u16* __restrict__ dy,
                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out,
                                                            u16* __restrict__ dxb, float* __restrict__ part, int Np, int n0,
                                                            int rpb, int D) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NB_WAVES][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
   const int D4 = D >> 2;
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   float4 ag[MAXC], ab[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
-  for (int k = 0; k < 4; k++) {
-    const int j = chunk * 16 + wave + 4 * k;
+  for (int k = 0; k < 16 / NB_WAVES; k++) {
+    const int j = chunk * 16 + wave + NB_WAVES * k;
     if (j >= rpb) break;
     const long xrow = ((long)b * Np + n0 + j) * D;
     const long drow = ((long)b * rpb + j) * D;
@@ -139,11 +140,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
   __syncthreads();
   float4* p4 = reinterpret_cast<float4*>(part + ((long)b * chunks + chunk) * 2 * D);
-  for (int idx = threadIdx.x; idx < 2 * D4; idx += 256) {
+  for (int idx = threadIdx.x; idx < 2 * D4; idx += 64 * NB_WAVES) {
     const int which = idx / D4, c = idx - which * D4;
     float4 s = r4[(0 * 2 + which) * D4 + c];
 #pragma unroll
-    for (int w = 1; w < 4; w++) {
+    for (int w = 1; w < NB_WAVES; w++) {
       const float4 t = r4[(w * 2 + which) * D4 + c];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -298,7 +299,15 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_bwd: bad row range");
   dim3 grid(cdiv(rows_per_batch, 16), B);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 4 * 2 * D * sizeof(float), (hipStream_t)stream, x, gamma,
+  const size_t lds = (size_t)NB_WAVES * 2 * D * sizeof(float);
+  if (lds > 48 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(64 * NB_WAVES), lds, (hipStream_t)stream, x, gamma,
                      gb_stride, (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, Np, n0, rows_per_batch, D);
   VBX_LAUNCH_CHECK();
   return 0;
