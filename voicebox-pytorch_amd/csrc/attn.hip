@@ -12,6 +12,7 @@
 // key (s&3) + 8*(s>>2) + 4*hi inside each 16-key group; the V^T fragment uses the same key order).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -261,6 +262,228 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
   __builtin_amdgcn_wave_barrier();
   if (active) {
     // wave-private staging: only this wave's lanes touch ost, the DS queue is in order -> no block barrier needed
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int qq = q0 + row;
+      if (qq < Np) {
+        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+        const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
+        *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
+        if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
+      }
+    }
+  }
+}
+
+
+// ============================================================================ forward, v2: LDS-DMA ring
+// K|V tiles (16 KiB per 64 keys) arrive by global_load_lds into a 3-slot ring (48 KiB -> 3 workgroups per CU) with two
+// tiles in flight while one is consumed; no staging registers, one raw barrier per tile.  The DMA image is lane-linear,
+// so the 16-byte XOR swizzle is applied to the per-lane SOURCE address (slot s holds logical chunk (s&7)^(row&7)).
+// Fragment reads are inline asm (a compiler-visible ds_read would make hipcc drain vmcnt(0) while DMAs are in flight)
+// with the ring slot / key block folded into the DS immediate.
+constexpr int ANST = 3;
+constexpr int ASTAGE = 2 * TILE16;
+
+VBX_DEV unsigned lds_addr32(const char* p) { return (unsigned)(size_t)LDS_PTR(char, p); }
+
+VBX_DEV void dma_tile(char* dst, const u16* __restrict__ base, int row0, int row_lim, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int s = i * 256 + tid;
+    const int row = s >> 3, c = (s & 7) ^ (row & 7);
+    const int gr = min(row0 + row, row_lim - 1);  // rows past the end re-read the last row (masked / never stored)
+    const u16* src = base + (long)gr * 64 + c * 8;
+    char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
+  }
+}
+
+template <int OFF>
+VBX_DEV f16x8 asm_read_b128(unsigned a) {
+  f16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF) : "memory");
+  return r;
+}
+template <int OFF>
+VBX_DEV void asm_read_tr(s16x4& lo, s16x4& hi, unsigned a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "i"(OFF + 1024) : "memory");
+}
+
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                             const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                             u16* __restrict__ out, u16* __restrict__ outb,
+                                                             float* __restrict__ lse, int H, int Np, float scale2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * H + h;
+  const u16* kbase = k16 + bh * Np * 64;
+  const u16* vbase = vv + bh * Np * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < Np;
+  const int q = q0 + (lane & 31);
+  const int qc = min(q, Np - 1);
+  const int ntiles = (Np + 63) / 64;
+
+#pragma unroll
+  for (int s = 0; s < ANST - 1; s++)
+    if (s < ntiles) {
+      dma_tile(smem + s * ASTAGE, kbase, s * 64, Np, tid);
+      dma_tile(smem + s * ASTAGE + TILE16, vbase, s * 64, Np, tid);
+    }
+
+  f16x8 qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+
+  // lane-constant LDS addresses (slot 0, key block 0): K rows for the four d-steps; V transpose reads for the two d-halves
+  unsigned ka[4], va[2];
+  {
+    const int row = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + row * 128 + (((2 * t + hi) ^ (row & 7)) << 4));
+    const int G = lane >> 4, a16 = lane & 15;
+    const int vrow = 4 * (G >> 1) + (a16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; db++) {
+      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
+      va[db] = lds_addr32(smem + TILE16 + vrow * 128 + (((d >> 3) ^ (vrow & 7)) << 4) + (d & 7) * 2);
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  auto step = [&](auto stg_c, int kt) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int NXT = (STG + ANST - 1) % ANST;
+    constexpr int SO = STG * ASTAGE;
+    if (ntiles - 1 - kt >= ANST - 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + ANST - 1 < ntiles) {
+      dma_tile(smem + NXT * ASTAGE, kbase, (kt + ANST - 1) * 64, Np, tid);
+      dma_tile(smem + NXT * ASTAGE + TILE16, vbase, (kt + ANST - 1) * 64, Np, tid);
+    }
+    if (!active) return;
+    const int k0 = kt * 64;
+    const bool two = (Np - k0 > 32);  // the tail tile may hold <= 32 valid keys
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { s[0][i] = 0.f; s[1][i] = 0.f; }
+    {
+      f16x8 kf0[4], kf1[4];
+      kf0[0] = asm_read_b128<SO>(ka[0]); kf0[1] = asm_read_b128<SO>(ka[1]);
+      kf0[2] = asm_read_b128<SO>(ka[2]); kf0[3] = asm_read_b128<SO>(ka[3]);
+      kf1[0] = asm_read_b128<SO + 4096>(ka[0]); kf1[1] = asm_read_b128<SO + 4096>(ka[1]);
+      kf1[2] = asm_read_b128<SO + 4096>(ka[2]); kf1[3] = asm_read_b128<SO + 4096>(ka[3]);
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 4; t++) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[t], qf[t], s[0], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (two) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[t], qf[t], s[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int kg = k0 + kb * 32 + acc_row(r, hi);
+          bool ok = kg < Np;
+          if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
+          if (!ok) s[kb][r] = NEG_INF;
+        }
+    }
+    float mx = NEG_INF;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale2);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run - m_use);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = fast_exp2(fmaf(s[kb][r], scale2, -m_use));
+        s[kb][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    // O^T += V^T . P^T : per 32-key block, 2 sixteen-key groups x 2 d-halves
+#define VBX_PV(KB)                                                                                     \
+    {                                                                                                  \
+      s16x4 l00, h00, l01, h01, l10, h10, l11, h11;                                                    \
+      asm_read_tr<SO + TILE16 * 0 + KB * 4096>(l00, h00, va[0]);                                      \
+      asm_read_tr<SO + TILE16 * 0 + KB * 4096>(l01, h01, va[1]);                                      \
+      asm_read_tr<SO + TILE16 * 0 + KB * 4096 + 2048>(l10, h10, va[0]);                               \
+      asm_read_tr<SO + TILE16 * 0 + KB * 4096 + 2048>(l11, h11, va[1]);                               \
+      const f16x8 p0 = pack_frag_f16_fast(s[KB], 0), p1 = pack_frag_f16_fast(s[KB], 1);                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      const s16x8 v00 = {l00[0], l00[1], l00[2], l00[3], h00[0], h00[1], h00[2], h00[3]};              \
+      const s16x8 v01 = {l01[0], l01[1], l01[2], l01[3], h01[0], h01[1], h01[2], h01[3]};              \
+      const s16x8 v10 = {l10[0], l10[1], l10[2], l10[3], h10[0], h10[1], h10[2], h10[3]};              \
+      const s16x8 v11 = {l11[0], l11[1], l11[2], l11[3], h11[0], h11[1], h11[2], h11[3]};              \
+      __builtin_amdgcn_s_setprio(1);                                                                   \
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v00), p0, o[0], 0, 0, 0); \
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v01), p0, o[1], 0, 0, 0); \
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v10), p1, o[0], 0, 0, 0); \
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v11), p1, o[1], 0, 0, 0); \
+      __builtin_amdgcn_s_setprio(0);                                                                   \
+    }
+    VBX_PV(0)
+    if (two) VBX_PV(1)
+#undef VBX_PV
+  };
+  for (int kt = 0; kt < ntiles; kt += 3) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, kt + 1);
+    if (kt + 2 < ntiles) step(std::integral_constant<int, 2>{}, kt + 2);
+  }
+  __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (active && hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
+  char* ost = smem + wave * 8192;
+  if (active) {
+    const int ql = lane & 31;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
+                    v3 = o[db][4 * g4 + 3] * inv;
+        const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
+        *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
+        if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (active) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
@@ -564,8 +787,13 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
   dim3 grid(cdiv(Np, 128), H, B);
   static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                     (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl);
+  static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
+  if (legacy || abl)
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
+                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,
+                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E);
   VBX_LAUNCH_CHECK();
   return 0;
 }
