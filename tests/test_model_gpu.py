@@ -241,3 +241,24 @@ def test_attend_module_matches_reference_math():
     assert rel(out, ref) < 2e-3
     out.sum().backward()
     assert qd.grad is not None and kd.grad.shape == k.shape and vd.grad.shape == v.shape
+
+
+def test_dim1024_config3_shape_vs_oracle():
+    """BASELINE config 3 architecture (dim 1024, heads 16, ff inner 2730 -> padded 2752) at depth 2 / small batch:
+    loss parity with the CPU oracle (the full depth-12 B=8 shape is exercised by bench.py --dim 1024)."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    cfg = restate.Cfg(dim=1024, depth=2, heads=16, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=2)
+    vbx, vb, wrapper = build(dict(dim=1024, depth=2, heads=16), state)
+    B, N = 1, 200
+    gen = torch.Generator().manual_seed(21)
+    x1, x0 = torch.randn(B, N, 1024, generator=gen), torch.randn(B, N, 1024, generator=gen)
+    times, frac, rand = torch.rand(B, generator=gen), 0.7 + 0.3 * torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    with torch.no_grad():
+        ref = restate.cfm_loss(state, cfg, x1, x0, times, frac, rand)
+    with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
+        loss = wrapper(x1.to(dev))
+    assert abs(float(loss) - float(ref)) < 1e-3, (float(loss), float(ref))
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None)

@@ -309,6 +309,66 @@ __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict_
     }
   }
 }
+
+// adaLN projections as a register-level MFMA "GEMV": ada[b][j] = bias[j] + temb[b,:] . W[j,:]   (B <= 16, W fp16 [J,Th])
+// One wave owns 16 outputs j and streams their weight rows straight from HBM into MFMA B fragments (k contiguous: no
+// LDS); temb (fp32, L2 resident) becomes the A fragment as an fp16 hi + lo pair (two MFMAs) so the time conditioning keeps
+// ~22 mantissa bits.  Weight-streaming bound: 100 MB at dim 512 / depth 12.
+__global__ __launch_bounds__(256) void adaln_fwd_mfma_kernel(const float* __restrict__ temb, const u16* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ ada, int B,
+                                                             int Th, int J, int group) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = (blockIdx.x * 4 + wave) * 16;
+  if (j0 >= J) return;
+  const int jr = min(j0 + (lane & 15), J - 1), kq = (lane >> 4) * 8, bi = lane & 15;
+  const u16* wrow = w + (long)jr * Th + kq;
+  const float* trow = temb + (long)min(bi, B - 1) * Th + kq;
+  const bool bval = bi < B;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;  // k-steps (32 wide) kept in flight
+  for (int k0 = 0; k0 < Th; k0 += 32 * U) {
+    uint4 wf[U];
+    float4 t0[U], t1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + 32 * u;
+      if (k < Th) {
+        wf[u] = *reinterpret_cast<const uint4*>(wrow + k);
+        t0[u] = *reinterpret_cast<const float4*>(trow + k);
+        t1[u] = *reinterpret_cast<const float4*>(trow + k + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + 32 * u;
+      if (k < Th) {
+        const float tv[8] = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y, t1[u].z, t1[u].w};
+        f16x8 ahi, alo;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float x = bval ? tv[i] : 0.f;
+          const _Float16 h = (_Float16)x;
+          ahi[i] = h;
+          alo[i] = (_Float16)(x - (float)h);
+        }
+        const f16x8 bf = __builtin_bit_cast(f16x8, wf[u]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bf, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bf, acc, 0, 0, 0);
+      }
+    }
+  }
+  // C layout: col j = lane&15, row b = (lane>>4)*4 + r
+  const int j = j0 + (lane & 15);
+  if (j < J) {
+    const float bj = bias[j];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int b = (lane >> 4) * 4 + r;
+      if (b < B) ada[((long)(j / group) * B + b) * group + (j % group)] = acc[r] + bj;
+    }
+  }
+}
+
 // dW[j][t] = sum_b dada[b][j] temb[b][t] ; dbias[j] = sum_b dada[b][j]
 __global__ void adaln_bwd_w_kernel(const float* __restrict__ temb, const float* __restrict__ dada, float* __restrict__ dw,
                                    float* __restrict__ dbias, int B, int Th, int J) {
@@ -778,6 +838,12 @@ extern "C" int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const f
   VBX_REQUIRE(temb && w_bf16 && bias && ada && Th % 8 == 0, "vbx_adaln_proj_fwd: bad args");
   if (group <= 0) group = J;
   VBX_REQUIRE(J % group == 0, "vbx_adaln_proj_fwd: J must be a multiple of group");
+  if (B <= 16 && Th % 32 == 0) {  // the usual case: MFMA weight-streaming kernel
+    hipLaunchKernelGGL(adaln_fwd_mfma_kernel, dim3(cdiv(J, 64)), dim3(256), 0, ST, temb, (const u16*)w_bf16, bias, ada, B, Th, J,
+                       group);
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   int bc = B < 8 ? B : 8;
   while ((size_t)bc * Th * sizeof(float) > 128 * 1024 && bc > 1) bc >>= 1;
   const int lds = bc * Th * (int)sizeof(float);
