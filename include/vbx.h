@@ -103,8 +103,9 @@ int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long 
  * part[b][chunk][2][D] (chunk count = ceil(rows_per_batch/16)).  dy is dense bf16 [B*rows, D].
  * dx tensors have the same (Np, n0) row addressing as x.  dxb: optional bf16 copy of dx_out (same addressing). */
 int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
-                    float* dx_out, void* dxb_bf16, float* part, int B, int Np, int n0, int rows_per_batch, int D,
-                    void* stream);
+                    float* dx_out, void* dxb_bf16, float* part,
+                    float* colpart /* optional [B][chunks][D]: per-chunk column sums of dx_in (a fused bias gradient) */,
+                    int B, int Np, int n0, int rows_per_batch, int D, void* stream);
 
 /* ------------------------------------------------------------------ attention */
 /* Attend.forward math path (attend.py:121-135): softmax(scale * q k^T + key-pad mask) v, fused
@@ -162,6 +163,8 @@ int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J);
 /* reduce rmsnorm_bwd partials over chunks: out[b][2][D] = sum_chunk part[b][chunk][2][D] */
 int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D, int sum_batch,
                              void* stream);
+/* out[d] = sum_{b,chunk} colpart[b][chunk][d]  (the fused column sums of vbx_rmsnorm_bwd) */
+int vbx_reduce_col_partials(const float* colpart, float* out, int B, int chunks, int D, void* stream);
 /* GEGLU backward on the interleaved pre-activation (voicebox_pytorch.py:338-340) */
 int vbx_geglu_bwd(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, void* stream);
 /* column sums: out[c] (+)= sum_r in[r][c]   (bias grads) ; rowmap as in vbx_splitk_reduce */

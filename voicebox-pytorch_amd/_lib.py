@@ -32,7 +32,7 @@ _PROTOS = {
     "vbx_gemm": [C.POINTER(GemmDesc), P],
     "vbx_splitk_reduce": [P, I, I, I, P, I, I, I, I, I, I, P],
     "vbx_rmsnorm_fwd": [P, P, P, L, P, P, I, I, I, I, I, P],
-    "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, I, I, I, I, I, P],
+    "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_attn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
     "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P],
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
@@ -50,6 +50,7 @@ _PROTOS = {
     "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd_scratch_floats": [I, I, I],
     "vbx_reduce_norm_partials": [P, P, L, I, I, I, I, P],
+    "vbx_reduce_col_partials": [P, P, I, I, I, P],
     "vbx_geglu_bwd": [P, P, P, I, I, P],
     "vbx_colsum_bf16": [P, I, I, I, P, I, I, I, P, P],
     "vbx_colsum_f32": [P, I, I, I, P, P, P],

@@ -60,17 +60,19 @@ constexpr int NB_WAVES = 8;  // waves per block of the backward kernel (16-row c
 __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            long gb_stride, const u16* __restrict__ dy,
                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out,
-                                                           u16* __restrict__ dxb, float* __restrict__ part, int Np, int n0,
-                                                           int rpb, int D) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [NB_WAVES][2][D]
+                                                           u16* __restrict__ dxb, float* __restrict__ part,
+                                                           float* __restrict__ cpart, int Np, int n0, int rpb, int D) {
+  // cpart (optional): per-chunk column sums of dx_in, [b][chunk][D] -- the bias gradient of the Linear whose output was
+  // added to the residual stream right after this norm's input (FeedForward[3].bias, voicebox_pytorch.py:348,472)
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NB_WAVES][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
   const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
-  float4 ag[MAXC], ab[MAXC];
+  float4 ag[MAXC], ab[MAXC], ac[MAXC];
 #pragma unroll
-  for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0); }
   for (int k = 0; k < 16 / NB_WAVES; k++) {
     const int j = chunk * 16 + wave + NB_WAVES * k;
     if (j >= rpb) break;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
         if (din) {
           const float4 a = din[c];
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+          ac[i].x += a.x; ac[i].y += a.y; ac[i].z += a.z; ac[i].w += a.w;
         }
         dout[c] = o;
         if (dbo) dbo[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
@@ -134,44 +137,49 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
   for (int i = 0; i < MAXC; i++) {
     const int c = lane + 64 * i;
     if (c < D4) {
-      r4[(wave * 2 + 0) * D4 + c] = ag[i];
-      r4[(wave * 2 + 1) * D4 + c] = ab[i];
+      r4[(wave * 3 + 0) * D4 + c] = ag[i];
+      r4[(wave * 3 + 1) * D4 + c] = ab[i];
+      r4[(wave * 3 + 2) * D4 + c] = ac[i];
     }
   }
   __syncthreads();
   float4* p4 = reinterpret_cast<float4*>(part + ((long)b * chunks + chunk) * 2 * D);
-  for (int idx = threadIdx.x; idx < 2 * D4; idx += 64 * NB_WAVES) {
+  float4* c4 = cpart ? reinterpret_cast<float4*>(cpart + ((long)b * chunks + chunk) * D) : nullptr;
+  for (int idx = threadIdx.x; idx < 3 * D4; idx += 64 * NB_WAVES) {
     const int which = idx / D4, c = idx - which * D4;
-    float4 s = r4[(0 * 2 + which) * D4 + c];
+    if (which == 2 && !c4) continue;
+    float4 s = r4[(0 * 3 + which) * D4 + c];
 #pragma unroll
     for (int w = 1; w < NB_WAVES; w++) {
-      const float4 t = r4[(w * 2 + which) * D4 + c];
+      const float4 t = r4[(w * 3 + which) * D4 + c];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    p4[which * D4 + c] = s;
+    if (which < 2) p4[which * D4 + c] = s;
+    else c4[c] = s;
   }
 }
 
 // out[b][which][d] = sum_chunk part[b][chunk][which][d]   (optionally also summed over b)
 // block = 64 idx x 4 chunk lanes; grid (2D/64, sum_batch ? 1 : B)
 __global__ __launch_bounds__(256) void reduce_norm_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                    long out_b_stride, int B, int chunks, int D, int sum_batch) {
+                                                                    long out_b_stride, int B, int chunks, int W, int sum_batch) {
+  // W = row width of the partial records (2*D for gamma|beta records, D for column-sum records)
   __shared__ float red[4][64];
   const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + il;
   float s = 0.f;
-  if (idx < 2 * D) {
+  if (idx < W) {
     if (sum_batch) {
       const long total = (long)B * chunks;
-      for (long c = cl; c < total; c += 4) s += part[c * 2 * D + idx];
+      for (long c = cl; c < total; c += 4) s += part[c * W + idx];
     } else {
       const int b = blockIdx.y;
-      for (int c = cl; c < chunks; c += 4) s += part[((long)b * chunks + c) * 2 * D + idx];
+      for (int c = cl; c < chunks; c += 4) s += part[((long)b * chunks + c) * W + idx];
     }
   }
   red[cl][il] = s;
   __syncthreads();
-  if (cl == 0 && idx < 2 * D) {
+  if (cl == 0 && idx < W) {
     const float t = red[0][il] + red[1][il] + red[2][il] + red[3][il];
     if (sum_batch) out[idx] = t;
     else out[(long)blockIdx.y * out_b_stride + idx] = t;
@@ -293,22 +301,23 @@ extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* 
 }
 
 extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
-                               float* dx_out, void* dxb_bf16, float* part, int B, int Np, int n0, int rows_per_batch, int D,
-                               void* stream) {
+                               float* dx_out, void* dxb_bf16, float* part, float* colpart, int B, int Np, int n0,
+                               int rows_per_batch, int D, void* stream) {
   VBX_REQUIRE(x && gamma && dy_bf16 && dx_out && part, "vbx_rmsnorm_bwd: null pointer");
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_bwd: bad row range");
   dim3 grid(cdiv(rows_per_batch, 16), B);
-  const size_t lds = (size_t)NB_WAVES * 2 * D * sizeof(float);
+  VBX_REQUIRE(!colpart || dx_in, "vbx_rmsnorm_bwd: column sums need dx_in");
+  const size_t lds = (size_t)NB_WAVES * 3 * D * sizeof(float);
   if (lds > 48 * 1024) {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
   }
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(64 * NB_WAVES), lds, (hipStream_t)stream, x, gamma,
-                     gb_stride, (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, Np, n0, rows_per_batch, D);
+                     gb_stride, (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -318,7 +327,15 @@ extern "C" int vbx_reduce_norm_partials(const float* part, float* out, long out_
   VBX_REQUIRE(part && out && B > 0 && chunks > 0 && D > 0, "vbx_reduce_norm_partials: bad args");
   dim3 grid(cdiv(2 * D, 64), sum_batch ? 1 : B);
   hipLaunchKernelGGL(reduce_norm_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, out, out_b_stride, B,
-                     chunks, D, sum_batch);
+                     chunks, 2 * D, sum_batch);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_reduce_col_partials(const float* colpart, float* out, int B, int chunks, int D, void* stream) {
+  VBX_REQUIRE(colpart && out && B > 0 && chunks > 0 && D > 0, "vbx_reduce_col_partials: bad args");
+  hipLaunchKernelGGL(reduce_norm_partials_kernel, dim3(cdiv(D, 64), 1), dim3(256), 0, (hipStream_t)stream, colpart, out, 0L, B,
+                     chunks, D, 1);
   VBX_LAUNCH_CHECK();
   return 0;
 }

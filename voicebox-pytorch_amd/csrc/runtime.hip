@@ -91,7 +91,7 @@ struct Acts {
   u16 *hf, *hfh;
   float *pred, *per_b;
   // backward scratch
-  float *dx, *dq, *dk, *delta, *slabs, *npart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
+  float *dx, *dq, *dk, *delta, *slabs, *npart, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb;
   size_t slab_floats;
@@ -179,6 +179,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.slab_floats = sf;
     a.slabs = c.take<float>(sf);
     a.npart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * 2 * d.D);
+    a.cpart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * d.D);
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
@@ -366,7 +367,8 @@ extern "C" int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, con
     vbx_set_error("vbx_model_backward_head: memset failed");
     return VBX_EINVAL;
   }
-  CK(vbx_rmsnorm_bwd(a.xs[2 * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, d.B, d.Np, d.R, d.N, d.D, stream));
+  CK(vbx_rmsnorm_bwd(a.xs[2 * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, d.R, d.N, d.D,
+                     stream));
   CK(vbx_reduce_norm_partials(a.npart, a.tmp2d, 0, d.B, (d.N + 15) / 16, d.D, 1, stream));
   CK(vbx_sum_rows_f32(a.tmp2d, 1, d.D, Gd + G[VBX_P_FNG], d.D, 0, stream));
   return 0;
@@ -391,15 +393,17 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   const int M = (int)d.M;
 
   // ---- FeedForward
-  CK(vbx_colsum_f32(a.dx, M, d.D, d.D, Gd + o[VBX_L_FF2B], a.cs_scratch, stream));
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
   CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st));
   CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
   CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
-  CK(vbx_rmsnorm_bwd(a.xs[2 * l + 1], ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, d.B, d.Np, 0, d.Np, d.D, stream));
+  // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
+  CK(vbx_rmsnorm_bwd(a.xs[2 * l + 1], ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
+                     stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
   CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
@@ -415,7 +419,7 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
-  CK(vbx_rmsnorm_bwd(a.xs[2 * l], ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, d.B, d.Np, 0, d.Np, d.D, stream));
+  CK(vbx_rmsnorm_bwd(a.xs[2 * l], ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
   CK(vbx_adaln_proj_bwd(a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
