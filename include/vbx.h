@@ -164,7 +164,8 @@ int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J);
 int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D, int sum_batch,
                              void* stream);
 /* out[d] = sum_{b,chunk} colpart[b][chunk][d]  (the fused column sums of vbx_rmsnorm_bwd) */
-int vbx_reduce_col_partials(const float* colpart, float* out, int B, int chunks, int D, void* stream);
+int vbx_reduce_col_partials(const float* colpart, float* out, float* tmp /* B*D floats */, int B, int chunks, int D,
+                            void* stream);
 /* GEGLU backward on the interleaved pre-activation (voicebox_pytorch.py:338-340) */
 int vbx_geglu_bwd(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, void* stream);
 /* column sums: out[c] (+)= sum_r in[r][c]   (bias grads) ; rowmap as in vbx_splitk_reduce */

@@ -277,7 +277,7 @@ def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
     cpart = torch.zeros(Bsz, chunks, D, device=dev)
     L.call("vbx_rmsnorm_bwd", xd, gd, stride, dy.to(dev), dx_in.to(dev), dx_out, dxb, part, cpart, Bsz, Np, n0, rpb, D, st())
     csum = torch.zeros(D, device=dev)
-    L.call("vbx_reduce_col_partials", cpart, csum, Bsz, chunks, D, st())
+    L.call("vbx_reduce_col_partials", cpart, csum, torch.zeros(Bsz, D, device=dev), Bsz, chunks, D, st())
     assert rel_err(csum, dx_in[:, n0:n0 + rpb].double().sum((0, 1))) < 1e-5  # fused column sums of dx_in
     exp_dx = xr.grad[:, n0:n0 + rpb] + dx_in[:, n0:n0 + rpb].double()
     assert rel_err(dx_out[:, n0:n0 + rpb], exp_dx) < 1e-5

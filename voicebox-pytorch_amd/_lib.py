@@ -50,7 +50,7 @@ _PROTOS = {
     "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd_scratch_floats": [I, I, I],
     "vbx_reduce_norm_partials": [P, P, L, I, I, I, I, P],
-    "vbx_reduce_col_partials": [P, P, I, I, I, P],
+    "vbx_reduce_col_partials": [P, P, P, I, I, I, P],
     "vbx_geglu_bwd": [P, P, P, I, I, P],
     "vbx_colsum_bf16": [P, I, I, I, P, I, I, I, P, P],
     "vbx_colsum_f32": [P, I, I, I, P, P, P],

@@ -332,10 +332,15 @@ extern "C" int vbx_reduce_norm_partials(const float* part, float* out, long out_
   return 0;
 }
 
-extern "C" int vbx_reduce_col_partials(const float* colpart, float* out, int B, int chunks, int D, void* stream) {
-  VBX_REQUIRE(colpart && out && B > 0 && chunks > 0 && D > 0, "vbx_reduce_col_partials: bad args");
-  hipLaunchKernelGGL(reduce_norm_partials_kernel, dim3(cdiv(D, 64), 1), dim3(256), 0, (hipStream_t)stream, colpart, out, 0L, B,
-                     chunks, D, 1);
+extern "C" int vbx_reduce_col_partials(const float* colpart, float* out, float* tmp /* [B][D] */, int B, int chunks, int D,
+                                       void* stream) {
+  VBX_REQUIRE(colpart && out && tmp && B > 0 && chunks > 0 && D > 0, "vbx_reduce_col_partials: bad args");
+  // per-batch sums over the chunks (B x D/64 blocks), then the few batch rows
+  hipLaunchKernelGGL(reduce_norm_partials_kernel, dim3(cdiv(D, 64), B), dim3(256), 0, (hipStream_t)stream, colpart, tmp, (long)D,
+                     B, chunks, D, 0);
+  VBX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_norm_partials_kernel, dim3(cdiv(D, 64), 1), dim3(256), 0, (hipStream_t)stream, tmp, out, 0L, B, 1, D,
+                     1);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -403,7 +403,7 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   CK(vbx_rmsnorm_bwd(a.xs[2 * l + 1], ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
                      stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
-  CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], d.B, chunks, d.D, stream));
+  CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
   CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
