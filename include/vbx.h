@@ -202,6 +202,23 @@ int vbx_counter_add(int* counter, int inc, void* stream);
 int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16 /* or NULL */, void* dst_f16 /* or NULL */,
                     int dst_rows, int dst_cols, int rowmap, int F, void* stream);
 int vbx_pack_bias(const float* src, int n, float* dst, int dst_n, int rowmap, int F, void* stream);
+/* ------------------------------------------------------------------ GateLoop (optional layer, use_gateloop_layers)
+ * gateloop_transformer.SimpleGateLoopLayer(dim, post_ln=True), call sites voicebox_pytorch.py:399,465-466 (third-party,
+ * restated in oracle/restate.py:gateloop -- parity unpinned).  qkva = RMSNorm(x) W^T is produced by vbx_rmsnorm_fwd +
+ * vbx_gemm; these entries are the gated linear scan and the post-LayerNorm.
+ * scan fwd: a = sigmoid(qkva[..,2D:]); h_t = a_t h_{t-1} + qkva[..,D:2D]_t; s_t = qkva[..,:D]_t h_t.
+ *   qkva [B,Np,3D] fp32, s [B,Np,D] fp32, hstate [B,Np,D] fp32 or NULL (kept for the backward).
+ * scan bwd: ds [B,Np,D] fp32 -> d(qkva) bf16 [B,Np,3D] (sigmoid derivative applied). */
+int vbx_gateloop_scan_fwd(const float* qkva, float* s, float* hstate, int B, int Np, int D, void* stream);
+int vbx_gateloop_scan_bwd(const float* qkva, const float* hstate, const float* ds, void* dqkva_bf16, int B, int Np, int D,
+                          void* stream);
+/* y = LayerNorm(s) * w + bias (+ resid), rows of D (biased variance, eps as nn.LayerNorm). */
+int vbx_layernorm_fwd(const float* s, const float* w, const float* bias, const float* resid, float* y, long rows, int D,
+                      float eps, void* stream);
+/* ds and per-16-row partial records part[B][ceil(Np/16)][2][D] (dw | dbias), to be summed by vbx_reduce_norm_partials. */
+int vbx_layernorm_bwd(const float* s, const float* w, const float* dy, float* ds, float* part, int B, int Np, int D, float eps,
+                      void* stream);
+
 /* fused Adam (torch.optim.Adam semantics, no weight decay/amsgrad) over a flat fp32 buffer; grads are
  * pre-multiplied by *gscale (device scalar, e.g. clip coefficient) if non-NULL. */
 int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
@@ -221,9 +238,11 @@ int vbx_clip_coef(const float* sumsq, float max_norm, float inv_world, float* co
  * bf16 weight arena and the activation arena (sizes from the *_bytes queries). */
 enum { VBX_P_SINW = 0, VBX_P_T1W, VBX_P_T1B, VBX_P_EMBW, VBX_P_EMBB, VBX_P_CONVW, VBX_P_CONVB, VBX_P_REG, VBX_P_FNG,
        VBX_P_PREDW, VBX_NG };
-/* per layer; the four adaLN weights, and the four adaLN biases, must be contiguous in this order */
+/* per layer; the four adaLN weights, and the four adaLN biases, must be contiguous in this order; so must the GateLoop
+ * post-LayerNorm weight and bias (GLLNW, GLLNB).  The four GL* slots are read only when vbx_model.gateloop != 0. */
 enum { VBX_L_G1W = 0, VBX_L_B1W, VBX_L_G2W, VBX_L_B2W, VBX_L_G1B, VBX_L_B1B, VBX_L_G2B, VBX_L_B2B, VBX_L_QG, VBX_L_KG,
-       VBX_L_QKVW, VBX_L_OUTW, VBX_L_FF1W, VBX_L_FF1B, VBX_L_FF2W, VBX_L_FF2B, VBX_NL };
+       VBX_L_QKVW, VBX_L_OUTW, VBX_L_FF1W, VBX_L_FF1B, VBX_L_FF2W, VBX_L_FF2B, VBX_L_GLG, VBX_L_GLW, VBX_L_GLLNW, VBX_L_GLLNB,
+       VBX_NL };
 
 typedef struct {
   int B, N, R, D, H, F, Th, L, ksize;
@@ -237,6 +256,7 @@ typedef struct {
   void* act;              /* activation arena */
   const float* rot_cos;   /* [N+R,32] host-built rotary tables (voicebox_pytorch.py:184-191,436-443) */
   const float* rot_sin;
+  int gateloop;           /* use_gateloop_layers (:898): x = GateLoop(x) + x in front of every attention block (:465-466) */
 } vbx_model;
 
 typedef struct {

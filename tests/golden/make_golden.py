@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,cfg1}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,cfg1}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -36,7 +36,7 @@ def build_reference(ref, cfg, state=None, seed=0):
     torch.manual_seed(seed)
     vb = ref.VoiceBox(dim=cfg.dim, num_cond_tokens=500, depth=cfg.depth, dim_head=cfg.dim_head,
                       heads=cfg.heads, condition_on_text=False,
-                      num_register_tokens=cfg.num_register_tokens)
+                      num_register_tokens=cfg.num_register_tokens, use_gateloop_layers=cfg.use_gateloop)
     wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb)
     if state is not None:
         missing = vb.load_state_dict(state, strict=False)
@@ -125,6 +125,36 @@ def gen_small(ref):
     print("small: loss", float(loss), "masked", float(loss_m))
 
 
+def gen_small_gateloop(ref):
+    """use_gateloop_layers=True: the reference's module tree and call order (voicebox_pytorch.py:399,465-466) around
+    the RESTATED third-party layer (oracle/restate.py:GateLoopRestated -- gateloop_transformer is not installable
+    here, so the layer's own arithmetic is parity-unpinned; its placement, residual and state-dict keys are pinned)."""
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64, use_gateloop=True)
+    vb, wrapper = build_reference(ref, cfg, seed=0)
+    g = torch.Generator().manual_seed(321)
+    with torch.no_grad():
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or ".to_beta." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            if name.endswith("norm.gamma") or ".maybe_post_ln." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+    state = {k: v.detach().clone() for k, v in vb.state_dict().items()}
+    b, n = 2, 72
+    x1 = torch.randn(b, n, cfg.dim, generator=torch.Generator().manual_seed(17))
+    x0, times, frac, rand = replay_draws(x1, seed=98)
+    torch.manual_seed(98)
+    loss = wrapper(x1)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    vb.eval()
+    with torch.no_grad():
+        pred = vb(x1, times=torch.tensor([0.3, 0.6]), cond_token_ids=None, cond=x1, cond_drop_prob=0.0)
+    torch.save(dict(cfg=dict(dim=64, depth=2, heads=2, dim_head=64, use_gateloop=True), state=state, x1=x1, x0=x0,
+                    times=times, frac=frac, rand=rand, loss=loss.detach(), grads=grads, eval_times=torch.tensor([0.3, 0.6]),
+                    pred=pred), os.path.join(HERE, "small_gateloop.pt"))
+    print("small_gateloop: loss", float(loss))
+
+
 def gen_cfg1(ref):
     """BASELINE config 1/2: dim 512, depth 2, heads 16, B=2, N=1024.  Weights by the committed
     recipe oracle.restate.init_state_dict(seed=0) (too big to commit); only scalars/slices stored."""
@@ -149,7 +179,7 @@ def gen_cfg1(ref):
 
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
-    gen_masks(ref)
-    gen_rotary(ref)
-    gen_small(ref)
-    gen_cfg1(ref)
+    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "cfg1"]
+    for w in which:
+        {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop,
+         "cfg1": gen_cfg1}[w](ref)

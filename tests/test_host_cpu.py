@@ -109,7 +109,7 @@ def test_no_cpu_fallback(golden):
 def test_unsupported_configurations_raise():
     import voicebox_pytorch_amd as vbx
 
-    for kw in (dict(dim_head=32), dict(use_gateloop_layers=True), dict(attn_dropout=0.1), dict(ff_dropout=0.1),
+    for kw in (dict(dim_head=32), dict(attn_dropout=0.1), dict(ff_dropout=0.1),
                dict(conv_pos_embed_kernel_size=15), dict(dim=100)):
         base = dict(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
         base.update(kw)
@@ -118,6 +118,25 @@ def test_unsupported_configurations_raise():
     vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
     with pytest.raises(NotImplementedError):
         vbx.ConditionalFlowMatcherWrapper(voicebox=vb, use_torchode=True)
+
+
+def test_gateloop_state_dict_layout(golden):
+    """use_gateloop_layers=True: the module tree must carry the reference's keys (voicebox_pytorch.py:399) so that
+    checkpoints interchange; the flat-buffer order keeps the post-LayerNorm weight|bias contiguous for the runtime."""
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("small_gateloop")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False,
+                      use_gateloop_layers=True)
+    mine = {k: tuple(v.shape) for k, v in vb.state_dict().items()}
+    ref = {k: tuple(v.shape) for k, v in g["state"].items()}
+    assert {k: v for k, v in mine.items() if "inv_freq" not in k} == {k: v for k, v in ref.items() if "inv_freq" not in k}
+    res = vb.load_state_dict(g["state"], strict=False)
+    assert not res.unexpected_keys
+    fp = vb.flat_params()
+    for l in range(2):
+        assert fp.offsets[f"L{l}.GLLNB"] == fp.offsets[f"L{l}.GLLNW"] + 64
+    assert torch.equal(vb.transformer.layers[1][1].to_qkva[0].weight, g["state"]["transformer.layers.1.1.to_qkva.0.weight"])
 
 
 def test_midpoint_tables_match_oracle_grid():

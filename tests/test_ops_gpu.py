@@ -557,3 +557,73 @@ def test_adam_sumsq_clip(L):
         L.call("vbx_clip_coef", ss, 0.5, 1.0, coef, st())
         L.call("vbx_adam_step", pd, gd, m, v, n, 3e-4, 0.9, 0.99, 1e-8, step, coef, st())
     assert max_err(pd, ref_p.detach()) < 2e-6
+
+
+# ----------------------------------------------------------------------------- GateLoop (scan + post LayerNorm)
+def _scan_ref(qkva):
+    """oracle/restate.py:gateloop recurrence on an fp64 [B, Np, 3D] projection (autograd-able)."""
+    q, kv, a = qkva.chunk(3, dim=-1)
+    a = a.sigmoid()
+    h = torch.zeros_like(kv[:, 0])
+    hs, outs = [], []
+    for t in range(qkva.shape[1]):
+        h = a[:, t] * h + kv[:, t]
+        hs.append(h)
+        outs.append(q[:, t] * h)
+    return torch.stack(outs, 1), torch.stack(hs, 1)
+
+
+@pytest.mark.parametrize("Bsz,Np,D", [(2, 56, 64), (3, 1040, 96), (1, 7, 32), (2, 33, 40)])
+def test_gateloop_scan_fwd_bwd(L, Bsz, Np, D):
+    g = torch.Generator().manual_seed(Np + D)
+    qkva = torch.randn(Bsz, Np, 3 * D, generator=g)
+    qkva[..., 2 * D:] = qkva[..., 2 * D:] * 1.5 + 1.0  # gates mostly open: long memory, exercises the chunk carries
+    ds = torch.randn(Bsz, Np, D, generator=g)
+    s = torch.empty(Bsz, Np, D, device=dev)
+    h = torch.empty(Bsz, Np, D, device=dev)
+    L.call("vbx_gateloop_scan_fwd", qkva.to(dev), s, h, Bsz, Np, D, st())
+    ref_in = qkva.double().requires_grad_(True)
+    s_ref, h_ref = _scan_ref(ref_in)
+    assert rel_err(s, s_ref) < 2e-6, rel_err(s, s_ref)
+    assert rel_err(h, h_ref) < 2e-6
+    s2 = torch.empty_like(s)
+    L.call("vbx_gateloop_scan_fwd", qkva.to(dev), s2, None, Bsz, Np, D, st())  # eval form: no state kept
+    assert torch.equal(s, s2)
+    dq = torch.empty(Bsz, Np, 3 * D, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_gateloop_scan_bwd", qkva.to(dev), h, ds.to(dev), dq, Bsz, Np, D, st())
+    s_ref.backward(ds.double())
+    # output is bf16 (a GEMM operand): 2^-9 relative per element
+    assert rel_err(dq.float(), ref_in.grad) < 4e-3, rel_err(dq.float(), ref_in.grad)
+    for part in range(3):
+        sl = slice(part * D, (part + 1) * D)
+        assert rel_err(dq.float()[..., sl], ref_in.grad[..., sl]) < 4e-3, part
+
+
+@pytest.mark.parametrize("Bsz,Np,D", [(2, 56, 64), (8, 1040, 512), (1, 5, 2048)])
+def test_layernorm_fwd_bwd(L, Bsz, Np, D):
+    g = torch.Generator().manual_seed(D)
+    s = torch.randn(Bsz, Np, D, generator=g) * 2 + 0.3
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    resid = torch.randn(Bsz, Np, D, generator=g)
+    dy = torch.randn(Bsz, Np, D, generator=g)
+    y = torch.empty(Bsz, Np, D, device=dev)
+    L.call("vbx_layernorm_fwd", s.to(dev), w.to(dev), b.to(dev), resid.to(dev), y, Bsz * Np, D, 1e-5, st())
+    sd, wd, bd = s.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(sd, (D,), wd, bd, eps=1e-5)
+    assert rel_err(y, ref + resid.double()) < 2e-6
+    y0 = torch.empty_like(y)
+    L.call("vbx_layernorm_fwd", s.to(dev), w.to(dev), b.to(dev), None, y0, Bsz * Np, D, 1e-5, st())
+    assert rel_err(y0, ref) < 2e-6
+    ref.backward(dy.double())
+    chunks = (Np + 15) // 16
+    dsg = torch.empty(Bsz, Np, D, device=dev)
+    part = torch.empty(Bsz, chunks, 2, D, device=dev)
+    L.call("vbx_layernorm_bwd", s.to(dev), w.to(dev), dy.to(dev), dsg, part, Bsz, Np, D, 1e-5, st())
+    assert rel_err(dsg, sd.grad) < 1e-5, rel_err(dsg, sd.grad)
+    tmp = torch.empty(Bsz, 2 * D, device=dev)
+    L.call("vbx_reduce_norm_partials", part, tmp, 2 * D, Bsz, chunks, D, 0, st())
+    out = torch.empty(2 * D, device=dev)
+    L.call("vbx_sum_rows_f32", tmp, Bsz, 2 * D, out, 2 * D, 0, st())
+    assert rel_err(out[:D], wd.grad) < 1e-5
+    assert rel_err(out[D:], bd.grad) < 1e-5

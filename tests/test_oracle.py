@@ -66,6 +66,33 @@ def test_small_model_eval_and_sample(golden):
             assert torch.allclose(s, g[key], rtol=1e-4, atol=1e-5), key
 
 
+def test_small_gateloop_model(golden):
+    """use_gateloop_layers=True: restated stack vs the reference module tree run around the restated third-party
+    layer (its own arithmetic is parity-unpinned, see oracle/restate.py:gateloop)."""
+    g = golden("small_gateloop")
+    cfg = _cfg(g["cfg"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    loss = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        got = p[k].grad
+        assert got is not None, k
+        assert float((got - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-3, k
+    # an independent formulation of the scan (closed form through cumulative log-gates) agrees with the loop
+    torch.manual_seed(0)
+    q, kv, a = torch.randn(3, 2, 37, 8, dtype=torch.float64).unbind(0)
+    a = a.sigmoid()
+    logc = a.log().cumsum(1)
+    closed = q * (torch.exp(logc) * (kv * torch.exp(-logc)).cumsum(1))
+    h = torch.zeros(2, 8, dtype=torch.float64)
+    loop = []
+    for t in range(37):
+        h = a[:, t] * h + kv[:, t]
+        loop.append(q[:, t] * h)
+    assert torch.allclose(torch.stack(loop, 1), closed, rtol=1e-9, atol=1e-9)
+
+
 def test_cfg1_loss(golden):
     """BASELINE config 1 (dim 512, depth 2, B=2, N=1024) on CPU: restatement vs reference scalars."""
     g = golden("cfg1")

@@ -51,6 +51,10 @@ _PROTOS = {
     "vbx_adaln_proj_bwd_scratch_floats": [I, I, I],
     "vbx_reduce_norm_partials": [P, P, L, I, I, I, I, P],
     "vbx_reduce_col_partials": [P, P, P, I, I, I, P],
+    "vbx_gateloop_scan_fwd": [P, P, P, I, I, I, P],
+    "vbx_gateloop_scan_bwd": [P, P, P, P, I, I, I, P],
+    "vbx_layernorm_fwd": [P, P, P, P, P, L, I, F, P],
+    "vbx_layernorm_bwd": [P, P, P, P, P, I, I, I, F, P],
     "vbx_geglu_bwd": [P, P, P, I, I, P],
     "vbx_colsum_bf16": [P, I, I, I, P, I, I, I, P, P],
     "vbx_colsum_f32": [P, I, I, I, P, P, P],

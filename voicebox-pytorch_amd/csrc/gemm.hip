@@ -307,6 +307,25 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
   DmaPlan<MB, 128> db;
   da.init(p.A, p.lda, m0, p.M, tid);
   db.init(p.B, p.ldb, n0, p.N, tid);
+  if (p.abl & 24) {  // ablation: operand tiles stored as contiguous 8 KiB k-tile images (what a tiled layout would stream)
+    const int nkt = (p.K + BK2 - 1) / BK2;
+    if (p.abl & 8) {
+#pragma unroll
+      for (int i = 0; i < DmaPlan<MA, BM_>::N; i++) {
+        da.base[i] = p.A + ((long)tm * nkt * (BM_ * 32)) + (i * 256 + tid) * 8;
+        da.kstride = BM_;  // k0 * kstride = (k0/32) * BM_*32
+        da.ok[i] = true; da.kq[i] = 0;
+      }
+    }
+    if (p.abl & 16) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        db.base[i] = p.B + ((long)tn * nkt * 4096) + (i * 256 + tid) * 8;
+        db.kstride = 128;
+        db.ok[i] = true; db.kq[i] = 0;
+      }
+    }
+  }
   FragPlan<MA> fa;
   FragPlan<MB> fb;
   fa.init(smem, wm * 64, lane);

@@ -47,7 +47,7 @@ Dims dims_of(const vbx_model* m) {
 
 // *h = fp16 copy (forward NT GEMMs), plain = bf16 copy (backward dgrad NN GEMMs)
 struct WLayer {
-  u16 *qkv, *qkvh, *out, *outh, *w1, *w1h, *w2, *w2h;
+  u16 *qkv, *qkvh, *out, *outh, *w1, *w1h, *w2, *w2h, *glw, *glwh;
   float* b1;
 };
 struct WPack {
@@ -75,6 +75,8 @@ void carve_wpack(const vbx_model* m, WPack& w) {
     w.layer[l].b1 = c.take<float>(2 * d.Fp);
     w.layer[l].w2 = c.take<u16>((size_t)d.D * d.Fp);
     w.layer[l].w2h = c.take<u16>((size_t)d.D * d.Fp);
+    w.layer[l].glw = m->gateloop ? c.take<u16>((size_t)3 * d.D * d.D) : nullptr;
+    w.layer[l].glwh = m->gateloop ? c.take<u16>((size_t)3 * d.D * d.D) : nullptr;
   }
   w.bytes = al256(c.off);
 }
@@ -82,6 +84,9 @@ void carve_wpack(const vbx_model* m, WPack& w) {
 struct ALayer {
   u16 *hn1, *hn1h, *q16, *k16, *qb, *kb, *v, *vh, *o, *oh, *hn2, *hn2h, *h1, *g, *gh;
   float *qrn, *krn, *lse;
+  // GateLoop: normed input (bf16 | fp16), projection q|kv|a, scan state h, scan output s
+  u16 *hg, *hgh;
+  float *glp, *glh, *gls;
 };
 struct Acts {
   u16 *embed_in, *embed_inh;
@@ -93,7 +98,8 @@ struct Acts {
   // backward scratch
   float *dx, *dq, *dk, *delta, *slabs, *npart, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
-  u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb;
+  u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp;
+  float* gl_ds;
   size_t slab_floats;
   size_t bytes;
 };
@@ -120,11 +126,12 @@ void carve_acts(const vbx_model* m, Acts& a) {
   a.pre = c.take<float>((size_t)d.B * d.Th);
   a.temb = c.take<float>((size_t)d.B * d.Th);
   a.ada = c.take<float>((size_t)d.B * d.J);
-  const int nxs = tr ? 2 * d.L + 1 : 2;
-  a.xs.resize(2 * d.L + 1);
+  const int S = m->gateloop ? 3 : 2;  // residual updates per layer
+  const int nxs = tr ? S * d.L + 1 : 2;
+  a.xs.resize(S * d.L + 1);
   std::vector<float*> bufs(nxs);
   for (int i = 0; i < nxs; i++) bufs[i] = c.take<float>((size_t)d.M * d.D);
-  for (int i = 0; i <= 2 * d.L; i++) a.xs[i] = bufs[tr ? i : (i & 1)];
+  for (int i = 0; i <= S * d.L; i++) a.xs[i] = bufs[tr ? i : (i & 1)];
   a.layer.resize(d.L);
   const size_t hs = (size_t)d.B * d.H * d.Np * 64;
   ALayer shared{};
@@ -149,6 +156,13 @@ void carve_acts(const vbx_model* m, Acts& a) {
       y.h1 = tr ? c.take<u16>((size_t)d.M * 2 * d.Fp) : nullptr;
       y.g = tr ? c.take<u16>((size_t)d.M * d.Fp) : nullptr;
       y.gh = c.take<u16>((size_t)d.M * d.Fp);
+      if (m->gateloop) {
+        y.hg = tr ? c.take<u16>((size_t)d.M * d.D) : nullptr;
+        y.hgh = c.take<u16>((size_t)d.M * d.D);
+        y.glp = c.take<float>((size_t)d.M * 3 * d.D);
+        y.glh = tr ? c.take<float>((size_t)d.M * d.D) : nullptr;
+        y.gls = c.take<float>((size_t)d.M * d.D);
+      }
       shared = y;
     } else {
       a.layer[l] = shared;
@@ -176,6 +190,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     };
     upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
     upd(d.D, 2 * d.D, d.M0); upd(d.D, d.D, d.M0);
+    if (m->gateloop) upd(3 * d.D, d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(sf);
     a.npart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * 2 * d.D);
@@ -193,6 +208,8 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.dpb = c.take<u16>((size_t)d.M0 * d.D);
     a.wpart = c.take<float>((size_t)vbx_convpos_bwd_chunks(d.B, d.N) * d.D * 64);
     a.tscratch = c.take<float>((size_t)vbx_time_embed_bwd_scratch_floats(d.B, d.D));
+    a.gl_ds = m->gateloop ? c.take<float>((size_t)d.M * d.D) : nullptr;
+    a.gl_dp = m->gateloop ? c.take<u16>((size_t)d.M * 3 * d.D) : nullptr;
   }
   a.bytes = al256(c.off);
 }
@@ -216,6 +233,8 @@ int check_model(const vbx_model* m) {
                 "vbx_model: adaLN weights of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
     VBX_REQUIRE(o[VBX_L_B1B] == o[VBX_L_G1B] + m->D && o[VBX_L_G2B] == o[VBX_L_B1B] + m->D && o[VBX_L_B2B] == o[VBX_L_G2B] + m->D,
                 "vbx_model: adaLN biases of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
+    VBX_REQUIRE(!m->gateloop || o[VBX_L_GLLNB] == o[VBX_L_GLLNW] + m->D,
+                "vbx_model: GateLoop post-LayerNorm weight and bias of layer %d are not contiguous", l);
   }
   return 0;
 }
@@ -280,6 +299,7 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
     CK(vbx_pack_weight(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, w.layer[l].w1h, 2 * d.Fp, d.D, 1, d.F, stream));
     CK(vbx_pack_bias(P + o[VBX_L_FF1B], 2 * d.F, w.layer[l].b1, 2 * d.Fp, 1, d.F, stream));
     CK(vbx_pack_weight(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, w.layer[l].w2h, d.D, d.Fp, 0, 0, stream));
+    if (m->gateloop) CK(vbx_pack_weight(P + o[VBX_L_GLW], 3 * d.D, d.D, w.layer[l].glw, w.layer[l].glwh, 3 * d.D, d.D, 0, 0, stream));
   }
   return 0;
 }
@@ -315,9 +335,19 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
     const ALayer& y = a.layer[l];
     const float* ada_l = a.ada + (size_t)l * d.B * 4 * d.D;  // [B][g1|b1|g2|b2]
-    float* x_in = a.xs[2 * l];
-    float* x_mid = a.xs[2 * l + 1];
-    float* x_out = a.xs[2 * l + 2];
+    const int S = m->gateloop ? 3 : 2;
+    float* x_in = a.xs[S * l + S - 2];
+    float* x_mid = a.xs[S * l + S - 1];
+    float* x_out = a.xs[S * l + S];
+    if (m->gateloop) {
+      // x = GateLoop(x) + x   (:465-466): RMSNorm -> to_qkva -> gated scan -> post LayerNorm + residual
+      float* x0 = a.xs[S * l];
+      CK(vbx_rmsnorm_fwd(x0, P + o[VBX_L_GLG], nullptr, 0, y.hg, y.hgh, d.B, d.Np, 0, d.Np, d.D, stream));
+      CK(gemm_nt(y.hgh, d.D, w.layer[l].glwh, d.D, (int)d.M, 3 * d.D, d.D, VBX_EPI_F32, y.glp, 3 * d.D, nullptr, nullptr, nullptr,
+                 nullptr, st));
+      CK(vbx_gateloop_scan_fwd(y.glp, y.gls, tr ? y.glh : nullptr, d.B, d.Np, d.D, stream));
+      CK(vbx_layernorm_fwd(y.gls, P + o[VBX_L_GLLNW], P + o[VBX_L_GLLNB], x0, x_in, d.M, d.D, 1e-5f, stream));
+    }
     // attn_prenorm -> to_qkv (+qk-norm, rotary) -> Attend -> to_out + residual   (:468-469, :317-333)
     CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, y.hn1h, d.B, d.Np, 0, d.Np, d.D, stream));
     vbx_gemm_desc g{};
@@ -338,7 +368,7 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
                nullptr, st));
   }
   // strip registers, final RMSNorm, to_pred   (:476-479, :1092)
-  CK(vbx_rmsnorm_fwd(a.xs[2 * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, a.hfh, d.B, d.Np, d.R, d.N, d.D, stream));
+  CK(vbx_rmsnorm_fwd(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, a.hfh, d.B, d.Np, d.R, d.N, d.D, stream));
   float* pred = io->pred ? io->pred : a.pred;
   CK(gemm_nt(a.hfh, d.D, w.predh, d.D, (int)d.M0, d.D, d.D, VBX_EPI_F32, pred, d.D, nullptr, nullptr, nullptr, nullptr, st));
   if (io->target) CK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a.per_b, io->loss, d.B, d.N, d.D, stream));
@@ -367,7 +397,7 @@ extern "C" int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, con
     vbx_set_error("vbx_model_backward_head: memset failed");
     return VBX_EINVAL;
   }
-  CK(vbx_rmsnorm_bwd(a.xs[2 * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, d.R, d.N, d.D,
+  CK(vbx_rmsnorm_bwd(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, d.R, d.N, d.D,
                      stream));
   CK(vbx_reduce_norm_partials(a.npart, a.tmp2d, 0, d.B, (d.N + 15) / 16, d.D, 1, stream));
   CK(vbx_sum_rows_f32(a.tmp2d, 1, d.D, Gd + G[VBX_P_FNG], d.D, 0, stream));
@@ -391,6 +421,9 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   float* dada_l = a.dada + (size_t)l * d.B * 4 * d.D;
   const int chunks = (d.Np + 15) / 16;
   const int M = (int)d.M;
+  const int S = m->gateloop ? 3 : 2;
+  const float* x_in = a.xs[S * l + S - 2];   // input of the attention block
+  const float* x_mid = a.xs[S * l + S - 1];  // input of the feed-forward block
 
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
@@ -400,7 +433,7 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
-  CK(vbx_rmsnorm_bwd(a.xs[2 * l + 1], ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
+  CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
                      stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
   CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
@@ -419,8 +452,20 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
-  CK(vbx_rmsnorm_bwd(a.xs[2 * l], ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+  CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
   CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  if (m->gateloop) {
+    // ---- GateLoop: a.dx is the gradient of x_gl = LayerNorm(s) + x0; the residual branch stays in a.dx
+    CK(vbx_layernorm_bwd(y.gls, P + o[VBX_L_GLLNW], a.dx, a.gl_ds, a.npart, d.B, d.Np, d.D, 1e-5f, stream));
+    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));  // [B][dw|db]
+    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_GLLNW], 2 * d.D, 0, stream));
+    CK(vbx_gateloop_scan_bwd(y.glp, y.glh, a.gl_ds, a.gl_dp, d.B, d.Np, d.D, stream));
+    CK(gemm_nn_bf16(a.gl_dp, 3 * d.D, w.layer[l].glw, d.D, M, d.D, 3 * d.D, a.dhn, d.D, st));
+    CK(wgrad(a.gl_dp, 3 * d.D, y.hg, d.D, 3 * d.D, d.D, d.M, a.slabs, Gd + o[VBX_L_GLW], 3 * d.D, d.D, 0, 0, st));
+    CK(vbx_rmsnorm_bwd(a.xs[S * l], P + o[VBX_L_GLG], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_GLG], d.D, 0, stream));
+  }
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
   CK(vbx_adaln_proj_bwd(a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
                         a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));
@@ -460,9 +505,10 @@ extern "C" void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int l
     if (n == "hn1") return y.hn1; if (n == "hn1h") return y.hn1h; if (n == "q16") return y.q16; if (n == "k16") return y.k16;
     if (n == "qb") return y.qb; if (n == "kb") return y.kb; if (n == "v") return y.v; if (n == "vh") return y.vh;
     if (n == "o") return y.o; if (n == "oh") return y.oh; if (n == "lse") return y.lse; if (n == "qrn") return y.qrn;
+    if (n == "glp") return y.glp; if (n == "glh") return y.glh; if (n == "gls") return y.gls;
     if (n == "krn") return y.krn; if (n == "hn2") return y.hn2; if (n == "h1") return y.h1; if (n == "g") return y.g;
   }
-  if (n == "xs" && layer >= 0 && layer <= 2 * d.L) return a.xs[layer];
+  if (n == "xs" && layer >= 0 && layer < (int)a.xs.size()) return a.xs[layer];
   if (n == "dx") return a.dx; if (n == "dxb") return a.dxb; if (n == "dq") return a.dq; if (n == "dk") return a.dk;
   if (n == "dqkv") return a.dqkv; if (n == "dO") return a.dO; if (n == "delta") return a.delta; if (n == "dhn") return a.dhn;
   if (n == "e") return a.e; if (n == "temb") return a.temb; if (n == "ada") return a.ada; if (n == "pred") return a.pred;

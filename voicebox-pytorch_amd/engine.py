@@ -11,14 +11,15 @@ from ._lib import P, I, F
 
 # enum mirrors of include/vbx.h
 G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW"]
-L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B"]
+L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B",
+           "GLG", "GLW", "GLLNW", "GLLNB"]
 NG, NL = len(G_NAMES), len(L_NAMES)
 
 
 class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
-                ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P)]
+                ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I)]
 
 
 class VbxIO(C.Structure):
@@ -145,6 +146,7 @@ class Engine:
         m.qk_norm = 1 if cfg["qk_norm"] else 0
         m.attn_scale = float(cfg["attn_scale"])
         m.training = 1 if training else 0
+        m.gateloop = 1 if cfg.get("gateloop") else 0
         self.off_table = flat.offset_table()
         m.off = C.cast(self.off_table, P)
         self.rot_cos, self.rot_sin = rotary_tables(N, cfg["R"], 64, cfg["theta"], device)

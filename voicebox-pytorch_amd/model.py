@@ -154,6 +154,21 @@ def FeedForward(dim, mult=4, dropout=0.):  # voicebox_pytorch.py:342-349
     return nn.Sequential(nn.Linear(dim, dim_inner * 2), GEGLU(), nn.Dropout(dropout), nn.Linear(dim_inner, dim))
 
 
+class GateLoop(nn.Module):
+    """Parameter holder of gateloop_transformer.SimpleGateLoopLayer(dim, post_ln=True) (third-party; call sites
+    voicebox_pytorch.py:31,399,465-466): state-dict keys norm.gamma, to_qkva.0.weight, maybe_post_ln.{weight,bias}.
+    The compute (RMSNorm -> Linear(D, 3D) -> gated linear scan -> LayerNorm) is csrc/gateloop.hip."""
+
+    def __init__(self, dim, use_jax_associative_scan=False, post_ln=True):
+        super().__init__()
+        if use_jax_associative_scan:
+            raise NotImplementedError("gateloop_use_jax: there is no jax in the HIP path (the scan is a native kernel)")
+        assert post_ln
+        self.norm = RMSNorm(dim)
+        self.to_qkva = nn.Sequential(nn.Linear(dim, dim * 3, bias=False))
+        self.maybe_post_ln = nn.LayerNorm(dim)
+
+
 class Transformer(nn.Module):
     """voicebox_pytorch.py:353-479.  Holds the stack's parameters with the reference's module tree.  The
     compute runs inside VoiceBox (the native runtime fuses the whole stack); a standalone
@@ -167,8 +182,6 @@ class Transformer(nn.Module):
         assert depth % 2 == 0
         if use_unet_skip_connection:
             raise NotImplementedError("u-net skip connections are never enabled by VoiceBox (voicebox_pytorch.py:948-962)")
-        if use_gateloop_layers:
-            raise NotImplementedError("GateLoop layers (default off, voicebox_pytorch.py:898) are not built yet")
         self.layers = nn.ModuleList([])
         self.rotary_emb = RotaryEmbedding(dim=dim_head)
         self.num_register_tokens = int(num_register_tokens)
@@ -180,7 +193,7 @@ class Transformer(nn.Module):
         self.skip_connect_scale = default(skip_connect_scale, 2 ** -0.5)
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
-                None, None, norm(),
+                None, GateLoop(dim=dim, use_jax_associative_scan=gateloop_use_jax) if use_gateloop_layers else None, norm(),
                 Attention(dim=dim, dim_head=dim_head, heads=heads, dropout=attn_dropout, flash=attn_flash, qk_norm=attn_qk_norm),
                 norm(), FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout)]))
         self.final_norm = RMSNorm(dim)
@@ -259,7 +272,8 @@ class VoiceBox(nn.Module):
         self.to_pred = nn.Linear(dim, dim_in, bias=False)
         self._cfg = dict(D=dim, H=heads, L=depth, F=int(dim * ff_mult * 2 / 3), Th=time_hidden_dim,
                          R=int(num_register_tokens), ksize=conv_pos_embed_kernel_size, qk_norm=bool(attn_qk_norm),
-                         attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0)
+                         attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
+                         gateloop=bool(use_gateloop_layers))
         self._flat = None
         self._engines = {}
 
@@ -272,8 +286,11 @@ class VoiceBox(nn.Module):
         if t.has_register_tokens:
             s["REG"] = t.register_tokens
         for l, layer in enumerate(t.layers):
-            _, _, n1, attn, n2, ff = layer
+            _, gl, n1, attn, n2, ff = layer
             p = f"L{l}."
+            if gl is not None:
+                s[p + "GLG"], s[p + "GLW"] = gl.norm.gamma, gl.to_qkva[0].weight
+                s[p + "GLLNW"], s[p + "GLLNB"] = gl.maybe_post_ln.weight, gl.maybe_post_ln.bias
             s[p + "G1W"], s[p + "G1B"] = n1.to_gamma.weight, n1.to_gamma.bias
             s[p + "B1W"], s[p + "B1B"] = n1.to_beta.weight, n1.to_beta.bias
             s[p + "G2W"], s[p + "G2B"] = n2.to_gamma.weight, n2.to_gamma.bias
