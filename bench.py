@@ -37,7 +37,7 @@ def build_model(args, dev):
 
     torch.manual_seed(0)  # identical weights on every rank
     vb = vbx.VoiceBox(dim=args.dim, num_cond_tokens=500, depth=args.depth, dim_head=64, heads=args.heads,
-                      condition_on_text=False)
+                      condition_on_text=False, use_gateloop_layers=args.gateloop)
     with torch.no_grad():  # exercise the time conditioning (adaLN projections are zero-initialised)
         for name, p in vb.named_parameters():
             if ".to_gamma.weight" in name or ".to_beta." in name:
@@ -82,10 +82,18 @@ def dominant_kernel_roofline(args, dev):
         assert rc == 0
 
     sec = time_kernel(launch)
+    # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of this same command; tools/pmc_summary.py applies the gfx950 read-side correction)
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_hbm.json")
+    if os.path.exists(pmc) and (B, N, D) == (8, 1024, 512):
+        for name, e in json.load(open(pmc)).items():
+            if "EpiGEGLU" in name and "hbm_bytes_per_launch" in e:
+                traffic = round(e["hbm_bytes_per_launch"])
     flops = 2.0 * M * D * 2 * F  # algorithmic (unpadded F) FLOPs per launch
     ach = flops / sec / 1e12
     return {"bound": "mfma", "kernel": "gemm_kernel<NT,EpiGEGLU,f16> (FeedForward-in + GEGLU)", "achieved": round(ach, 1),
-            "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
             "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2)}
 
 
@@ -124,6 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
+    ap.add_argument("--gateloop", action="store_true", help="use_gateloop_layers=True (not a BASELINE config; off by default)")
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--heads", type=int, default=16)
@@ -196,7 +205,7 @@ def main():
             "vs_baseline": None, "dtype": "f16/bf16 (fp16 forward operands, bf16 backward operands, fp32 accumulate/master)",
             "data": "synthetic",
             "config": {"workload": f"VoiceBox dim {args.dim} depth {args.depth} heads {args.heads} unconditional, "
-                                   f"{args.batch}x{args.frames} frames per GPU, {args.mode}",
+                                   f"{args.batch}x{args.frames} frames per GPU, {args.mode}" + (", GateLoop layers" if args.gateloop else ""),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
             "step_tflops_per_gpu": round(step_tf, 1), "step_roofline_frac": round(step_tf / PEAK_MFMA_TFLOPS, 4),
         }

@@ -122,19 +122,45 @@ VBX_DEV void store_rows_f32(char* wst, const f32x16 (&acc)[2], float scale, floa
   }
 }
 
+// Workgroup -> (128-row tile, head, batch).  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with a private
+// L2; the tiles of one (batch, head) all read the same K/V (or Q/dO) panels, so they are given ids that land on ONE XCD
+// and run back to back there.  With the plain (tile, h, b) grid the 9 tiles of a head sat on 9 different XCDs and every
+// panel was fetched 8-9x from HBM/MALL (rocprofv3 FETCH_SIZE: 290 MB per forward launch against 51 MB of q|k|v).
+struct AttnCoord { int tile, h, b; bool ok; };
+VBX_DEV AttnCoord attn_coord(int H, int Np, int BH, int xmap) {
+  const int nq = (Np + 127) >> 7;
+  const int id = blockIdx.x;
+  AttnCoord c;
+  int bh;
+  if (xmap) {
+    const int slot = id >> 3;
+    bh = (slot / nq) * 8 + (id & 7);
+    c.tile = slot % nq;
+  } else {
+    bh = id / nq;
+    c.tile = id - bh * nq;
+  }
+  c.ok = bh < BH;
+  c.b = bh / H;
+  c.h = bh - c.b * H;
+  return c;
+}
+
 // ============================================================================ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                           const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                           u16* __restrict__ out, u16* __restrict__ outb,
-                                                          float* __restrict__ lse, int H, int Np, float scale2, int abl) {
+                                                          float* __restrict__ lse, int H, int Np, float scale2, int abl, int BH, int xmap) {
   // abl: timing ablations (tools only, results wrong): 1 no K/V staging after tile 0, 2 no softmax math, 4 no P.V, 8 no Q.K
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const AttnCoord co = attn_coord(H, Np, BH, xmap);
+  if (!co.ok) return;
+  const int h = co.h, b = co.b;
   const long bh = (long)b * H + h;
   const u16* kbase = k16 + bh * Np * 64;
   const u16* vbase = vv + bh * Np * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = co.tile * 128 + wave * 32;
   const bool active = q0 < Np;
   const int q = q0 + (lane & 31);
   const int qc = min(q, Np - 1);
@@ -316,14 +342,16 @@ VBX_DEV void asm_read_tr(s16x4& lo, s16x4& hi, unsigned a) {
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                              const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                              u16* __restrict__ out, u16* __restrict__ outb,
-                                                             float* __restrict__ lse, int H, int Np, float scale2) {
+                                                             float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const AttnCoord co = attn_coord(H, Np, BH, xmap);
+  if (!co.ok) return;
+  const int h = co.h, b = co.b;
   const long bh = (long)b * H + h;
   const u16* kbase = k16 + bh * Np * 64;
   const u16* vbase = vv + bh * Np * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = co.tile * 128 + wave * 32;
   const bool active = q0 < Np;
   const int q = q0 + (lane & 31);
   const int qc = min(q, Np - 1);
@@ -536,15 +564,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
                                                              const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              float* __restrict__ dq, int H, int Np, float scale2,
-                                                             float scale) {
+                                                             float scale, int BH, int xmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const AttnCoord co = attn_coord(H, Np, BH, xmap);
+  if (!co.ok) return;
+  const int h = co.h, b = co.b;
   const long bh = (long)b * H + h;
   const u16* kbase = k16 + bh * Np * 64;
   const u16* kbbase = kb16 + bh * Np * 64;
   const u16* vbase = vv + bh * Np * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = co.tile * 128 + wave * 32;
   const bool active = q0 < Np;
   const int q = q0 + (lane & 31);
   const int qc = min(q, Np - 1);
@@ -642,15 +672,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
                                                                const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dk, u16* __restrict__ dv, int dv_ld, int H,
-                                                               int Np, float scale2, float scale) {
+                                                               int Np, float scale2, float scale, int BH, int xmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const AttnCoord co = attn_coord(H, Np, BH, xmap);
+  if (!co.ok) return;
+  const int h = co.h, b = co.b;
   const long bh = (long)b * H + h;
   const u16* qbase = q16 + bh * Np * 64;
   const u16* qbbase = qb16 + bh * Np * 64;
   const u16* dobase = dout + (long)b * Np * (H * 64) + h * 64;
-  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int key0 = co.tile * 128 + wave * 32;
   const bool active = key0 < Np;
   const int key = key0 + (lane & 31);
   const int keyc = min(key, Np - 1);
@@ -785,15 +817,17 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
                             float* lse, int B, int H, int Np, float scale, void* stream) {
   VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
-  dim3 grid(cdiv(Np, 128), H, B);
+  static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;  // 0: A/B against the plain tile order
+  const int BH = B * H;
+  dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
   static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   if (legacy || abl)
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl);
+                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl, BH, xmap);
   else
     hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,
-                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E);
+                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -819,13 +853,15 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
     hipLaunchKernelGGL(attn_delta_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
                        delta, H, Np, chunks);
   VBX_LAUNCH_CHECK();
-  dim3 grid(cdiv(Np, 128), H, B);
+  static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;
+  const int BH = B * H;
+  dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
-                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale);
+                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
                      (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
-                     scale * LOG2E, scale);
+                     scale * LOG2E, scale, BH, xmap);
   VBX_LAUNCH_CHECK();
   return 0;
 }
