@@ -223,6 +223,24 @@ int vbx_layernorm_bwd(const float* s, const float* w, const float* dy, float* ds
  * pre-multiplied by *gscale (device scalar, e.g. clip coefficient) if non-NULL. */
 int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   int step, const float* gscale, void* stream);
+/* Adam over the flat buffer that ALSO refreshes the packed fp16/bf16 operand copies of the weights it updates, so the
+ * next forward needs no vbx_model_pack_weights pass (62 pack launches and a second read of every parameter per step).
+ * The flat buffer is described by segments [off, off+count) that tile [0, n): plain ones (dst all NULL) and packed ones
+ * (a [rows, cols] weight written to dst_bf16 / dst_f16 with row stride dst_ld, or a bias copied to dst_f32; rowmap = 1
+ * applies the GEGLU row interleave of vbx_pack_weight).  vbx_model_adam_segments() writes the table of a model into
+ * HOST memory (returns the count, or a negative VBX_E* code; call with out = NULL to size it); the caller keeps a DEVICE
+ * copy and hands it to vbx_adam_step_packed(). */
+typedef struct {
+  long off, count;  /* floats, inside the flat buffer */
+  void* dst_bf16;
+  void* dst_f16;
+  float* dst_f32;
+  int cols, dst_ld, rowmap, F;
+  long block0;      /* first 2048-element block of this segment in the launch grid */
+} vbx_adam_seg;
+int vbx_adam_step_packed(float* p, const float* g, float* m, float* v, const vbx_adam_seg* segs_dev, int nsegs,
+                         long total_blocks, float lr, float beta1, float beta2, float eps, int step, const float* gscale,
+                         void* stream);
 /* sum of squares of a flat buffer -> out[0] (two-stage, deterministic) ; scratch >= 1024 floats */
 int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
 /* gradient-clip coefficient for a buffer holding the SUM over `world` ranks (inv_world = 1/world):
@@ -275,6 +293,8 @@ typedef struct {
 size_t vbx_model_wpack_bytes(const vbx_model* m);
 size_t vbx_model_act_bytes(const vbx_model* m);
 int vbx_model_pack_weights(const vbx_model* m, void* stream);
+/* segment table for vbx_adam_step_packed (see there) */
+int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam_seg* out, int max_segs, long* total_blocks);
 int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);
 /* backward: head (loss, to_pred, final norm) -> layers L-1..0 -> embed (conv, to_embed, time MLP).  Each call
  * finishes the gradients of its own parameters, so the caller can all-reduce them while the next runs. */

@@ -301,3 +301,51 @@ def test_gateloop_model_golden(golden):
         cmask = torch.ones(g["x1"].shape[:2], dtype=torch.bool)  # eval with cond_mask None zeroes the conditioning
         epred = restate.voicebox_forward(g["state"], cfg, g["x1"], g["eval_times"], g["x1"], cmask)
     assert rel(pred, epred) < 5e-3, rel(pred, epred)
+
+
+def test_train_step_matches_torch_clip_adam_and_keeps_operand_copies_current(golden):
+    """TrainStep = backward + clip_grad_norm_(0.5) + Adam(betas=(0.9, 0.99)) (trainer.py:274-278, optimizer.py:10-35), with
+    the fp16/bf16 operand copies refreshed inside the Adam pass: parameters must equal torch's clip + Adam applied to the
+    same gradients, and the packed arena must equal a from-scratch repack of the updated parameters (bit-exact)."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+
+    for key, kw in (("small", {}), ("small_gateloop", dict(use_gateloop_layers=True))):
+        g = golden(key)
+        draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+
+        def make():
+            vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False, **kw)
+            vb.load_state_dict(g["state"], strict=False)
+            vb = vb.to(dev)
+            return vb, vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+
+        # reference: autograd gradients of the same model -> torch clip + Adam
+        vb_r, w_r = make()
+        with rng_override(**draws):
+            w_r(g["x1"].to(dev)).backward()
+        params = [p for p in vb_r.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99))
+        torch.nn.utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+        # product: two fused steps (the second runs on operand copies refreshed by the first)
+        vb, w = make()
+        ts = TrainStep(w, lr=1e-3, max_grad_norm=0.5)
+        with rng_override(**draws):
+            ts.step(g["x1"].to(dev))
+        ref = dict(vb_r.named_parameters())
+        for k, p in vb.named_parameters():
+            if p.requires_grad:
+                # Adam's first step moves every weight by ~lr*sign(g): compare the UPDATE, not the weight
+                upd, upd_r = p.detach() - g["state"][k].to(dev), ref[k].detach() - g["state"][k].to(dev)
+                assert rel(upd, upd_r) < 2e-2, (key, k, rel(upd, upd_r))
+        eng = vb.engine(*g["x1"].shape[:2], True)
+        assert eng.packed_version is not None  # no repack pending
+        fused = eng.wpack.clone()
+        eng.packed_version = None
+        eng.bind_params()
+        assert torch.equal(fused, eng.wpack), key
+        with rng_override(**draws):
+            loss2 = ts.step(g["x1"].to(dev))
+        assert torch.isfinite(loss2).all() and float(loss2) < float(g["loss"]) + 0.05

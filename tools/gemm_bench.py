@@ -106,3 +106,15 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pad":
         gemm_padded(8320, 3072, 512, pad, "NT bf16-out qkv shape")
     for pad in (0, 64, 72):
         gemm_padded(8192, 8192, 8192, pad, "NT bf16-out 8192^3")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "norm":
+    B, Np, D = 8, 1040, 512
+    x = torch.randn(B, Np, D, device=dev)
+    ada = torch.randn(B, 4 * D, device=dev)
+    y16 = torch.empty(B, Np, D, device=dev, dtype=torch.float16)
+    yb = torch.empty(B, Np, D, device=dev, dtype=torch.bfloat16)
+    sec = timeit(lambda: L.call("vbx_rmsnorm_fwd", x, ada, ada[:, D:], 4 * D, None, y16, B, Np, 0, Np, D, st), iters=50)
+    print(f"rmsnorm fwd (eval: fp16 out)    {sec*1e6:7.2f} us  {(x.numel()*4 + y16.numel()*2)/sec/1e12:5.2f} TB/s")
+    sec = timeit(lambda: L.call("vbx_rmsnorm_fwd", x, ada, ada[:, D:], 4 * D, yb, y16, B, Np, 0, Np, D, st), iters=50)
+    print(f"rmsnorm fwd (train: fp16+bf16)  {sec*1e6:7.2f} us  {(x.numel()*4 + y16.numel()*4)/sec/1e12:5.2f} TB/s")

@@ -103,7 +103,7 @@ def lib():
 
 
 def exported_symbols():
-    return sorted(_PROTOS) + ["vbx_last_error"]
+    return sorted(_PROTOS) + ["vbx_last_error"]  # + the stage-level entries bound in engine.py
 
 
 def ptr(t):

@@ -19,7 +19,19 @@ namespace {
 constexpr int TILE16 = 64 * 128;  // one [64 rows][64 x 16-bit] tile, 16-byte XOR swizzle: 8192 B
 constexpr float NEG_INF = -__builtin_inff();
 
-VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// 16-byte-chunk swizzle of the [64][128 B] K/V/Q/dO tiles.  Two 128-byte rows span the 64 LDS banks, so same-parity rows
+// compete for the same 32 banks and the XOR key must separate them for BOTH access shapes used on these tiles:
+//  * ds_read_b128 row fragments: a 16-lane service group holds 8 same-parity rows with p = row>>1 covering all of p mod 8
+//    -> the key must be a bijection of p mod 8;
+//  * ds_read_b64_tr_b16 transposed fragments: a 32-lane group holds rows r, r+2 (p, p+1) reading the same 4 chunks
+//    -> key(p) ^ key(p+1) must flip bit 2 (move the other row to the other 64-byte half).
+// key = (p&1)<<2 | (p>>1)&3 does both (the previous key, row&7, was 2-way conflicted on every K and V^T read;
+// SQ_LDS_BANK_CONFLICT was 2.5 cycles per LDS instruction).  key(row+16) == key(row), key(row+8) != key(row).
+VBX_DEV int attn_swz(int row) {
+  const int p = row >> 1;
+  return ((p & 1) << 2) | ((p >> 1) & 3);
+}
+VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ attn_swz(row)) << 4); }
 
 // cooperative (256 threads) load of a [64][64] 16-bit tile: 2 x 16 B per thread.
 struct Stage2 {
@@ -60,9 +72,10 @@ VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
   const int G = lane >> 4, a = lane & 15;
   const int row = rbase + 4 * (G >> 1) + (a >> 2);
   const int d = d0 + (G & 1) * 16 + 4 * (a & 3);
-  const char* p = tile + row * 128 + (((d >> 3) ^ (row & 7)) << 4) + (d & 7) * 2;
+  const char* p = tile + swz_off(row, d >> 3) + (d & 7) * 2;
+  const char* p8 = tile + swz_off(row + 8, d >> 3) + (d & 7) * 2;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 8 * 128));  // row+8 keeps row&7
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p8));
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -318,7 +331,7 @@ VBX_DEV void dma_tile(char* dst, const u16* __restrict__ base, int row0, int row
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int s = i * 256 + tid;
-    const int row = s >> 3, c = (s & 7) ^ (row & 7);
+    const int row = s >> 3, c = (s & 7) ^ attn_swz(row);
     const int gr = min(row0 + row, row_lim - 1);  // rows past the end re-read the last row (masked / never stored)
     const u16* src = base + (long)gr * 64 + c * 8;
     char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;
@@ -334,15 +347,17 @@ VBX_DEV f16x8 asm_read_b128(unsigned a) {
   return r;
 }
 template <int OFF>
-VBX_DEV void asm_read_tr(s16x4& lo, s16x4& hi, unsigned a) {
+VBX_DEV void asm_read_tr(s16x4& lo, s16x4& hi, unsigned a, unsigned a8) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(OFF) : "memory");
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "i"(OFF + 1024) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a8), "i"(OFF) : "memory");
 }
 
+template <int abl>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restrict__ q16, const u16* __restrict__ k16,
                                                              const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                              u16* __restrict__ out, u16* __restrict__ outb,
                                                              float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
+  // abl (tools only, wrong results): 1 no per-tile barrier, 2 no exp, 4 no P.V MFMAs, 8 no Q.K MFMAs, 16 no K|V DMA after the prologue
   extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const AttnCoord co = attn_coord(H, Np, BH, xmap);
@@ -356,6 +371,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
   const int q = q0 + (lane & 31);
   const int qc = min(q, Np - 1);
   const int ntiles = (Np + 63) / 64;
+  long clk0 = 0, wclk0 = 0;
+  if (abl == 64) { clk0 = clock64(); wclk0 = wall_clock64(); }
 
 #pragma unroll
   for (int s = 0; s < ANST - 1; s++)
@@ -368,19 +385,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
 #pragma unroll
   for (int t = 0; t < 4; t++)
     qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+  // Retire the Q loads HERE.  Left pending, hipcc's waitcnt pass cannot count the (conditional) DMA issues younger than
+  // them and puts `s_waitcnt vmcnt(0)` in front of the first Q.K MFMA of EVERY tile -- which drains the two K|V tiles
+  // just put in flight and turns the 3-slot ring into a synchronous load per tile.
+#pragma unroll
+  for (int t = 0; t < 4; t++) asm volatile("" ::"v"(qf[t]));
 
   // lane-constant LDS addresses (slot 0, key block 0): K rows for the four d-steps; V transpose reads for the two d-halves
-  unsigned ka[4], va[2];
+  unsigned ka[4], va[2], va8[2];  // va8: rows +8 (the swizzle key differs there; +16 / +32 rows keep it)
   {
     const int row = lane & 31;
 #pragma unroll
-    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + row * 128 + (((2 * t + hi) ^ (row & 7)) << 4));
+    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off(row, 2 * t + hi));
     const int G = lane >> 4, a16 = lane & 15;
     const int vrow = 4 * (G >> 1) + (a16 >> 2);
 #pragma unroll
     for (int db = 0; db < 2; db++) {
       const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
-      va[db] = lds_addr32(smem + TILE16 + vrow * 128 + (((d >> 3) ^ (vrow & 7)) << 4) + (d & 7) * 2);
+      va[db] = lds_addr32(smem + TILE16 + swz_off(vrow, d >> 3) + (d & 7) * 2);
+      va8[db] = lds_addr32(smem + TILE16 + swz_off(vrow + 8, d >> 3) + (d & 7) * 2);
     }
   }
 
@@ -395,8 +418,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
     constexpr int SO = STG * ASTAGE;
     if (ntiles - 1 - kt >= ANST - 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + ANST - 1 < ntiles) {
+    if (!(abl & 1)) __builtin_amdgcn_s_barrier();
+    if (kt + ANST - 1 < ntiles && !(abl & 16)) {
       dma_tile(smem + NXT * ASTAGE, kbase, (kt + ANST - 1) * 64, Np, tid);
       dma_tile(smem + NXT * ASTAGE + TILE16, vbase, (kt + ANST - 1) * 64, Np, tid);
     }
@@ -415,16 +438,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
       asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (!(abl & 8))
 #pragma unroll
       for (int t = 0; t < 4; t++) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[t], qf[t], s[0], 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (two) {
+      if (two && !(abl & 8)) {
 #pragma unroll
         for (int t = 0; t < 4; t++) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[t], qf[t], s[1], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    // V^T fragments of the whole tile are requested NOW: they land while the softmax below keeps the VALU busy
+    // (issued after the softmax they cost an exposed LDS round trip in front of each P.V block)
+    s16x4 vl[2][4], vh[2][4];
+    asm_read_tr<SO>(vl[0][0], vh[0][0], va[0], va8[0]);
+    asm_read_tr<SO>(vl[0][1], vh[0][1], va[1], va8[1]);
+    asm_read_tr<SO + 2048>(vl[0][2], vh[0][2], va[0], va8[0]);
+    asm_read_tr<SO + 2048>(vl[0][3], vh[0][3], va[1], va8[1]);
+    asm_read_tr<SO + 4096>(vl[1][0], vh[1][0], va[0], va8[0]);
+    asm_read_tr<SO + 4096>(vl[1][1], vh[1][1], va[1], va8[1]);
+    asm_read_tr<SO + 4096 + 2048>(vl[1][2], vh[1][2], va[0], va8[0]);
+    asm_read_tr<SO + 4096 + 2048>(vl[1][3], vh[1][3], va[1], va8[1]);
     const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
     if (need_mask) {
 #pragma unroll
@@ -446,49 +481,277 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
     const float m_new = fmaxf(m_run, mx * scale2);
     const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
     const float alpha = fast_exp2(m_run - m_use);
-    float psum = 0.f;
+    // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): two logits per VALU instruction
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sc2 = {scale2, scale2}, mneg = {-m_use, -m_use};
+    f2 ps2 = {0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float p = fast_exp2(fmaf(s[kb][r], scale2, -m_use));
-        s[kb][r] = p;
-        psum += p;
+      for (int r = 0; r < 16; r += 2) {
+        const f2 sv = {s[kb][r], s[kb][r + 1]};
+        const f2 e = __builtin_elementwise_fma(sv, sc2, mneg);
+        const f2 p = (abl & 2) ? e : (f2){fast_exp2(e.x), fast_exp2(e.y)};
+        s[kb][r] = p.x;
+        s[kb][r + 1] = p.y;
+        ps2 += p;
       }
-    l_run = l_run * alpha + psum;
+    l_run = l_run * alpha + (ps2.x + ps2.y);
     m_run = m_new;
+    {
+      const f2 a2 = {alpha, alpha};
 #pragma unroll
-    for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    // O^T += V^T . P^T : per 32-key block, 2 sixteen-key groups x 2 d-halves
-#define VBX_PV(KB)                                                                                     \
-    {                                                                                                  \
-      s16x4 l00, h00, l01, h01, l10, h10, l11, h11;                                                    \
-      asm_read_tr<SO + TILE16 * 0 + KB * 4096>(l00, h00, va[0]);                                      \
-      asm_read_tr<SO + TILE16 * 0 + KB * 4096>(l01, h01, va[1]);                                      \
-      asm_read_tr<SO + TILE16 * 0 + KB * 4096 + 2048>(l10, h10, va[0]);                               \
-      asm_read_tr<SO + TILE16 * 0 + KB * 4096 + 2048>(l11, h11, va[1]);                               \
-      const f16x8 p0 = pack_frag_f16_fast(s[KB], 0), p1 = pack_frag_f16_fast(s[KB], 1);                \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                               \
-      const s16x8 v00 = {l00[0], l00[1], l00[2], l00[3], h00[0], h00[1], h00[2], h00[3]};              \
-      const s16x8 v01 = {l01[0], l01[1], l01[2], l01[3], h01[0], h01[1], h01[2], h01[3]};              \
-      const s16x8 v10 = {l10[0], l10[1], l10[2], l10[3], h10[0], h10[1], h10[2], h10[3]};              \
-      const s16x8 v11 = {l11[0], l11[1], l11[2], l11[3], h11[0], h11[1], h11[2], h11[3]};              \
-      __builtin_amdgcn_s_setprio(1);                                                                   \
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v00), p0, o[0], 0, 0, 0); \
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v01), p0, o[1], 0, 0, 0); \
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v10), p1, o[0], 0, 0, 0); \
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, v11), p1, o[1], 0, 0, 0); \
-      __builtin_amdgcn_s_setprio(0);                                                                   \
+      for (int i = 0; i < 16; i += 2) {
+        f2 t0 = {o[0][i], o[0][i + 1]}, t1 = {o[1][i], o[1][i + 1]};
+        t0 *= a2;
+        t1 *= a2;
+        o[0][i] = t0.x; o[0][i + 1] = t0.y;
+        o[1][i] = t1.x; o[1][i + 1] = t1.y;
+      }
     }
-    VBX_PV(0)
-    if (two) VBX_PV(1)
-#undef VBX_PV
+    // O^T += V^T . P^T : per 32-key block, 2 sixteen-key groups x 2 d-halves
+    const f16x8 p00 = pack_frag_f16_fast(s[0], 0), p01 = pack_frag_f16_fast(s[0], 1);
+    const f16x8 p10 = pack_frag_f16_fast(s[1], 0), p11 = pack_frag_f16_fast(s[1], 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 vf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const s16x8 t = {vl[kb][j][0], vl[kb][j][1], vl[kb][j][2], vl[kb][j][3], vh[kb][j][0], vh[kb][j][1], vh[kb][j][2], vh[kb][j][3]};
+        vf[kb][j] = __builtin_bit_cast(f16x8, t);
+      }
+    __builtin_amdgcn_s_setprio(1);
+    if (!(abl & 4)) {
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], p00, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], p00, o[1], 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][2], p01, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][3], p01, o[1], 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], p10, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], p10, o[1], 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][2], p11, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][3], p11, o[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < ntiles; kt += 3) {
     step(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, kt + 1);
     if (kt + 2 < ntiles) step(std::integral_constant<int, 2>{}, kt + 2);
+  }
+  __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (active && hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
+  char* ost = smem + wave * 8192;
+  if (active) {
+    const int ql = lane & 31;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
+                    v3 = o[db][4 * g4 + 3] * inv;
+        const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
+        *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
+        if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (active) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int qq = q0 + row;
+      if (qq < Np) {
+        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+        const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
+        *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
+        if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
+      }
+    }
+  }
+  if (abl == 64 && tid == 0 && co.tile == 0) {  // shader-clock probe: cycles and 100 MHz ticks this workgroup lived
+    lse[bh * Np + 0] = (float)(clock64() - clk0);
+    lse[bh * Np + 1] = (float)(wall_clock64() - wclk0);
+  }
+}
+
+// ============================================================================ forward, v3: 4 workgroups per CU
+// Same data flow as v2, resized so that FOUR workgroups fit a CU (<= 128 VGPRs, 2-slot ring = 32 KiB): the benchmark
+// grid is 8 x 16 heads x 9 query tiles = 1152 workgroups, i.e. 1.5 rounds of the 768 slots v2 gets (measured: two
+// ~35 us rounds, shader clock 1.8 GHz); with 1024 slots all full tiles run in ONE round.  One K|V tile is in flight
+// while one is consumed (K/V panels are L2 hits thanks to the XCD-aware order, the deeper ring bought nothing).
+// Register diet: K fragments in two halves, V^T fragments per 32-key block.
+constexpr int A3ST = 2;
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                             const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                             u16* __restrict__ out, u16* __restrict__ outb,
+                                                             float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const AttnCoord co = attn_coord(H, Np, BH, xmap);
+  if (!co.ok) return;
+  const int h = co.h, b = co.b;
+  const long bh = (long)b * H + h;
+  const u16* kbase = k16 + bh * Np * 64;
+  const u16* vbase = vv + bh * Np * 64;
+  const int q0 = co.tile * 128 + wave * 32;
+  const bool active = q0 < Np;
+  const int q = q0 + (lane & 31);
+  const int qc = min(q, Np - 1);
+  const int ntiles = (Np + 63) / 64;
+
+  dma_tile(smem, kbase, 0, Np, tid);
+  dma_tile(smem + TILE16, vbase, 0, Np, tid);
+
+  f16x8 qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+#pragma unroll
+  for (int t = 0; t < 4; t++) asm volatile("" ::"v"(qf[t]));  // retire the Q loads here (see v2)
+
+  unsigned ka[4], va[2], va8[2];
+  {
+    const int row = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off(row, 2 * t + hi));
+    const int G = lane >> 4, a16 = lane & 15;
+    const int vrow = 4 * (G >> 1) + (a16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; db++) {
+      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
+      va[db] = lds_addr32(smem + TILE16 + swz_off(vrow, d >> 3) + (d & 7) * 2);
+      va8[db] = lds_addr32(smem + TILE16 + swz_off(vrow + 8, d >> 3) + (d & 7) * 2);
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  auto step = [&](auto stg_c, int kt) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int SO = STG * ASTAGE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                     // tile kt visible to all; everyone is done with tile kt-1
+    if (kt + 1 < ntiles) {
+      dma_tile(smem + (STG ^ 1) * ASTAGE, kbase, (kt + 1) * 64, Np, tid);
+      dma_tile(smem + (STG ^ 1) * ASTAGE + TILE16, vbase, (kt + 1) * 64, Np, tid);
+    }
+    if (!active) return;
+    const int k0 = kt * 64;
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { s[0][i] = 0.f; s[1][i] = 0.f; }
+    {
+      f16x8 kf[4];
+      kf[0] = asm_read_b128<SO>(ka[0]); kf[1] = asm_read_b128<SO>(ka[1]);
+      kf[2] = asm_read_b128<SO>(ka[2]); kf[3] = asm_read_b128<SO>(ka[3]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 4; t++) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t], qf[t], s[0], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      kf[0] = asm_read_b128<SO + 4096>(ka[0]); kf[1] = asm_read_b128<SO + 4096>(ka[1]);
+      kf[2] = asm_read_b128<SO + 4096>(ka[2]); kf[3] = asm_read_b128<SO + 4096>(ka[3]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 4; t++) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t], qf[t], s[1], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // V^T fragments of the first 32-key block: requested now, consumed after the softmax
+    s16x4 vl[4], vh[4];
+    asm_read_tr<SO>(vl[0], vh[0], va[0], va8[0]);
+    asm_read_tr<SO>(vl[1], vh[1], va[1], va8[1]);
+    asm_read_tr<SO + 2048>(vl[2], vh[2], va[0], va8[0]);
+    asm_read_tr<SO + 2048>(vl[3], vh[3], va[1], va8[1]);
+    const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int kg = k0 + kb * 32 + acc_row(r, hi);
+          bool ok = kg < Np;
+          if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
+          if (!ok) s[kb][r] = NEG_INF;
+        }
+    }
+    float mx = NEG_INF;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale2);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run - m_use);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sc2 = {scale2, scale2}, mneg = {-m_use, -m_use};
+    f2 ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f2 sv = {s[kb][r], s[kb][r + 1]};
+        const f2 e = __builtin_elementwise_fma(sv, sc2, mneg);
+        const f2 p = {fast_exp2(e.x), fast_exp2(e.y)};
+        s[kb][r] = p.x;
+        s[kb][r + 1] = p.y;
+        ps2 += p;
+      }
+    l_run = l_run * alpha + (ps2.x + ps2.y);
+    m_run = m_new;
+    {
+      const f2 a2 = {alpha, alpha};
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f2 t0 = {o[0][i], o[0][i + 1]}, t1 = {o[1][i], o[1][i + 1]};
+        t0 *= a2;
+        t1 *= a2;
+        o[0][i] = t0.x; o[0][i + 1] = t0.y;
+        o[1][i] = t1.x; o[1][i + 1] = t1.y;
+      }
+    }
+#define VBX_PV3(KB)                                                                                             \
+    {                                                                                                           \
+      const f16x8 p0 = pack_frag_f16_fast(s[KB], 0), p1 = pack_frag_f16_fast(s[KB], 1);                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      f16x8 vf[4];                                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                           \
+        const s16x8 t = {vl[j][0], vl[j][1], vl[j][2], vl[j][3], vh[j][0], vh[j][1], vh[j][2], vh[j][3]};       \
+        vf[j] = __builtin_bit_cast(f16x8, t);                                                                   \
+      }                                                                                                         \
+      __builtin_amdgcn_s_setprio(1);                                                                            \
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], p0, o[0], 0, 0, 0);                                  \
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], p0, o[1], 0, 0, 0);                                  \
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2], p1, o[0], 0, 0, 0);                                  \
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[3], p1, o[1], 0, 0, 0);                                  \
+      __builtin_amdgcn_s_setprio(0);                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }
+    VBX_PV3(0)
+    asm_read_tr<SO + 4096>(vl[0], vh[0], va[0], va8[0]);
+    asm_read_tr<SO + 4096>(vl[1], vh[1], va[1], va8[1]);
+    asm_read_tr<SO + 4096 + 2048>(vl[2], vh[2], va[0], va8[0]);
+    asm_read_tr<SO + 4096 + 2048>(vl[3], vh[3], va[1], va8[1]);
+    VBX_PV3(1)
+#undef VBX_PV3
+  };
+  for (int kt = 0; kt < ntiles; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, kt + 1);
   }
   __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
 
@@ -822,12 +1085,35 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
   static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
+  static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
+  static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
+  if (v3 && !legacy && !abl && !abl2) {
+    hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
+                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   if (legacy || abl)
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl, BH, xmap);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,
-                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
+  {
+#define VBX_FWD2(A)                                                                                                   \
+  hipLaunchKernelGGL(attn_fwd_kernel_v2<A>, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,     \
+                     (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap)
+    switch (abl2) {  // timing ablations are separate instantiations: the production kernel carries no switches
+      case 0: VBX_FWD2(0); break;
+      case 1: VBX_FWD2(1); break;
+      case 2: VBX_FWD2(2); break;
+      case 12: VBX_FWD2(12); break;
+      case 14: VBX_FWD2(14); break;
+      case 15: VBX_FWD2(15); break;
+      case 16: VBX_FWD2(16); break;
+      case 64: VBX_FWD2(64); break;
+      default: VBX_FWD2(31); break;
+    }
+#undef VBX_FWD2
+  }
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -1,6 +1,7 @@
 // RMSNorm / AdaptiveRMSNorm forward+backward and the backward of MultiheadRMSNorm+rotary.
 // Memory-bound row kernels: one wave64 per row, float4 (16 B/lane) loads, wave-shuffle reductions.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -8,6 +9,8 @@ constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
 
 // ---------------------------------------------------------------- forward
 // y = x / max(|x|, 1e-12) * sqrt(D) * gamma[b] (+ beta[b])        (voicebox_pytorch.py:246-247, 270-276)
+// FWD_ROWS = rows per wave in flight (loads of all issued before any reduction)
+template <int FWD_ROWS>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, long gb_stride,
                                                            u16* __restrict__ y, u16* __restrict__ y16, int B, int Np, int n0,
@@ -16,37 +19,54 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
   const long rows = (long)B * rpb;
-  for (long ri = (long)blockIdx.x * 4 + wave; ri < rows; ri += (long)gridDim.x * 4) {
-    const int b = (int)(ri / rpb), j = (int)(ri - (long)b * rpb);
-    const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
-    float4 v[MAXC];
-    float ss = 0.f;
+  for (long r0 = ((long)blockIdx.x * 4 + wave) * FWD_ROWS; r0 < rows; r0 += (long)gridDim.x * 4 * FWD_ROWS) {
+    float4 v[FWD_ROWS][MAXC];
+    float ss[FWD_ROWS];
+    int bb[FWD_ROWS];
 #pragma unroll
-    for (int i = 0; i < MAXC; i++) {
-      const int c = lane + 64 * i;
-      if (c < D4) {
-        v[i] = xr[c];
-        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    for (int k = 0; k < FWD_ROWS; k++) {
+      const long ri = min(r0 + k, rows - 1);
+      const int b = (int)(ri / rpb), j = (int)(ri - (long)b * rpb);
+      bb[k] = b;
+      const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
+      ss[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const int c = lane + 64 * i;
+        if (c < D4) v[k][i] = xr[c];
       }
     }
-    ss = wave_sum(ss);
-    const float r = sqrtD / fmaxf(sqrtf(ss), 1e-12f);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
-    const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)b * gb_stride) : nullptr;
-    uint2* yr = y ? reinterpret_cast<uint2*>(y + ri * D) : nullptr;
-    uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + ri * D) : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAXC; i++) {
-      const int c = lane + 64 * i;
-      if (c < D4) {
-        const float4 g = g4[c];
-        float4 o = make_float4(v[i].x * r * g.x, v[i].y * r * g.y, v[i].z * r * g.z, v[i].w * r * g.w);
-        if (b4) {
-          const float4 bb = b4[c];
-          o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+    for (int k = 0; k < FWD_ROWS; k++) {
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const int c = lane + 64 * i;
+        if (c < D4) ss[k] += v[k][i].x * v[k][i].x + v[k][i].y * v[k][i].y + v[k][i].z * v[k][i].z + v[k][i].w * v[k][i].w;
+      }
+      ss[k] = wave_sum(ss[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < FWD_ROWS; k++) {
+      const long ri = r0 + k;
+      if (ri >= rows) break;
+      const float r = sqrtD / fmaxf(sqrtf(ss[k]), 1e-12f);
+      const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)bb[k] * gb_stride);
+      const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)bb[k] * gb_stride) : nullptr;
+      uint2* yr = y ? reinterpret_cast<uint2*>(y + ri * D) : nullptr;
+      uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + ri * D) : nullptr;
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+          const float4 g = g4[c];
+          float4 o = make_float4(v[k][i].x * r * g.x, v[k][i].y * r * g.y, v[k][i].z * r * g.z, v[k][i].w * r * g.w);
+          if (b4) {
+            const float4 bv = b4[c];
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+          }
+          if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+          if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
         }
-        if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-        if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
       }
     }
   }
@@ -292,10 +312,15 @@ extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* 
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_fwd: bad row range");
   const long rows = (long)B * rows_per_batch;
-  int blocks = cdiv(rows, 4);
+  static const int rpw = getenv("VBX_RMS_ROWS") ? atoi(getenv("VBX_RMS_ROWS")) : 1;  // A/B: rows per wave in flight
+  int blocks = cdiv(rows, 4 * (rpw == 2 ? 2 : 1));
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                     (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
+  if (rpw == 2)
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
+                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
+                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }

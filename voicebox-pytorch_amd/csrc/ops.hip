@@ -648,6 +648,81 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, int n, float* __
 }
 
 // ---------------------------------------------------------------- optimizer
+// Adam + packed-copy refresh (multi-tensor apply over a segment table; one block = 2048 consecutive floats of one segment)
+constexpr int ADAM_BLOCK = 2048;
+struct AdamCoef { float lr_bc1, b1, b2, eps, bc2_sqrt, gs; };
+VBX_DEV float adam_one(float pv, float gv, float& mv, float& vv, const AdamCoef& k) {
+  const float gr = gv * k.gs;
+  mv = k.b1 * mv + (1.0f - k.b1) * gr;
+  vv = k.b2 * vv + (1.0f - k.b2) * gr * gr;
+  // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+  return pv - k.lr_bc1 * mv / (sqrtf(vv) / k.bc2_sqrt + k.eps);
+}
+__global__ __launch_bounds__(256) void adam_packed_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const vbx_adam_seg* __restrict__ segs, int nsegs,
+                                                          float lr_bc1, float b1, float b2, float eps, float bc2_sqrt,
+                                                          const float* __restrict__ gscale) {
+  // segment of this block: last s with segs[s].block0 <= blockIdx.x
+  int lo = 0, hi = nsegs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].block0 <= (long)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const vbx_adam_seg sg = segs[lo];
+  const AdamCoef k{lr_bc1, b1, b2, eps, bc2_sqrt, gscale ? gscale[0] : 1.0f};
+  const long j0 = ((long)blockIdx.x - sg.block0) * ADAM_BLOCK;
+  u16* db = (u16*)sg.dst_bf16;
+  u16* dh = (u16*)sg.dst_f16;
+  const bool packed = db || dh || sg.dst_f32;
+  // 4 consecutive floats per lane (16-byte accesses, 8-byte packed stores) whenever a group cannot straddle a row
+  const bool vec = (sg.off & 3) == 0 && (!packed || ((sg.cols & 3) == 0 && (sg.dst_ld & 3) == 0));
+#pragma unroll
+  for (int it = 0; it < ADAM_BLOCK / 1024; it++) {
+    const long j = j0 + (long)(it * 256 + threadIdx.x) * 4;
+    if (j >= sg.count) break;
+    const long i = sg.off + j;
+    if (vec && j + 3 < sg.count) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+      float4 pv = *reinterpret_cast<const float4*>(p + i);
+      pv.x = adam_one(pv.x, gv.x, mv.x, vv.x, k);
+      pv.y = adam_one(pv.y, gv.y, mv.y, vv.y, k);
+      pv.z = adam_one(pv.z, gv.z, mv.z, vv.z, k);
+      pv.w = adam_one(pv.w, gv.w, mv.w, vv.w, k);
+      *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+      *reinterpret_cast<float4*>(p + i) = pv;
+      if (packed) {
+        const int r = (int)(j / sg.cols), c = (int)(j - (long)r * sg.cols);
+        int dr = r;
+        if (sg.rowmap == 1) dr = r < sg.F ? ((r >> 6) << 7) + (r & 63) : ((((r - sg.F) >> 6) << 7) + 64 + ((r - sg.F) & 63));
+        const long o = (long)dr * sg.dst_ld + c;
+        if (db) *reinterpret_cast<uint2*>(db + o) = make_uint2(pack_bf16x2(pv.x, pv.y), pack_bf16x2(pv.z, pv.w));
+        if (dh) *reinterpret_cast<uint2*>(dh + o) = make_uint2(pack_f16x2(pv.x, pv.y), pack_f16x2(pv.z, pv.w));
+        if (sg.dst_f32) *reinterpret_cast<float4*>(sg.dst_f32 + o) = pv;
+      }
+    } else {
+      for (int e = 0; e < 4 && j + e < sg.count; e++) {
+        float mv = m[i + e], vv = v[i + e];
+        const float pn = adam_one(p[i + e], g[i + e], mv, vv, k);
+        m[i + e] = mv;
+        v[i + e] = vv;
+        p[i + e] = pn;
+        if (packed) {
+          const long jj = j + e;
+          const int r = (int)(jj / sg.cols), c = (int)(jj - (long)r * sg.cols);
+          int dr = r;
+          if (sg.rowmap == 1) dr = r < sg.F ? ((r >> 6) << 7) + (r & 63) : ((((r - sg.F) >> 6) << 7) + 64 + ((r - sg.F) & 63));
+          const long o = (long)dr * sg.dst_ld + c;
+          if (db) db[o] = f32_to_bf16(pn);
+          if (dh) dh[o] = f32_to_f16(pn);
+          if (sg.dst_f32) sg.dst_f32[o] = pn;
+        }
+      }
+    }
+  }
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
                             const float* __restrict__ gscale) {
@@ -979,6 +1054,18 @@ extern "C" int vbx_pack_weight(const float* src, int src_rows, int src_cols, voi
 extern "C" int vbx_pack_bias(const float* src, int n, float* dst, int dst_n, int rowmap, int F, void* stream) {
   VBX_REQUIRE(src && dst, "vbx_pack_bias: null pointer");
   hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(dst_n, 256)), dim3(256), 0, ST, src, n, dst, dst_n, rowmap, F);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_adam_step_packed(float* p, const float* g, float* m, float* v, const vbx_adam_seg* segs_dev, int nsegs,
+                                    long total_blocks, float lr, float beta1, float beta2, float eps, int step,
+                                    const float* gscale, void* stream) {
+  VBX_REQUIRE(p && g && m && v && segs_dev && nsegs > 0 && total_blocks > 0 && step >= 1, "vbx_adam_step_packed: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_packed_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST, p, g, m, v, segs_dev, nsegs, lr / bc1, beta1,
+                     beta2, eps, sqrtf(bc2), gscale);
   VBX_LAUNCH_CHECK();
   return 0;
 }

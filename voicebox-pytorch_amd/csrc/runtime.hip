@@ -13,6 +13,7 @@
 // is bf16 (gradients need the exponent range), so in training each saved activation also has a bf16 copy.
 #include "common.hpp"
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -492,6 +493,55 @@ extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, vo
   CK(vbx_time_embed_bwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], a.four, a.pre, a.dtemb, Gd + G[VBX_P_SINW],
                         Gd + G[VBX_P_T1W], Gd + G[VBX_P_T1B], a.tscratch, d.B, d.D, d.Th, stream));
   return 0;
+}
+
+// Segment table of the fused Adam + repack step (vbx_adam_step_packed): every parameter that vbx_model_pack_weights
+// copies into the operand arena, in flat-buffer order, with plain segments in between.
+extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam_seg* out, int max_segs, long* total_blocks) {
+  CK(check_model(m));
+  VBX_REQUIRE(n_flat > 0 && total_blocks, "vbx_model_adam_segments: bad args");
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  const long* G = m->off;
+  std::vector<vbx_adam_seg> ps;
+  auto add = [&](long off, long rows, long cols, void* b, void* h16, float* f32, int ld, int rowmap, int F) {
+    vbx_adam_seg s{};
+    s.off = off; s.count = rows * cols; s.dst_bf16 = b; s.dst_f16 = h16; s.dst_f32 = f32; s.cols = (int)cols; s.dst_ld = ld;
+    s.rowmap = rowmap; s.F = F;
+    ps.push_back(s);
+  };
+  add(G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, nullptr, 2 * d.D, 0, 0);
+  add(G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
+  for (int l = 0; l < d.L; l++) {
+    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    add(o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, nullptr, d.Th, 0, 0);
+    add(o[VBX_L_G1B], 1, 4 * d.D, nullptr, nullptr, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0);
+    add(o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, w.layer[l].qkvh, nullptr, d.D, 0, 0);
+    add(o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, w.layer[l].outh, nullptr, d.I, 0, 0);
+    add(o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, w.layer[l].w1h, nullptr, d.D, 1, d.F);
+    add(o[VBX_L_FF1B], 2 * d.F, 1, nullptr, nullptr, w.layer[l].b1, 1, 1, d.F);
+    add(o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, w.layer[l].w2h, nullptr, d.Fp, 0, 0);
+    if (m->gateloop) add(o[VBX_L_GLW], 3 * d.D, d.D, w.layer[l].glw, w.layer[l].glwh, nullptr, d.D, 0, 0);
+  }
+  std::sort(ps.begin(), ps.end(), [](const vbx_adam_seg& a, const vbx_adam_seg& b) { return a.off < b.off; });
+  std::vector<vbx_adam_seg> all;
+  long cur = 0;
+  for (const auto& s : ps) {
+    VBX_REQUIRE(s.off >= cur && s.off + s.count <= n_flat, "vbx_model_adam_segments: overlapping / out-of-range parameter slots");
+    if (s.off > cur) { vbx_adam_seg gseg{}; gseg.off = cur; gseg.count = s.off - cur; gseg.cols = 1; all.push_back(gseg); }
+    all.push_back(s);
+    cur = s.off + s.count;
+  }
+  if (cur < n_flat) { vbx_adam_seg gseg{}; gseg.off = cur; gseg.count = n_flat - cur; gseg.cols = 1; all.push_back(gseg); }
+  long blocks = 0;
+  for (auto& s : all) { s.block0 = blocks; blocks += (s.count + 2047) / 2048; }
+  *total_blocks = blocks;
+  if (out) {
+    VBX_REQUIRE((int)all.size() <= max_segs, "vbx_model_adam_segments: table needs %d entries", (int)all.size());
+    for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
+  }
+  return (int)all.size();
 }
 
 // Debug/introspection (tests only): device pointer of a named arena tensor.

@@ -6,6 +6,8 @@ Semantics to match (VoiceBoxTrainer.train_step, trainer.py:237-313, SURVEY 8(a) 
 the mean over its local batch; gradients are averaged over ranks (DDP), clipped to max_grad_norm = 0.5
 (trainer.py:274-275), then Adam(lr, betas=(0.9, 0.99)) (optimizer.py:10-35, wd = 0 default trainer.py:74).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -123,7 +125,12 @@ class TrainStep:
         self.steps += 1
         _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
-        _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
-                  float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
+        # Adam + refresh of the training engine's fp16/bf16 operand copies in one pass (other engines repack lazily)
         self._dirty()
+        if os.environ.get("VBX_FUSED_ADAM", "1") != "0":
+            eng.adam_step_packed(self.gflat, self.m, self.v, float(lr if lr is not None else self.lr), self.betas[0], self.betas[1],
+                                 self.eps, self.steps, self.coef)
+        else:  # A/B: plain Adam, the next forward repacks every weight
+            _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
+                      float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
         return loss

@@ -27,6 +27,11 @@ class VbxIO(C.Structure):
                 ("times", P), ("target", P), ("pred", P), ("loss", P)]
 
 
+class VbxAdamSeg(C.Structure):
+    _fields_ = [("off", C.c_long), ("count", C.c_long), ("dst_bf16", P), ("dst_f16", P), ("dst_f32", P),
+                ("cols", I), ("dst_ld", I), ("rowmap", I), ("F", I), ("block0", C.c_long)]
+
+
 _runtime_protos_done = False
 
 
@@ -39,6 +44,10 @@ def _rt():
         l.vbx_model_wpack_bytes.restype = C.c_size_t
         l.vbx_model_act_bytes.argtypes = [MP]
         l.vbx_model_act_bytes.restype = C.c_size_t
+        l.vbx_model_adam_segments.argtypes = [MP, C.c_long, C.POINTER(VbxAdamSeg), I, C.POINTER(C.c_long)]
+        l.vbx_model_adam_segments.restype = I
+        l.vbx_adam_step_packed.argtypes = [P, P, P, P, P, I, C.c_long, F, F, F, F, I, P, P]
+        l.vbx_adam_step_packed.restype = I
         for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
                          ("vbx_model_backward_head", [MP, IP, P, P]), ("vbx_model_backward_layer", [MP, IP, I, P]),
                          ("vbx_model_backward_embed", [MP, IP, P])):
@@ -169,6 +178,28 @@ class Engine:
         if key != self.packed_version:
             _check(_rt().vbx_model_pack_weights(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights")
             self.packed_version = key
+
+    # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
+    def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale):
+        l = _rt()
+        flat = self.fp.flat
+        self.bind_params()  # the packed arena must be current before it is updated incrementally
+        if getattr(self, "_adam_segs", None) is None:
+            nblocks = C.c_long(0)
+            n = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), None, 0, C.byref(nblocks))
+            if n <= 0:
+                _check(n if n < 0 else -1, "vbx_model_adam_segments")
+            tab = (VbxAdamSeg * n)()
+            n2 = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), tab, n, C.byref(nblocks))
+            assert n2 == n
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            self._adam_segs = (raw, n, nblocks.value)
+        raw, n, nblocks = self._adam_segs
+        _check(l.vbx_adam_step_packed(flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), raw.data_ptr(), n, nblocks,
+                                      float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                      gscale.data_ptr() if gscale is not None else None, _lib.current_stream()),
+               "vbx_adam_step_packed")
+        self.packed_version = (flat.data_ptr(), flat._version)  # this engine's operand copies were refreshed in the same pass
 
     # -- forward
     def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None):
