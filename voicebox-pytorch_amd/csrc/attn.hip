@@ -31,7 +31,10 @@ VBX_DEV int attn_swz(int row) {
   const int p = row >> 1;
   return ((p & 1) << 2) | ((p >> 1) & 3);
 }
-VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ attn_swz(row)) << 4); }
+VBX_DEV int swz_off2(int row, int chunk) { return row * 128 + ((chunk ^ attn_swz(row)) << 4); }  // LDS-DMA forward kernels
+// register-staged kernels (legacy forward, both backward kernels) keep the row&7 key: their transposed reads reach rows
+// +8 through one address and an immediate (key(row+8) == key(row)); measured with the new key there: backward 217 -> 234 us
+VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // cooperative (256 threads) load of a [64][64] 16-bit tile: 2 x 16 B per thread.
 struct Stage2 {
@@ -73,9 +76,8 @@ VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
   const int row = rbase + 4 * (G >> 1) + (a >> 2);
   const int d = d0 + (G & 1) * 16 + 4 * (a & 3);
   const char* p = tile + swz_off(row, d >> 3) + (d & 7) * 2;
-  const char* p8 = tile + swz_off(row + 8, d >> 3) + (d & 7) * 2;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p8));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 8 * 128));  // row+8 keeps row&7
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -396,14 +398,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restri
   {
     const int row = lane & 31;
 #pragma unroll
-    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off(row, 2 * t + hi));
+    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off2(row, 2 * t + hi));
     const int G = lane >> 4, a16 = lane & 15;
     const int vrow = 4 * (G >> 1) + (a16 >> 2);
 #pragma unroll
     for (int db = 0; db < 2; db++) {
       const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
-      va[db] = lds_addr32(smem + TILE16 + swz_off(vrow, d >> 3) + (d & 7) * 2);
-      va8[db] = lds_addr32(smem + TILE16 + swz_off(vrow + 8, d >> 3) + (d & 7) * 2);
+      va[db] = lds_addr32(smem + TILE16 + swz_off2(vrow, d >> 3) + (d & 7) * 2);
+      va8[db] = lds_addr32(smem + TILE16 + swz_off2(vrow + 8, d >> 3) + (d & 7) * 2);
     }
   }
 
@@ -619,14 +621,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
   {
     const int row = lane & 31;
 #pragma unroll
-    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off(row, 2 * t + hi));
+    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off2(row, 2 * t + hi));
     const int G = lane >> 4, a16 = lane & 15;
     const int vrow = 4 * (G >> 1) + (a16 >> 2);
 #pragma unroll
     for (int db = 0; db < 2; db++) {
       const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
-      va[db] = lds_addr32(smem + TILE16 + swz_off(vrow, d >> 3) + (d & 7) * 2);
-      va8[db] = lds_addr32(smem + TILE16 + swz_off(vrow + 8, d >> 3) + (d & 7) * 2);
+      va[db] = lds_addr32(smem + TILE16 + swz_off2(vrow, d >> 3) + (d & 7) * 2);
+      va8[db] = lds_addr32(smem + TILE16 + swz_off2(vrow + 8, d >> 3) + (d & 7) * 2);
     }
   }
 
