@@ -680,51 +680,71 @@ struct EpiQKV {
     const int I = H * 64;
     const int which = n0 / I;
     const int hbase = (n0 % I) >> 6;
-    for (int it = 0; it < rows / 16; it++) {
-      const int row = it * 16 + (tid >> 4), cc = tid & 15;
+    if (which == 2) {  // v: plain head split
+      for (int it = 0; it < rows / 16; it++) {
+        const int row = it * 16 + (tid >> 4), cc = tid & 15;
+        const int gr = m0 + row;
+        if (gr >= M) continue;
+        const int b = gr / Np, n = gr - b * Np;
+        float t[8];
+        load8(Cs, row, cc, t);
+        const long o = (((long)b * H + hbase + (cc >> 3)) * Np + n) * 64 + (cc & 7) * 8;
+        if (v) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
+        if (v16) *reinterpret_cast<uint4*>(v16 + o) = pack8_f16(t);
+      }
+      return;
+    }
+    // q / k: a thread owns the rotary pair of 8-wide chunks (d0..d0+7, d0+32..d0+39) of one (row, head), so rotate_half
+    // needs no cross-lane traffic and the 64-wide sum of squares is a 4-lane quad reduction (DPP, no LDS permutes).
+    // 8 threads per row (2 heads x 4 chunk pairs), 32 rows per pass.
+    for (int it = 0; it < rows / 32; it++) {
+      const int row = it * 32 + (tid >> 3), hj = tid & 7;
       const int gr = m0 + row;
       const bool valid = gr < M;
       const int grc = valid ? gr : (M - 1);
       const int b = grc / Np, n = grc - b * Np;
-      const int head = hbase + (cc >> 3);
-      const int d0 = (cc & 7) * 8;
-      float t[8];
-      load8(Cs, row, cc, t);
-      const long o = (((long)b * H + head) * Np + n) * 64 + d0;
-      if (which == 2) {
-        if (valid) {
-          if (v) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
-          if (v16) *reinterpret_cast<uint4*>(v16 + o) = pack8_f16(t);
-        }
-        continue;
-      }
+      const int hl = hj >> 2, j = hj & 3;  // head inside the 128-column tile, chunk pair
+      const int head = hbase + hl;
+      const int d0 = j * 8;
+      float lo[8], hi[8];
+      load8(Cs, row, hl * 8 + j, lo);
+      load8(Cs, row, hl * 8 + j + 4, hi);
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; i++) ss += t[i] * t[i];
+      for (int i = 0; i < 8; i++) ss += lo[i] * lo[i] + hi[i] * hi[i];
       ss += __shfl_xor(ss, 1, 64);
       ss += __shfl_xor(ss, 2, 64);
-      ss += __shfl_xor(ss, 4, 64);
       const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
       if (qk_scale > 0.f) {
         const float* gam = (which == 0 ? qg : kg) + head * 64 + d0;
+        const float rs_ = rinv * qk_scale;
 #pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = t[i] * rinv * qk_scale * gam[i];
+        for (int i = 0; i < 8; i++) {
+          lo[i] = lo[i] * rs_ * gam[i];
+          hi[i] = hi[i] * rs_ * gam[32 + i];
+        }
       }
-      float out[8];
-      const float sgn = (d0 < 32) ? -1.f : 1.f;
-      const float* cp = rc + (long)n * 32 + (d0 & 31);
-      const float* sp = rs + (long)n * 32 + (d0 & 31);
+      // rotate_half (voicebox_pytorch.py:193-199): out[d] = t[d] cos - t[d+32] sin (d < 32), out[d+32] = t[d+32] cos + t[d] sin
+      const float* cp = rc + (long)n * 32 + d0;
+      const float* sp = rs + (long)n * 32 + d0;
+      float olo[8], ohi[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        const float partner = __shfl_xor(t[i], 4, 64);
-        out[i] = t[i] * cp[i] + sgn * partner * sp[i];
+        olo[i] = lo[i] * cp[i] - hi[i] * sp[i];
+        ohi[i] = hi[i] * cp[i] + lo[i] * sp[i];
       }
       if (valid) {
-        *reinterpret_cast<uint4*>((which == 0 ? q16 : k16) + o) = pack8_f16(out);
+        const long o = (((long)b * H + head) * Np + n) * 64 + d0;
+        u16* dst = (which == 0 ? q16 : k16);
+        *reinterpret_cast<uint4*>(dst + o) = pack8_f16(olo);
+        *reinterpret_cast<uint4*>(dst + o + 32) = pack8_f16(ohi);
         u16* bcopy = (which == 0 ? qb : kb);
-        if (bcopy) *reinterpret_cast<uint4*>(bcopy + o) = pack8_bf16(out);
+        if (bcopy) {
+          *reinterpret_cast<uint4*>(bcopy + o) = pack8_bf16(olo);
+          *reinterpret_cast<uint4*>(bcopy + o + 32) = pack8_bf16(ohi);
+        }
         float* rn = (which == 0 ? qrn : krn);
-        if (rn && (cc & 7) == 0) rn[((long)b * H + head) * Np + n] = rinv;
+        if (rn && j == 0) rn[((long)b * H + head) * Np + n] = rinv;
       }
     }
   }
