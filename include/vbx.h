@@ -99,6 +99,9 @@ int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, float* dst, 
 int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
                     void* y_f16 /* optional fp16 copy (same dense layout); y_bf16 may then be NULL */,
                     int B, int Np, int n0, int rows_per_batch, int D, void* stream);
+/* same, fp32 output rows [B*rows_per_batch, D] (final norm of a standalone Transformer.forward, :479) */
+int vbx_rmsnorm_fwd_f32(const float* x, const float* gamma, const float* beta, long gb_stride, float* y_f32, int B, int Np,
+                        int n0, int rows_per_batch, int D, void* stream);
 /* backward: dx_out = dx_in (or 0 if NULL) + d/dx ; partial dgamma/dbeta sums per 16-row chunk:
  * part[b][chunk][2][D] (chunk count = ceil(rows_per_batch/16)).  dy is dense bf16 [B*rows, D].
  * dx tensors have the same (Np, n0) row addressing as x.  dxb: optional bf16 copy of dx_out (same addressing). */
@@ -134,6 +137,10 @@ int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_
                          void* out_bf16 /* optional copy: wgrad operand */, int B, int N, int D, void* stream);
 /* ConvPositionEmbed + residual + register tokens (voicebox_pytorch.py:220-233,1080,422-425):
  * xs[b, R+n, :] = e[b,n,:] + mask*gelu(conv(mask*e)[b,n,:] + bias);  xs[b, r<R, :] = reg[r,:]. */
+/* standalone Transformer.forward (voicebox_pytorch.py:417-431, :476-477): residual stream [B,N+R,D] = register tokens (rows
+ * n < R) followed by x [B,N,D]; backward: dx = rows n >= R of dxs, dreg[R,D] = sum over the batch of rows n < R. */
+int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream);
+int vbx_stack_input_bwd(const float* dxs, float* dx, float* dreg /* may be NULL */, int B, int N, int R, int D, void* stream);
 int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
                     float* xs, int B, int N, int R, int D, int ksize, void* stream);
 /* backward: de = dxs[:,R:] + conv-transpose(...) ; dw/db partials [chunks][D][ksize+1]; dreg [R,D]. */
@@ -260,7 +267,7 @@ enum { VBX_P_SINW = 0, VBX_P_T1W, VBX_P_T1B, VBX_P_EMBW, VBX_P_EMBB, VBX_P_CONVW
  * post-LayerNorm weight and bias (GLLNW, GLLNB).  The four GL* slots are read only when vbx_model.gateloop != 0. */
 enum { VBX_L_G1W = 0, VBX_L_B1W, VBX_L_G2W, VBX_L_B2W, VBX_L_G1B, VBX_L_B1B, VBX_L_G2B, VBX_L_B2B, VBX_L_QG, VBX_L_KG,
        VBX_L_QKVW, VBX_L_OUTW, VBX_L_FF1W, VBX_L_FF1B, VBX_L_FF2W, VBX_L_FF2B, VBX_L_GLG, VBX_L_GLW, VBX_L_GLLNW, VBX_L_GLLNB,
-       VBX_NL };
+       VBX_L_N1G, VBX_L_N2G /* plain RMSNorm gammas, read only when vbx_model.plain_norm != 0 */, VBX_NL };
 
 typedef struct {
   int B, N, R, D, H, F, Th, L, ksize;
@@ -275,6 +282,10 @@ typedef struct {
   const float* rot_cos;   /* [N+R,32] host-built rotary tables (voicebox_pytorch.py:184-191,436-443) */
   const float* rot_sin;
   int gateloop;           /* use_gateloop_layers (:898): x = GateLoop(x) + x in front of every attention block (:465-466) */
+  int stack_only;         /* 1: standalone Transformer.forward (:412-479): io->x is the stack input [B,N,D], io->cond the adaptive
+                             norm condition [B,Th] (unused with plain_norm), io->pred the final-norm output [B,N,D]; the backward
+                             entry points take d(output) in io->target and write io->dx / io->dcond */
+  int plain_norm;         /* 1: non-adaptive RMSNorm (adaptive_rmsnorm = False, :386-389): gammas at VBX_L_N1G / VBX_L_N2G */
 } vbx_model;
 
 typedef struct {
@@ -288,6 +299,8 @@ typedef struct {
   const float* target;          /* [B,N,D] or NULL */
   float* pred;                  /* [B,N,D] output */
   float* loss;                  /* [1] output when target != NULL */
+  float* dx;                    /* stack_only backward: [B,N,D] gradient of the stack input */
+  float* dcond;                 /* stack_only backward: [B,Th] gradient of the adaptive-norm condition (NULL with plain_norm) */
 } vbx_io;
 
 size_t vbx_model_wpack_bytes(const vbx_model* m);

@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,cfg1}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,transformer,cfg1}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -155,6 +155,40 @@ def gen_small_gateloop(ref):
     print("small_gateloop: loss", float(loss))
 
 
+def gen_transformer(ref):
+    """Standalone Transformer.forward (voicebox_pytorch.py:412-479): adaptive (registers, qk-norm, key-padding mask) and plain
+    (no registers, no qk-norm) variants, output + gradients of parameters, input and condition."""
+    out = {}
+    for name, kw, use_mask in (("adaptive", dict(num_register_tokens=4, adaptive_rmsnorm=True, adaptive_rmsnorm_cond_dim_in=32,
+                                                attn_qk_norm=True), True),
+                               ("plain", dict(num_register_tokens=0, adaptive_rmsnorm=False, attn_qk_norm=False), False)):
+        torch.manual_seed(5)
+        tr = ref.Transformer(dim=64, depth=2, dim_head=64, heads=2, **kw)
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for n, prm in tr.named_parameters():
+                if ".to_gamma." in n or ".to_beta." in n:
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+                if n.endswith("gamma"):
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+        state = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+        b, n = 2, 40
+        x = torch.randn(b, n, 64, generator=g).requires_grad_(True)
+        cond = torch.randn(b, 32, generator=g).requires_grad_(True) if kw["adaptive_rmsnorm"] else None
+        mask = None
+        if use_mask:
+            mask = torch.ones(b, n, dtype=torch.bool)
+            mask[1, 31:] = False
+        dout = torch.randn(b, n, 64, generator=g)
+        y = tr(x, mask=mask, adaptive_rmsnorm_cond=cond)
+        (y * dout).sum().backward()
+        out[name] = dict(kw=kw, state=state, x=x.detach().clone(), cond=None if cond is None else cond.detach().clone(), mask=mask,
+                         dout=dout, y=y.detach().clone(), dx=x.grad.clone(), dcond=None if cond is None else cond.grad.clone(),
+                         grads={k: p.grad.detach().clone() for k, p in tr.named_parameters() if p.grad is not None})
+        print("transformer", name, float(y.norm()))
+    torch.save(out, os.path.join(HERE, "transformer.pt"))
+
+
 def gen_cfg1(ref):
     """BASELINE config 1/2: dim 512, depth 2, heads 16, B=2, N=1024.  Weights by the committed
     recipe oracle.restate.init_state_dict(seed=0) (too big to commit); only scalars/slices stored."""
@@ -179,7 +213,7 @@ def gen_cfg1(ref):
 
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
-    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "cfg1"]
+    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "transformer", "cfg1"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop,
-         "cfg1": gen_cfg1}[w](ref)
+         "transformer": gen_transformer, "cfg1": gen_cfg1}[w](ref)

@@ -88,3 +88,27 @@ def test_bucketed_allreduce_equals_full_batch_gradient(bucket_bytes):
     assert err < 1e-5 * max(scale, 1.0), res
     assert lo == 0 and hi == numel  # buckets cover the whole flat buffer
     assert nbuckets == (4 if bucket_bytes == 1 else 1)  # depth 2: head, 2 layers, embed -> 4 stages
+
+
+def test_warmup_cosine_schedule_matches_trainer_rule():
+    """WarmupCosineLR replays VoiceBoxTrainer's rule (trainer.py:231-253): manual linear warm-up written into the optimizer,
+    then torch's CosineAnnealingLR.step() once per step."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR
+
+    from voicebox_pytorch_amd.dp import WarmupCosineLR
+
+    for lr, init, warm, total in ((3e-4, 1e-5, 7, 40), (1e-4, 1e-5, 0, 25), (5e-4, 0.0, 3, 10)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=lr)
+        sched = CosineAnnealingLR(opt, T_max=total)
+        mine = WarmupCosineLR(lr, total, warm, init)
+        for step in range(total + 5):
+            if step < warm:  # trainer.py:241-247
+                for g in opt.param_groups:
+                    g["lr"] = init + (lr - init) * step / warm
+            else:
+                opt.step()
+                sched.step()
+            want = opt.param_groups[0]["lr"]
+            got = mine.rate_for_step(step)
+            assert abs(got - want) <= 1e-12 + 1e-9 * abs(want), (step, got, want)

@@ -139,6 +139,21 @@ def test_gateloop_state_dict_layout(golden):
     assert torch.equal(vb.transformer.layers[1][1].to_qkva[0].weight, g["state"]["transformer.layers.1.1.to_qkva.0.weight"])
 
 
+def test_standalone_transformer_state_dict(golden):
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("transformer")
+    for name, c in g.items():
+        tr = vbx.Transformer(dim=64, depth=2, dim_head=64, heads=2, **c["kw"])
+        mine = {k: tuple(v.shape) for k, v in tr.state_dict().items() if "inv_freq" not in k}
+        ref = {k: tuple(v.shape) for k, v in c["state"].items() if "inv_freq" not in k}
+        assert mine == ref, name
+        assert not tr.load_state_dict(c["state"], strict=False).unexpected_keys
+        if not torch.cuda.is_available():
+            with pytest.raises(Exception):  # no CPU fallback
+                tr(c["x"], mask=c["mask"], adaptive_rmsnorm_cond=c["cond"])
+
+
 def test_midpoint_tables_match_oracle_grid():
     """dt_i = t[i+1]-t[i] from the same fp32 linspace as the oracle: linspace(0,1,64) has several distinct dt."""
     t = torch.linspace(0, 1, 64)

@@ -93,6 +93,26 @@ def test_small_gateloop_model(golden):
     assert torch.allclose(torch.stack(loop, 1), closed, rtol=1e-9, atol=1e-9)
 
 
+def test_standalone_transformer(golden):
+    """restate.transformer (adaptive + plain RMSNorm, with/without registers and qk-norm) vs the reference's Transformer.forward."""
+    g = golden("transformer")
+    for name, c in g.items():
+        kw = c["kw"]
+        cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64, num_register_tokens=kw["num_register_tokens"],
+                          qk_norm=kw["attn_qk_norm"])
+        p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in c["state"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        cond = c["cond"].clone().requires_grad_(True) if c["cond"] is not None else None
+        y = restate.transformer(x, p, cfg, mask=c["mask"], cond=cond, pre="")
+        assert float((y - c["y"]).norm() / c["y"].norm()) < 1e-5, name
+        (y * c["dout"]).sum().backward()
+        assert float((x.grad - c["dx"]).norm() / c["dx"].norm()) < 2e-3, name
+        if cond is not None:
+            assert float((cond.grad - c["dcond"]).norm() / c["dcond"].norm()) < 2e-3, name
+        for k, ref in c["grads"].items():
+            assert float((p[k].grad - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-3, (name, k)
+
+
 def test_cfg1_loss(golden):
     """BASELINE config 1 (dim 512, depth 2, B=2, N=1024) on CPU: restatement vs reference scalars."""
     g = golden("cfg1")

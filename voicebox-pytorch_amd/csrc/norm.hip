@@ -14,7 +14,7 @@ template <int FWD_ROWS>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, long gb_stride,
                                                            u16* __restrict__ y, u16* __restrict__ y16, int B, int Np, int n0,
-                                                           int rpb, int D) {
+                                                           int rpb, int D, float* __restrict__ y32) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
           }
           if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
           if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
+          if (y32) reinterpret_cast<float4*>(y32 + ri * D)[c] = o;
         }
       }
     }
@@ -306,23 +307,31 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
-                               void* y_f16, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
-  VBX_REQUIRE(x && gamma && (y_bf16 || y_f16), "vbx_rmsnorm_fwd: null pointer");
+static int rmsnorm_fwd_launch(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16, void* y_f16,
+                              float* y_f32, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
+  VBX_REQUIRE(x && gamma && (y_bf16 || y_f16 || y_f32), "vbx_rmsnorm_fwd: null pointer");
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_fwd: bad row range");
   const long rows = (long)B * rows_per_batch;
-  static const int rpw = getenv("VBX_RMS_ROWS") ? atoi(getenv("VBX_RMS_ROWS")) : 1;  // A/B: rows per wave in flight
+  static const int rpw = getenv("VBX_RMS_ROWS") ? atoi(getenv("VBX_RMS_ROWS")) : 1;  // A/B: rows per wave in flight (2: 9 -> 14 us)
   int blocks = cdiv(rows, 4 * (rpw == 2 ? 2 : 1));
   if (blocks > 4096) blocks = 4096;
   if (rpw == 2)
     hipLaunchKernelGGL(rmsnorm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
+                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32);
   else
     hipLaunchKernelGGL(rmsnorm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D);
+                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32);
   VBX_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
+                               void* y_f16, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
+  return rmsnorm_fwd_launch(x, gamma, beta, gb_stride, y_bf16, y_f16, nullptr, B, Np, n0, rows_per_batch, D, stream);
+}
+extern "C" int vbx_rmsnorm_fwd_f32(const float* x, const float* gamma, const float* beta, long gb_stride, float* y_f32, int B,
+                                   int Np, int n0, int rows_per_batch, int D, void* stream) {
+  return rmsnorm_fwd_launch(x, gamma, beta, gb_stride, nullptr, nullptr, y_f32, B, Np, n0, rows_per_batch, D, stream);
 }
 
 extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,

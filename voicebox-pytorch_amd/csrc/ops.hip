@@ -98,6 +98,21 @@ __global__ __launch_bounds__(256) void convpos_fwd_kernel(const float* __restric
   }
 }
 
+// standalone Transformer.forward (voicebox_pytorch.py:412-431): rows n >= R of the residual stream = the caller's x
+__global__ void stack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int N, int R, int D, int to_stack) {
+  // to_stack = 1: dst[b, R+n, :] = src[b, n, :] ([B,N,D] -> [B,N+R,D]);  0: dst[b, n, :] = src[b, R+n, :]
+  const long total = (long)B * N * D / 4;
+  const int D4 = D / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / D4;
+    const int c = (int)(i - row * D4);
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const long wide = ((long)b * (N + R) + R + n) * D4 + c, narrow = i;
+    if (to_stack) reinterpret_cast<float4*>(dst)[wide] = reinterpret_cast<const float4*>(src)[narrow];
+    else reinterpret_cast<float4*>(dst)[narrow] = reinterpret_cast<const float4*>(src)[wide];
+  }
+}
+
 __global__ void regs_fill_kernel(const float* __restrict__ reg, float* __restrict__ xs, int B, int Np, int R, int D) {
   const long total = (long)B * R * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -837,6 +852,28 @@ extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias
   VBX_LAUNCH_CHECK();
   if (R > 0) {
     hipLaunchKernelGGL(regs_fill_kernel, dim3(grid_for((long)B * R * D)), dim3(256), 0, ST, reg, xs, B, N + R, R, D);
+    VBX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream) {
+  VBX_REQUIRE(x && xs && B > 0 && N > 0 && R >= 0 && D % 4 == 0 && (R == 0 || reg), "vbx_stack_input: bad args");
+  hipLaunchKernelGGL(stack_rows_kernel, dim3(grid_for((long)B * N * D / 4)), dim3(256), 0, ST, x, xs, B, N, R, D, 1);
+  VBX_LAUNCH_CHECK();
+  if (R > 0) {
+    hipLaunchKernelGGL(regs_fill_kernel, dim3(grid_for((long)B * R * D)), dim3(256), 0, ST, reg, xs, B, N + R, R, D);
+    VBX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int vbx_stack_input_bwd(const float* dxs, float* dx, float* dreg, int B, int N, int R, int D, void* stream) {
+  VBX_REQUIRE(dxs && dx && B > 0 && N > 0 && R >= 0 && D % 4 == 0, "vbx_stack_input_bwd: bad args");
+  hipLaunchKernelGGL(stack_rows_kernel, dim3(grid_for((long)B * N * D / 4)), dim3(256), 0, ST, dxs, dx, B, N, R, D, 0);
+  VBX_LAUNCH_CHECK();
+  if (R > 0 && dreg) {
+    hipLaunchKernelGGL(dreg_kernel, dim3(cdiv((long)R * D, 256)), dim3(256), 0, ST, dxs, dreg, B, N + R, R, D);
     VBX_LAUNCH_CHECK();
   }
   return 0;

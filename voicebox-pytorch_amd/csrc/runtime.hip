@@ -230,13 +230,18 @@ int check_model(const vbx_model* m) {
   const long DT = (long)m->D * m->Th;
   for (int l = 0; l < m->L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    if (m->plain_norm) continue;
     VBX_REQUIRE(o[VBX_L_B1W] == o[VBX_L_G1W] + DT && o[VBX_L_G2W] == o[VBX_L_B1W] + DT && o[VBX_L_B2W] == o[VBX_L_G2W] + DT,
                 "vbx_model: adaLN weights of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
     VBX_REQUIRE(o[VBX_L_B1B] == o[VBX_L_G1B] + m->D && o[VBX_L_G2B] == o[VBX_L_B1B] + m->D && o[VBX_L_B2B] == o[VBX_L_G2B] + m->D,
                 "vbx_model: adaLN biases of layer %d are not contiguous in (g1,b1,g2,b2) order", l);
-    VBX_REQUIRE(!m->gateloop || o[VBX_L_GLLNB] == o[VBX_L_GLLNW] + m->D,
+  }
+  for (int l = 0; l < m->L && m->gateloop; l++) {
+    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+    VBX_REQUIRE(o[VBX_L_GLLNB] == o[VBX_L_GLLNW] + m->D,
                 "vbx_model: GateLoop post-LayerNorm weight and bias of layer %d are not contiguous", l);
   }
+  VBX_REQUIRE(!m->plain_norm || m->stack_only, "vbx_model: plain_norm is only used by the standalone stack (VoiceBox is adaptive)");
   return 0;
 }
 
@@ -289,12 +294,16 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
   carve_wpack(m, w);
   const float* P = m->params;
   const long* G = m->off;
-  CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, d.D, 2 * d.D, 0, 0, stream));
-  CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, d.D, d.D, 0, 0, stream));
+  if (!m->stack_only) {
+    CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, d.D, 2 * d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, d.D, d.D, 0, 0, stream));
+  }
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
-    CK(vbx_pack_weight(P + o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, 4 * d.D, d.Th, 0, 0, stream));
-    CK(vbx_pack_bias(P + o[VBX_L_G1B], 4 * d.D, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0, stream));
+    if (!m->plain_norm) {
+      CK(vbx_pack_weight(P + o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, 4 * d.D, d.Th, 0, 0, stream));
+      CK(vbx_pack_bias(P + o[VBX_L_G1B], 4 * d.D, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0, stream));
+    }
     CK(vbx_pack_weight(P + o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, w.layer[l].qkvh, 3 * d.I, d.D, 0, 0, stream));
     CK(vbx_pack_weight(P + o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, w.layer[l].outh, d.D, d.I, 0, 0, stream));
     CK(vbx_pack_weight(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, w.layer[l].w1h, 2 * d.Fp, d.D, 1, d.F, stream));
@@ -307,7 +316,9 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
 
 extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream) {
   CK(check_model(m));
-  VBX_REQUIRE(io && io->x && io->cond && io->times, "vbx_model_forward: null io field");
+  VBX_REQUIRE(io && io->x, "vbx_model_forward: null io field");
+  VBX_REQUIRE(m->stack_only ? ((m->plain_norm || io->cond) && io->pred && !io->target) : (io->cond && io->times),
+              "vbx_model_forward: null io field");
   VBX_REQUIRE(!io->target || (io->loss_mask && io->loss), "vbx_model_forward: target needs loss_mask and loss");
   VBX_REQUIRE((io->attn_mask == nullptr) == (io->attn_mask_p == nullptr), "vbx_model_forward: attn_mask and attn_mask_p go together");
   hipStream_t st = (hipStream_t)stream;
@@ -320,6 +331,11 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   const long* G = m->off;
   const bool tr = m->training != 0;
 
+  if (m->stack_only) {
+    // standalone Transformer.forward: registers + x, the caller's condition drives the adaLN projections  (:417-431, :449-451)
+    CK(vbx_stack_input(io->x, d.R ? P + G[VBX_P_REG] : nullptr, a.xs[0], d.B, d.N, d.R, d.D, stream));
+    if (!m->plain_norm) CK(vbx_adaln_proj_fwd(io->cond, w.adah, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
+  } else {
   // to_embed(cat(x, cond * ~cond_mask))   (voicebox_pytorch.py:1035,1075-1078)
   CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
   CK(gemm_nt(a.embed_inh, 2 * d.D, w.embh, 2 * d.D, (int)d.M0, d.D, 2 * d.D, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
@@ -331,6 +347,7 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   CK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a.four, a.pre, a.temb, d.B, d.D,
                         d.Th, stream));
   CK(vbx_adaln_proj_fwd(a.temb, w.adah, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
+  }
 
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
@@ -350,7 +367,8 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
       CK(vbx_layernorm_fwd(y.gls, P + o[VBX_L_GLLNW], P + o[VBX_L_GLLNB], x0, x_in, d.M, d.D, 1e-5f, stream));
     }
     // attn_prenorm -> to_qkv (+qk-norm, rotary) -> Attend -> to_out + residual   (:468-469, :317-333)
-    CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, y.hn1h, d.B, d.Np, 0, d.Np, d.D, stream));
+    if (m->plain_norm) CK(vbx_rmsnorm_fwd(x_in, P + o[VBX_L_N1G], nullptr, 0, y.hn1, y.hn1h, d.B, d.Np, 0, d.Np, d.D, stream));
+    else CK(vbx_rmsnorm_fwd(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, y.hn1h, d.B, d.Np, 0, d.Np, d.D, stream));
     vbx_gemm_desc g{};
     g.mode = VBX_GEMM_NT; g.epilogue = VBX_EPI_QKV; g.M = (int)d.M; g.N = 3 * d.I; g.K = d.D; g.lda = d.D; g.ldb = d.D;
     g.A = y.hn1h; g.B = w.layer[l].qkvh; g.f16 = 1; g.Np = d.Np; g.H = d.H; g.qk_scale = m->qk_norm ? 8.0f : 0.0f;
@@ -362,12 +380,16 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
     CK(gemm_nt(y.oh, d.I, w.layer[l].outh, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, nullptr, st));
     // ff_prenorm -> FeedForward (GEGLU) + residual   (:471-472, :337-349)
-    CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
+    if (m->plain_norm) CK(vbx_rmsnorm_fwd(x_mid, P + o[VBX_L_N2G], nullptr, 0, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
+    else CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
     CK(gemm_nt(y.hn2h, d.D, w.layer[l].w1h, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.gh, d.Fp, w.layer[l].b1, nullptr,
                tr ? y.h1 : nullptr, y.g, st));
     CK(gemm_nt(y.gh, d.Fp, w.layer[l].w2h, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
                nullptr, st));
   }
+  if (m->stack_only)  // strip registers, final RMSNorm -> fp32 output   (:476-479)
+    return vbx_rmsnorm_fwd_f32(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, io->pred, d.B, d.Np, d.R, d.N, d.D,
+                               stream);
   // strip registers, final RMSNorm, to_pred   (:476-479, :1092)
   CK(vbx_rmsnorm_fwd(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, a.hfh, d.B, d.Np, d.R, d.N, d.D, stream));
   float* pred = io->pred ? io->pred : a.pred;
@@ -378,7 +400,8 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
 
 extern "C" int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, const float* gscale, void* stream) {
   CK(check_model(m));
-  VBX_REQUIRE(m->training && m->grads && io && io->target && io->loss_mask, "vbx_model_backward_head: needs a training forward");
+  VBX_REQUIRE(m->training && m->grads && io && io->target && (m->stack_only || io->loss_mask),
+              "vbx_model_backward_head: needs a training forward");
   hipStream_t st = (hipStream_t)stream;
   const Dims d = dims_of(m);
   WPack w;
@@ -388,10 +411,15 @@ extern "C" int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, con
   const float* P = m->params;
   float* Gd = m->grads;
   const long* G = m->off;
-  const float* pred = io->pred ? io->pred : a.pred;
-  CK(vbx_masked_mse_bwd(pred, io->target, io->loss_mask, a.per_b, gscale, nullptr, a.dpb, d.B, d.N, d.D, stream));
-  CK(wgrad(a.dpb, d.D, a.hf, d.D, d.D, d.D, d.M0, a.slabs, Gd + G[VBX_P_PREDW], d.D, d.D, 0, 0, st));
-  CK(gemm_nn_bf16(a.dpb, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, a.dhn, d.D, st));
+  if (m->stack_only) {
+    // io->target = d(output) fp32 [B,N,D] -> bf16 operand of the final-norm backward
+    CK(vbx_pack_weight(io->target, (int)d.M0, d.D, a.dhn, nullptr, (int)d.M0, d.D, 0, 0, stream));
+  } else {
+    const float* pred = io->pred ? io->pred : a.pred;
+    CK(vbx_masked_mse_bwd(pred, io->target, io->loss_mask, a.per_b, gscale, nullptr, a.dpb, d.B, d.N, d.D, stream));
+    CK(wgrad(a.dpb, d.D, a.hf, d.D, d.D, d.D, d.M0, a.slabs, Gd + G[VBX_P_PREDW], d.D, d.D, 0, 0, st));
+    CK(gemm_nn_bf16(a.dpb, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, a.dhn, d.D, st));
+  }
   // gradient wrt the last residual snapshot: zero at the register rows, final-norm backward elsewhere
   if (hipMemsetAsync(a.dx, 0, (size_t)d.M * d.D * sizeof(float), st) != hipSuccess ||
       hipMemsetAsync(a.dxb, 0, (size_t)d.M * d.D * sizeof(u16), st) != hipSuccess) {
@@ -434,9 +462,15 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
-  CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
-                     stream));
-  CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  if (m->plain_norm) {
+    CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N2G], d.D, 0, stream));
+  } else {
+    CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
+                       stream));
+    CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  }
   CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
@@ -453,8 +487,14 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
-  CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
-  CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  if (m->plain_norm) {
+    CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N1G], d.D, 0, stream));
+  } else {
+    CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  }
   if (m->gateloop) {
     // ---- GateLoop: a.dx is the gradient of x_gl = LayerNorm(s) + x0; the residual branch stays in a.dx
     CK(vbx_layernorm_bwd(y.gls, P + o[VBX_L_GLLNW], a.dx, a.gl_ds, a.npart, d.B, d.Np, d.D, 1e-5f, stream));
@@ -467,15 +507,17 @@ extern "C" int vbx_model_backward_layer(const vbx_model* m, const vbx_io* io, in
     CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
     CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_GLG], d.D, 0, stream));
   }
+  if (m->plain_norm) return 0;
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
-  CK(vbx_adaln_proj_bwd(a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
+  CK(vbx_adaln_proj_bwd(m->stack_only ? io->cond : a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
                         a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));
   return 0;
 }
 
 extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream) {
   CK(check_model(m));
-  VBX_REQUIRE(m->training && m->grads && io && io->times, "vbx_model_backward_embed: needs a training forward");
+  VBX_REQUIRE(m->training && m->grads && io && (m->stack_only ? io->dx != nullptr : io->times != nullptr),
+              "vbx_model_backward_embed: needs a training forward");
   hipStream_t st = (hipStream_t)stream;
   const Dims d = dims_of(m);
   WPack w;
@@ -485,6 +527,15 @@ extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, vo
   const float* P = m->params;
   float* Gd = m->grads;
   const long* G = m->off;
+  if (m->stack_only) {
+    CK(vbx_stack_input_bwd(a.dx, io->dx, d.R ? Gd + G[VBX_P_REG] : nullptr, d.B, d.N, d.R, d.D, stream));
+    if (!m->plain_norm && io->dcond &&
+        hipMemcpyAsync(io->dcond, a.dtemb, (size_t)d.B * d.Th * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      vbx_set_error("vbx_model_backward_embed: copy of d(cond) failed");
+      return VBX_EINVAL;
+    }
+    return 0;
+  }
   CK(vbx_convpos_bwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, a.dx, a.dpre, a.de, a.deb, a.wpart,
                      d.R ? Gd + G[VBX_P_REG] : nullptr, d.B, d.N, d.R, d.D, d.ks, stream));
   CK(vbx_conv_wgrad_finalize(a.wpart, vbx_convpos_bwd_chunks(d.B, d.N), d.D, d.ks, Gd + G[VBX_P_CONVW], Gd + G[VBX_P_CONVB], stream));
@@ -511,12 +562,16 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
     s.rowmap = rowmap; s.F = F;
     ps.push_back(s);
   };
-  add(G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, nullptr, 2 * d.D, 0, 0);
-  add(G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
+  if (!m->stack_only) {
+    add(G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, nullptr, 2 * d.D, 0, 0);
+    add(G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
+  }
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
-    add(o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, nullptr, d.Th, 0, 0);
-    add(o[VBX_L_G1B], 1, 4 * d.D, nullptr, nullptr, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0);
+    if (!m->plain_norm) {
+      add(o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, nullptr, d.Th, 0, 0);
+      add(o[VBX_L_G1B], 1, 4 * d.D, nullptr, nullptr, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0);
+    }
     add(o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, w.layer[l].qkvh, nullptr, d.D, 0, 0);
     add(o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, w.layer[l].outh, nullptr, d.I, 0, 0);
     add(o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, w.layer[l].w1h, nullptr, d.D, 1, d.F);

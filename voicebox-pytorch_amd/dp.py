@@ -65,11 +65,42 @@ class GradBucketReducer:
         self.works = []
 
 
+class WarmupCosineLR:
+    """The learning-rate rule of VoiceBoxTrainer.train_step (trainer.py:231-253, scheduler built at :144-145): linear warm-up
+    `initial_lr + (lr - initial_lr) * step / num_warmup_steps` while `step < num_warmup_steps`, afterwards one
+    `CosineAnnealingLR(T_max=num_train_steps, eta_min=0).step()` per training step -- torch's *recursive* update applied to
+    whatever rate the warm-up left in the optimizer, which is what this class replays on the host (pure Python floats)."""
+
+    def __init__(self, lr, num_train_steps, num_warmup_steps=0, initial_lr=1e-5):
+        import math
+
+        self._math = math
+        self.lr, self.initial_lr = float(lr), float(initial_lr)
+        self.T, self.warm = int(num_train_steps), int(num_warmup_steps or 0)
+        self.cur = float(lr)   # the optimizer's param_group['lr']
+        self.sched_epoch = 0   # CosineAnnealingLR.last_epoch
+
+    def rate_for_step(self, step):
+        """Call once per training step with the 0-based step counter; returns the rate that step must use."""
+        m = self._math
+        if step < self.warm:
+            self.cur = self.initial_lr + (self.lr - self.initial_lr) * step / self.warm
+        else:
+            self.sched_epoch += 1
+            t, T = self.sched_epoch, self.T
+            if (t - 1 - T) % (2 * T) == 0:   # torch.optim.lr_scheduler.CosineAnnealingLR.get_lr, eta_min = 0
+                self.cur = self.cur + self.lr * (1 - m.cos(m.pi / T)) / 2
+            else:
+                self.cur = (1 + m.cos(m.pi * t / T)) / (1 + m.cos(m.pi * (t - 1) / T)) * self.cur
+        return self.cur
+
+
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
-                 bucket_bytes=64 << 20, broadcast_params=True):
+                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None):
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.lr_schedule = lr_schedule  # e.g. WarmupCosineLR; an explicit `lr=` passed to step() wins
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -122,6 +153,8 @@ class TrainStep:
         red.finish()
         # --- clip (global norm of the rank-averaged gradient) + Adam, all on device, no host sync
         n = self.gflat.numel()
+        if lr is None and self.lr_schedule is not None:
+            lr = self.lr_schedule.rate_for_step(self.steps)
         self.steps += 1
         _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())

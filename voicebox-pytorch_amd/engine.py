@@ -12,19 +12,20 @@ from ._lib import P, I, F
 # enum mirrors of include/vbx.h
 G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW"]
 L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B",
-           "GLG", "GLW", "GLLNW", "GLLNB"]
+           "GLG", "GLW", "GLLNW", "GLLNB", "N1G", "N2G"]
 NG, NL = len(G_NAMES), len(L_NAMES)
 
 
 class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
-                ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I)]
+                ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
+                ("stack_only", I), ("plain_norm", I)]
 
 
 class VbxIO(C.Structure):
     _fields_ = [("x", P), ("cond", P), ("cond_mask", P), ("attn_mask", P), ("attn_mask_p", P), ("loss_mask", P),
-                ("times", P), ("target", P), ("pred", P), ("loss", P)]
+                ("times", P), ("target", P), ("pred", P), ("loss", P), ("dx", P), ("dcond", P)]
 
 
 class VbxAdamSeg(C.Structure):
@@ -86,7 +87,8 @@ class FlatParams:
         order = ["PREDW", "FNG"]
         for l in reversed(range(depth)):
             order += [f"L{l}.{n}" for n in L_NAMES if f"L{l}.{n}" in named_slots]
-        order += ["EMBW", "EMBB", "CONVW", "CONVB", "REG", "SINW", "T1W", "T1B"]
+        tail = ["EMBW", "EMBB", "CONVW", "CONVB", "REG", "SINW", "T1W", "T1B"]
+        order += tail
         self.order = [s for s in order if s in named_slots]
         self.slots = named_slots
         self.depth = depth
@@ -101,7 +103,8 @@ class FlatParams:
         # stage boundaries (in floats) for bucketed gradient exchange: [head][layer L-1]...[layer 0][embed]
         self.stage_ranges = []
         first_layer_slot = lambda l: next(s for s in self.order if s.startswith(f"L{l}."))
-        bounds = [0] + [self.offsets[first_layer_slot(l)] for l in reversed(range(depth))] + [self.offsets["EMBW"], off]
+        first_tail = next((self.offsets[t] for t in tail if t in self.offsets), off)  # a bare Transformer has REG at most
+        bounds = [0] + [self.offsets[first_layer_slot(l)] for l in reversed(range(depth))] + [first_tail, off]
         self.stage_ranges = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
 
     def is_current(self):
@@ -156,6 +159,8 @@ class Engine:
         m.attn_scale = float(cfg["attn_scale"])
         m.training = 1 if training else 0
         m.gateloop = 1 if cfg.get("gateloop") else 0
+        m.stack_only = 1 if cfg.get("stack_only") else 0
+        m.plain_norm = 1 if cfg.get("plain_norm") else 0
         self.off_table = flat.offset_table()
         m.off = C.cast(self.off_table, P)
         self.rot_cos, self.rot_sin = rotary_tables(N, cfg["R"], 64, cfg["theta"], device)
@@ -233,6 +238,47 @@ class Engine:
         self.generation += 1
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
         return self.loss if target is not None else pred
+
+    # -- standalone Transformer.forward / backward (vbx_model.stack_only)
+    def forward_stack(self, x, cond=None, attn_mask=None):
+        """x (B,N,D) fp32, cond (B,Th) fp32 or None (plain RMSNorm), attn_mask (B,N) bool or None -> (B,N,D) fp32."""
+        self.bind_params()
+        B, N, D, R = self.B, self.N, self.cfg["D"], self.cfg["R"]
+        x = x.contiguous()
+        cond = cond.contiguous() if cond is not None else None
+        am = amp = None
+        if attn_mask is not None:
+            am = attn_mask.to(torch.uint8).contiguous()
+            amp = torch.cat((torch.ones(B, R, dtype=torch.uint8, device=am.device), am), dim=1).contiguous() if R else am
+        out = torch.empty(B, N, D, dtype=torch.float32, device=self.device)
+        io = self.io
+        io.x, io.cond = x.data_ptr(), (cond.data_ptr() if cond is not None else None)
+        io.cond_mask = io.times = io.target = io.loss_mask = io.loss = io.dx = io.dcond = None
+        io.attn_mask = am.data_ptr() if am is not None else None
+        io.attn_mask_p = amp.data_ptr() if amp is not None else None
+        io.pred = out.data_ptr()
+        self._keep = (x, cond, am, amp, out)
+        self.generation += 1
+        _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
+        return out
+
+    def backward_stack(self, gflat, dout):
+        """dout (B,N,D) fp32 -> (dx (B,N,D), dcond (B,Th) or None); parameter gradients land in gflat."""
+        assert self.training
+        dout = dout.to(torch.float32).contiguous()
+        dx = torch.empty_like(dout)
+        dcond = None if self.cfg.get("plain_norm") else torch.empty(self.B, self.cfg["Th"], dtype=torch.float32, device=self.device)
+        io = self.io
+        io.target, io.dx, io.dcond = dout.data_ptr(), dx.data_ptr(), (dcond.data_ptr() if dcond is not None else None)
+        self.m.grads = gflat.data_ptr()
+        st, l = _lib.current_stream(), _rt()
+        _check(l.vbx_model_backward_head(C.byref(self.m), C.byref(io), None, st), "vbx_model_backward_head")
+        for layer in reversed(range(self.cfg["L"])):
+            _check(l.vbx_model_backward_layer(C.byref(self.m), C.byref(io), layer, st), "vbx_model_backward_layer")
+        _check(l.vbx_model_backward_embed(C.byref(self.m), C.byref(io), st), "vbx_model_backward_embed")
+        self.m.grads = None
+        io.target = io.dx = io.dcond = None
+        return dx, dcond
 
     def replay_forward(self):
         """Re-issue the last forward with the same (static) buffers -- the body of the captured ODE step."""

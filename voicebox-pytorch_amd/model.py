@@ -169,10 +169,30 @@ class GateLoop(nn.Module):
         self.maybe_post_ln = nn.LayerNorm(dim)
 
 
+class _StackFn(torch.autograd.Function):
+    """Transformer.forward as ONE autograd node over the native stack entry points (vbx_model.stack_only)."""
+
+    @staticmethod
+    def forward(ctx, tr, eng, x, cond, mask, *params):
+        out = eng.forward_stack(x, cond, mask)
+        ctx.tr, ctx.eng, ctx.gen, ctx.has_cond = tr, eng, eng.generation, cond is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tr, eng = ctx.tr, ctx.eng
+        if eng.generation != ctx.gen:
+            raise RuntimeError("Transformer: another forward of the same (batch, frames) shape ran before this backward; the "
+                               "activation arena holds one training forward at a time")
+        gflat = torch.zeros(tr._flat.numel, dtype=torch.float32, device=eng.device)
+        dx, dcond = eng.backward_stack(gflat, dout)
+        return (None, None, dx, dcond if ctx.has_cond else None, None) + tuple(tr._flat.grad_views(gflat))
+
+
 class Transformer(nn.Module):
-    """voicebox_pytorch.py:353-479.  Holds the stack's parameters with the reference's module tree.  The
-    compute runs inside VoiceBox (the native runtime fuses the whole stack); a standalone
-    Transformer.forward is a "next" row (SURVEY 8(f) #4) and raises for now."""
+    """voicebox_pytorch.py:353-479, same module tree / state-dict keys.  Inside VoiceBox the stack runs fused in
+    vbx_model_forward; called on its own (`Transformer.forward(x, mask, adaptive_rmsnorm_cond)`, :412-479) it runs the same
+    native layer sequence through the stack-only mode of the runtime (registers + x in, final RMSNorm out)."""
 
     def __init__(self, dim, *, depth, dim_head=64, heads=8, ff_mult=4, attn_dropout=0., ff_dropout=0.,
                  num_register_tokens=0., attn_flash=False, adaptive_rmsnorm=False, adaptive_rmsnorm_cond_dim_in=None,
@@ -189,6 +209,17 @@ class Transformer(nn.Module):
         if self.has_register_tokens:
             self.register_tokens = nn.Parameter(torch.randn(int(num_register_tokens), dim))
         self.adaptive_rmsnorm = adaptive_rmsnorm
+        if dim_head != 64:
+            raise NotImplementedError("the HIP kernels are built for dim_head == 64")
+        if dim % 64 != 0 or dim > 2048 or heads % 2 != 0:
+            raise NotImplementedError("dim must be a multiple of 64 (<= 2048) and heads even")
+        cond_dim = default(adaptive_rmsnorm_cond_dim_in, dim)  # AdaptiveRMSNorm: cond_dim = default(cond_dim, dim) (:256)
+        self._cfg = dict(D=dim, H=heads, L=depth, F=int(dim * ff_mult * 2 / 3), Th=cond_dim if adaptive_rmsnorm else 8,
+                         R=int(num_register_tokens), ksize=31, qk_norm=bool(attn_qk_norm),
+                         attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
+                         gateloop=bool(use_gateloop_layers), stack_only=True, plain_norm=not adaptive_rmsnorm)
+        self._flat = None
+        self._engines = {}
         norm = (lambda: AdaptiveRMSNorm(dim, cond_dim=adaptive_rmsnorm_cond_dim_in)) if adaptive_rmsnorm else (lambda: RMSNorm(dim))
         self.skip_connect_scale = default(skip_connect_scale, 2 ** -0.5)
         for _ in range(depth):
@@ -202,9 +233,71 @@ class Transformer(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def forward(self, x, mask=None, adaptive_rmsnorm_cond=None):
-        raise NotImplementedError("standalone Transformer.forward is not built yet; use VoiceBox (the stack runs fused "
-                                  "inside the native runtime)")
+    # ---- native plumbing of the standalone call (VoiceBox owns its own flat buffer over the same parameters)
+    def _layer_slots(self, s):
+        for l, layer in enumerate(self.layers):
+            _, gl, n1, attn, n2, ff = layer
+            p = f"L{l}."
+            if gl is not None:
+                s[p + "GLG"], s[p + "GLW"] = gl.norm.gamma, gl.to_qkva[0].weight
+                s[p + "GLLNW"], s[p + "GLLNB"] = gl.maybe_post_ln.weight, gl.maybe_post_ln.bias
+            if self.adaptive_rmsnorm:
+                s[p + "G1W"], s[p + "G1B"] = n1.to_gamma.weight, n1.to_gamma.bias
+                s[p + "B1W"], s[p + "B1B"] = n1.to_beta.weight, n1.to_beta.bias
+                s[p + "G2W"], s[p + "G2B"] = n2.to_gamma.weight, n2.to_gamma.bias
+                s[p + "B2W"], s[p + "B2B"] = n2.to_beta.weight, n2.to_beta.bias
+            else:
+                s[p + "N1G"], s[p + "N2G"] = n1.gamma, n2.gamma
+            if attn.qk_norm:
+                s[p + "QG"], s[p + "KG"] = attn.q_norm.gamma, attn.k_norm.gamma
+            s[p + "QKVW"], s[p + "OUTW"] = attn.to_qkv.weight, attn.to_out.weight
+            s[p + "FF1W"], s[p + "FF1B"], s[p + "FF2W"], s[p + "FF2B"] = ff[0].weight, ff[0].bias, ff[3].weight, ff[3].bias
+        return s
+
+    def _slots(self):
+        s = {"FNG": self.final_norm.gamma}
+        if self.has_register_tokens:
+            s["REG"] = self.register_tokens
+        return self._layer_slots(s)
+
+    def flat_params(self):
+        if self._flat is None:
+            self._flat = FlatParams(self._slots(), self._cfg["L"])
+        if not self._flat.is_current():
+            self._flat.slots = self._slots()
+            self._flat.flatten()
+            self._engines.clear()
+        return self._flat
+
+    def forward(self, x, mask=None, adaptive_rmsnorm_cond=None):  # voicebox_pytorch.py:412-479
+        if self.adaptive_rmsnorm:
+            assert exists(adaptive_rmsnorm_cond), "adaptive_rmsnorm = True needs adaptive_rmsnorm_cond (batch, cond_dim)"
+        else:
+            assert not exists(adaptive_rmsnorm_cond), "this Transformer was built with adaptive_rmsnorm = False"
+        fp = self.flat_params()
+        dev = fp.flat.device
+        if dev.type != "cuda":
+            raise _lib.VbxError("Transformer compute runs only on an MI355X (gfx950) through libvbx_hip.so; "
+                                f"parameters are on '{dev}' and there is no CPU fallback")
+        B, N, D = x.shape
+        assert D == self._cfg["D"]
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                or (exists(adaptive_rmsnorm_cond) and adaptive_rmsnorm_cond.requires_grad))
+        key = (B, N, bool(training))
+        eng = self._engines.get(key)
+        if eng is None:
+            if len(self._engines) >= 4:
+                self._engines.pop(next(iter(self._engines)))
+            eng = Engine(self._cfg, fp, B, N, training, dev)
+            self._engines[key] = eng
+        x32 = x.to(dev, torch.float32)
+        c32 = adaptive_rmsnorm_cond.to(dev, torch.float32) if exists(adaptive_rmsnorm_cond) else None
+        if exists(c32):
+            assert c32.shape == (B, self._cfg["Th"]), (tuple(c32.shape), (B, self._cfg["Th"]))
+        m = mask.to(dev) if exists(mask) else None
+        if not training:
+            return eng.forward_stack(x32, c32, m)
+        return _StackFn.apply(self, eng, x32, c32, m, *[fp.slots[s] for s in fp.order])
 
 
 # --------------------------------------------------------------------------------------- VoiceBox
@@ -285,20 +378,7 @@ class VoiceBox(nn.Module):
              "CONVB": self.conv_embed.dw_conv1d[0].bias, "FNG": t.final_norm.gamma, "PREDW": self.to_pred.weight}
         if t.has_register_tokens:
             s["REG"] = t.register_tokens
-        for l, layer in enumerate(t.layers):
-            _, gl, n1, attn, n2, ff = layer
-            p = f"L{l}."
-            if gl is not None:
-                s[p + "GLG"], s[p + "GLW"] = gl.norm.gamma, gl.to_qkva[0].weight
-                s[p + "GLLNW"], s[p + "GLLNB"] = gl.maybe_post_ln.weight, gl.maybe_post_ln.bias
-            s[p + "G1W"], s[p + "G1B"] = n1.to_gamma.weight, n1.to_gamma.bias
-            s[p + "B1W"], s[p + "B1B"] = n1.to_beta.weight, n1.to_beta.bias
-            s[p + "G2W"], s[p + "G2B"] = n2.to_gamma.weight, n2.to_gamma.bias
-            s[p + "B2W"], s[p + "B2B"] = n2.to_beta.weight, n2.to_beta.bias
-            if attn.qk_norm:
-                s[p + "QG"], s[p + "KG"] = attn.q_norm.gamma, attn.k_norm.gamma
-            s[p + "QKVW"], s[p + "OUTW"] = attn.to_qkv.weight, attn.to_out.weight
-            s[p + "FF1W"], s[p + "FF1B"], s[p + "FF2W"], s[p + "FF2B"] = ff[0].weight, ff[0].bias, ff[3].weight, ff[3].bias
+        t._layer_slots(s)
         return s
 
     def flat_params(self):
