@@ -137,6 +137,17 @@ int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_
                          void* out_bf16 /* optional copy: wgrad operand */, int B, int N, int D, void* stream);
 /* ConvPositionEmbed + residual + register tokens (voicebox_pytorch.py:220-233,1080,422-425):
  * xs[b, R+n, :] = e[b,n,:] + mask*gelu(conv(mask*e)[b,n,:] + bias);  xs[b, r<R, :] = reg[r,:]. */
+/* text-conditioned embed input (condition_on_text = True, voicebox_pytorch.py:1035-1076):
+ * out[b*N+n, :] = [ x | cond_emb | cond' ] as fp16 (+bf16), width 2*D + E, with
+ *   cond'    = drop[b] ? null_cond : cond * ~cond_mask                       (:1035, :1043-1048; drop_mask may be NULL)
+ *   cond_emb = table[drop[b] ? null_id : ids[b, .]] resized from T tokens to N frames by interpolate_1d (:89-107, :1057-1066):
+ *              F.interpolate bilinear, align_corners=False (identity when T == N).
+ * vbx_cond_emb_bwd scatters d(cond_emb) (bf16 [B*N, E], row stride ld) into the table gradient with fp32 atomics. */
+int vbx_pack_embed_input_text(const float* x, const float* cond, const uint8_t* cond_mask, const uint8_t* drop_mask,
+                              const float* null_cond, const long* ids, int T, const float* table, int E, long null_id,
+                              void* out_f16, void* out_bf16, int B, int N, int D, void* stream);
+int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, int T, const uint8_t* drop_mask, long null_id,
+                     float* gtable, int B, int N, int E, void* stream);
 /* standalone Transformer.forward (voicebox_pytorch.py:417-431, :476-477): residual stream [B,N+R,D] = register tokens (rows
  * n < R) followed by x [B,N,D]; backward: dx = rows n >= R of dxs, dreg[R,D] = sum over the batch of rows n < R. */
 int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream);
@@ -262,7 +273,8 @@ int vbx_clip_coef(const float* sumsq, float max_norm, float inv_world, float* co
  * The caller (Python) owns three arenas: flat fp32 parameters (+ same-layout gradients), the packed
  * bf16 weight arena and the activation arena (sizes from the *_bytes queries). */
 enum { VBX_P_SINW = 0, VBX_P_T1W, VBX_P_T1B, VBX_P_EMBW, VBX_P_EMBB, VBX_P_CONVW, VBX_P_CONVB, VBX_P_REG, VBX_P_FNG,
-       VBX_P_PREDW, VBX_NG };
+       VBX_P_PREDW,
+       VBX_P_CEMB /* to_cond_emb.weight [num_cond_tokens + 1, E], read only when vbx_model.E > 0 */, VBX_NG };
 /* per layer; the four adaLN weights, and the four adaLN biases, must be contiguous in this order; so must the GateLoop
  * post-LayerNorm weight and bias (GLLNW, GLLNB).  The four GL* slots are read only when vbx_model.gateloop != 0. */
 enum { VBX_L_G1W = 0, VBX_L_B1W, VBX_L_G2W, VBX_L_B2W, VBX_L_G1B, VBX_L_B1B, VBX_L_G2B, VBX_L_B2B, VBX_L_QG, VBX_L_KG,
@@ -285,6 +297,9 @@ typedef struct {
   int stack_only;         /* 1: standalone Transformer.forward (:412-479): io->x is the stack input [B,N,D], io->cond the adaptive
                              norm condition [B,Th] (unused with plain_norm), io->pred the final-norm output [B,N,D]; the backward
                              entry points take d(output) in io->target and write io->dx / io->dcond */
+  int E;                  /* dim_cond_emb of a text-conditioned model (condition_on_text, :931-940), 0 = unconditional:
+                             to_embed is Linear(2*D + E, D) over [x | cond_emb | cond] (:1071-1076) */
+  int V1;                 /* rows of the conditioning embedding table (num_cond_tokens + 1) */
   int plain_norm;         /* 1: non-adaptive RMSNorm (adaptive_rmsnorm = False, :386-389): gammas at VBX_L_N1G / VBX_L_N2G */
 } vbx_model;
 
@@ -299,6 +314,11 @@ typedef struct {
   const float* target;          /* [B,N,D] or NULL */
   float* pred;                  /* [B,N,D] output */
   float* loss;                  /* [1] output when target != NULL */
+  const long* cond_ids;         /* E > 0: [B,T] conditioning token ids (int64) */
+  int T;                        /* E > 0: tokens per sample */
+  long null_id;                 /* E > 0: id substituted where drop_mask is set (null_cond_id, :933) */
+  const uint8_t* drop_mask;     /* E > 0: [B] classifier-free-guidance drop mask (:1040-1053) or NULL */
+  const float* null_cond;       /* E > 0: [D] null_cond parameter (:944), required with drop_mask */
   float* dx;                    /* stack_only backward: [B,N,D] gradient of the stack input */
   float* dcond;                 /* stack_only backward: [B,Th] gradient of the adaptive-norm condition (NULL with plain_norm) */
 } vbx_io;

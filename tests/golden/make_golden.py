@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,transformer,cfg1}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,cfg1}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -155,6 +155,54 @@ def gen_small_gateloop(ref):
     print("small_gateloop: loss", float(loss))
 
 
+def gen_small_text(ref):
+    """condition_on_text=True (voicebox_pytorch.py:931-940, 1039-1076, 972-985): phoneme ids with tokens != frames (bilinear
+    resize), classifier-free-guidance drop during training, guided sampling from semantic ids."""
+    torch.manual_seed(0)
+    vb = ref.VoiceBox(dim=64, num_cond_tokens=50, dim_cond_emb=48, depth=2, dim_head=64, heads=2, condition_on_text=True,
+                      num_register_tokens=16)
+    wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb, cond_drop_prob=0.5)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or ".to_beta." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            if name.endswith("_norm.gamma") or name.endswith("final_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+        vb.null_cond.add_(torch.randn(vb.null_cond.shape, generator=g) * 0.3)  # exercise the null_cond substitution
+    state = {k: v.detach().clone() for k, v in vb.state_dict().items()}
+    b, n, t = 3, 40, 25
+    x1 = torch.randn(b, n, 64, generator=g)
+    ids = torch.randint(0, 50, (b, t), generator=g)
+    x0, times, frac, rand = replay_draws(x1, seed=55)
+    drop = torch.zeros((b,)).float().uniform_(0, 1) < 0.5  # prob_mask_like (:68-74), the draw after the span-mask draws
+    torch.manual_seed(55)
+    loss = wrapper(x1, phoneme_ids=ids)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    # tokens == frames, no drop
+    wrapper.cond_drop_prob = 0.
+    ids_n = torch.randint(0, 50, (b, n), generator=g)
+    vb.zero_grad()
+    torch.manual_seed(55)
+    loss_n = wrapper(x1, semantic_token_ids=ids_n)
+    loss_n.backward()
+    grads_n = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    vb.eval()
+    cond = torch.randn(b, n, 64, generator=g)
+    with torch.no_grad():
+        pred = vb(x1, times=torch.tensor(0.4), cond_token_ids=ids, cond=cond, cond_drop_prob=0.0)
+        pred_cfg = vb.forward_with_cond_scale(x1, times=torch.tensor(0.4), cond_token_ids=ids, cond=cond, cond_scale=1.7)
+    torch.manual_seed(4)
+    y0 = torch.randn_like(cond)
+    torch.manual_seed(4)
+    s3 = wrapper.sample(cond=cond, semantic_token_ids=ids_n, steps=3, cond_scale=1.3)
+    torch.save(dict(state=state, x1=x1, ids=ids, ids_n=ids_n, x0=x0, times=times, frac=frac, rand=rand, drop=drop, loss=loss.detach(),
+                    grads=grads, loss_n=loss_n.detach(), grads_n=grads_n, cond=cond, pred=pred, pred_cfg=pred_cfg, y0=y0, sample3=s3),
+               os.path.join(HERE, "small_text.pt"))
+    print("small_text: loss", float(loss), "drop", drop.tolist(), "loss_n", float(loss_n))
+
+
 def gen_transformer(ref):
     """Standalone Transformer.forward (voicebox_pytorch.py:412-479): adaptive (registers, qk-norm, key-padding mask) and plain
     (no registers, no qk-norm) variants, output + gradients of parameters, input and condition."""
@@ -213,7 +261,7 @@ def gen_cfg1(ref):
 
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
-    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "transformer", "cfg1"]
+    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "cfg1"]
     for w in which:
-        {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop,
+        {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "cfg1": gen_cfg1}[w](ref)

@@ -139,6 +139,22 @@ def test_gateloop_state_dict_layout(golden):
     assert torch.equal(vb.transformer.layers[1][1].to_qkva[0].weight, g["state"]["transformer.layers.1.1.to_qkva.0.weight"])
 
 
+def test_text_conditioned_state_dict(golden):
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("small_text")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=50, dim_cond_emb=48, depth=2, dim_head=64, heads=2, condition_on_text=True)
+    mine = {k: tuple(v.shape) for k, v in vb.state_dict().items() if "inv_freq" not in k}
+    ref = {k: tuple(v.shape) for k, v in g["state"].items() if "inv_freq" not in k}
+    assert mine == ref
+    assert vb.null_cond_id == 50 and not vb.null_cond.requires_grad
+    w = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    with pytest.raises(NotImplementedError):
+        w.sample(cond=g["cond"], phoneme_ids=g["ids"])  # needs a DurationPredictor
+    with pytest.raises(Exception):
+        w(g["x1"])  # text-conditioned training needs ids (voicebox_pytorch.py:1389); on a CPU-only box the missing GPU raises first
+
+
 def test_standalone_transformer_state_dict(golden):
     import voicebox_pytorch_amd as vbx
 

@@ -627,3 +627,45 @@ def test_layernorm_fwd_bwd(L, Bsz, Np, D):
     L.call("vbx_sum_rows_f32", tmp, Bsz, 2 * D, out, 2 * D, 0, st())
     assert rel_err(out[:D], wd.grad) < 1e-5
     assert rel_err(out[D:], bd.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------- text-conditioned embed input
+@pytest.mark.parametrize("T", [25, 40, 64])
+def test_pack_embed_text_and_table_grad(L, T):
+    """[x | to_cond_emb(ids) resized T->N (F.interpolate bilinear, voicebox_pytorch.py:89-107) | cond'] and the scatter of
+    d(cond_emb) into the table gradient."""
+    Bsz, N, D, E, V = 3, 40, 64, 48, 50
+    g = torch.Generator().manual_seed(T)
+    x, cond = torch.randn(Bsz, N, D, generator=g), torch.randn(Bsz, N, D, generator=g)
+    cmask = torch.rand(Bsz, N, generator=g) < 0.4
+    drop = torch.tensor([False, True, False])
+    null_cond = torch.randn(D, generator=g)
+    ids = torch.randint(0, V, (Bsz, T), generator=g)
+    table = torch.randn(V + 1, E, generator=g)
+    out16 = torch.empty(Bsz * N, 2 * D + E, dtype=torch.float16, device=dev)
+    outb = torch.empty(Bsz * N, 2 * D + E, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_pack_embed_input_text", x.to(dev), cond.to(dev), cmask.to(torch.uint8).to(dev), drop.to(torch.uint8).to(dev),
+           null_cond.to(dev), ids.to(dev), T, table.to(dev), E, V, out16, outb, Bsz, N, D, st())
+    tab = table.double().requires_grad_(True)
+    ids_eff = torch.where(drop[:, None], torch.full_like(ids, V), ids)
+    emb = tab[ids_eff]
+    if T != N:
+        emb = F.interpolate(emb.transpose(1, 2)[..., None].float(), (N, 1), mode="bilinear")[..., 0].transpose(1, 2)
+        emb_d = F.interpolate(tab[ids_eff].transpose(1, 2)[..., None], (N, 1), mode="bilinear")[..., 0].transpose(1, 2)
+    else:
+        emb_d = emb
+    c2 = cond * (~cmask)[..., None]
+    c2 = torch.where(drop[:, None, None], null_cond, c2)
+    ref = torch.cat((x, emb.detach().float(), c2), dim=-1).reshape(Bsz * N, -1)
+    got = out16.float().cpu()
+    assert torch.equal(got[:, :D], x.reshape(-1, D).half().float())
+    assert torch.equal(got[:, D + E:], c2.reshape(-1, D).half().float())
+    # interpolation weights in fp32 as torch computes them: equal up to the fp16 rounding of the stored operand
+    assert max_err(got[:, D:D + E], ref[:, D:D + E]) < 2e-3
+    assert rel_err(outb.float(), ref) < 4e-3
+    # table gradient
+    demb = bf(torch.randn(Bsz * N, E, generator=g))
+    gt = torch.zeros(V + 1, E, device=dev)
+    L.call("vbx_cond_emb_bwd", demb.to(dev), E, ids.to(dev), T, drop.to(torch.uint8).to(dev), V, gt, Bsz, N, E, st())
+    (emb_d.reshape(Bsz * N, E) * demb.double()).sum().backward()
+    assert rel_err(gt, tab.grad) < 1e-5, rel_err(gt, tab.grad)

@@ -93,6 +93,32 @@ def test_small_gateloop_model(golden):
     assert torch.allclose(torch.stack(loop, 1), closed, rtol=1e-9, atol=1e-9)
 
 
+def test_text_conditioned_model(golden):
+    """condition_on_text=True: embedding gather + bilinear token->frame resize + classifier-free-guidance drop, eval and guided
+    sampling, against the unmodified reference."""
+    g = golden("small_text")
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    for ids_key, loss_key, grads_key, drop in (("ids", "loss", "grads", g["drop"]), ("ids_n", "loss_n", "grads_n", None)):
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+        loss = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"], cond_token_ids=g[ids_key],
+                                cond_drop_mask=drop)
+        assert abs(float(loss) - float(g[loss_key])) < 1e-5, (ids_key, float(loss), float(g[loss_key]))
+        loss.backward()
+        for k, ref in g[grads_key].items():
+            assert p[k].grad is not None, k
+            assert float((p[k].grad - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-3, (ids_key, k)
+    st = g["state"]
+    b, n = g["x1"].shape[:2]
+    ones = torch.ones(b, n, dtype=torch.bool)  # eval with cond_mask None (:1028-1029)
+    with torch.no_grad():
+        pred = restate.voicebox_forward(st, cfg, g["x1"], torch.tensor(0.4), g["cond"], ones, cond_token_ids=g["ids"])
+        assert float((pred - g["pred"]).norm() / g["pred"].norm()) < 1e-5
+        pc = restate.forward_with_cond_scale(st, cfg, g["x1"], torch.tensor(0.4), g["cond"], ones, g["ids"], 1.7)
+        assert float((pc - g["pred_cfg"]).norm() / g["pred_cfg"].norm()) < 1e-5
+        s3 = restate.sample_midpoint(st, cfg, g["y0"], 3, cond=g["cond"], cond_token_ids=g["ids_n"], cond_scale=1.3)
+        assert float((s3 - g["sample3"]).norm() / g["sample3"].norm()) < 1e-4
+
+
 def test_standalone_transformer(golden):
     """restate.transformer (adaptive + plain RMSNorm, with/without registers and qk-norm) vs the reference's Transformer.forward."""
     g = golden("transformer")

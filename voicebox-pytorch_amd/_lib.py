@@ -38,6 +38,11 @@ _PROTOS = {
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
     "vbx_pack_embed_input": [P, P, P, P, P, I, I, I, P],
+    "vbx_pack_embed_input_text": [P, P, P, P, P, P, I, P, I, L, P, P, I, I, I, P],
+    "vbx_cond_emb_bwd": [P, I, P, I, P, L, P, I, I, I, P],
+    "vbx_stack_input": [P, P, P, I, I, I, I, P],
+    "vbx_stack_input_bwd": [P, P, P, I, I, I, I, P],
+    "vbx_rmsnorm_fwd_f32": [P, P, P, L, P, I, I, I, I, I, P],
     "vbx_convpos_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd_chunks": [I, I],

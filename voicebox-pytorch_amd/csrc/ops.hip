@@ -52,6 +52,91 @@ __global__ void pack_embed_kernel(const float* __restrict__ x, const float* __re
   }
 }
 
+// ---- text-conditioned embed input (voicebox_pytorch.py:1035-1076): row = [ x | cond_emb | cond' ]
+// cond' = where(drop[b], null_cond, cond * ~cond_mask)                                   (:1035, :1043-1048)
+// cond_emb = to_cond_emb(where(drop[b], null_id, ids))  resized from T tokens to N frames (:1050-1066); the resize is
+// F.interpolate(..., mode='bilinear', align_corners=False) over the frame axis (interpolate_1d, :89-107):
+//   src = max(T/N * (n + 0.5) - 0.5, 0);  i0 = floor(src);  i1 = i0 + (i0 < T-1);  lam = src - i0;  (1-lam) e[i0] + lam e[i1]
+VBX_DEV void interp_src(int n, int N, int T, int& i0, int& i1, float& lam) {
+  if (T == N) { i0 = i1 = n; lam = 0.f; return; }
+  const float scale = (float)T / (float)N;
+  float src = scale * ((float)n + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > T - 1) i0 = T - 1;
+  i1 = i0 + (i0 < T - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+__global__ void pack_embed_text_kernel(const float* __restrict__ x, const float* __restrict__ cond, const uint8_t* __restrict__ cmask,
+                                       const uint8_t* __restrict__ drop, const float* __restrict__ null_cond,
+                                       const long* __restrict__ ids, int T, const float* __restrict__ table, int E, long null_id,
+                                       u16* __restrict__ out, u16* __restrict__ outb, int B, int N, int D) {
+  const int cx = D / 8, ce = E / 8, cpr = 2 * cx + ce;  // 8-wide chunks per output row
+  const long total = (long)B * N * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cpr;
+    const int c = (int)(i - row * cpr);
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const bool dropped = drop && drop[b];
+    float v[8];
+    if (c < cx) {
+      const float* src = x + row * D + c * 8;
+      const float4 a = *reinterpret_cast<const float4*>(src), bb = *reinterpret_cast<const float4*>(src + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+    } else if (c < cx + ce) {
+      const int e0 = (c - cx) * 8;
+      int i0, i1;
+      float lam;
+      interp_src(n, N, T, i0, i1, lam);
+      const long id0 = dropped ? null_id : ids[(long)b * T + i0], id1 = dropped ? null_id : ids[(long)b * T + i1];
+      const float* r0 = table + id0 * E + e0;
+      const float* r1 = table + id1 * E + e0;
+      const float w0 = 1.0f - lam;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = (T == N) ? r0[k] : (w0 * r0[k] + lam * r1[k]);
+    } else {
+      const int d = (c - cx - ce) * 8;
+      if (dropped) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = null_cond[d + k];
+      } else if (cmask && cmask[row]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = 0.f;
+      } else {
+        const float* src = cond + row * D + d;
+        const float4 a = *reinterpret_cast<const float4*>(src), bb = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+      }
+    }
+    const long oo = row * (2L * D + E) + (long)c * 8;
+    *reinterpret_cast<uint4*>(out + oo) = pack8_h(v);
+    if (outb) *reinterpret_cast<uint4*>(outb + oo) = pack8(v);
+  }
+}
+// gradient of the embedding table: scatter of d(cond_emb) [B*N, E] (bf16) through the same resize weights.  fp32 atomics:
+// like torch's embedding backward the accumulation order is not deterministic.
+__global__ void cond_emb_bwd_kernel(const u16* __restrict__ demb, int ld, const long* __restrict__ ids, int T,
+                                    const uint8_t* __restrict__ drop, long null_id, float* __restrict__ gtable, int B, int N, int E) {
+  const long total = (long)B * N * E;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / E;
+    const int e = (int)(i - row * E);
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const bool dropped = drop && drop[b];
+    int i0, i1;
+    float lam;
+    interp_src(n, N, T, i0, i1, lam);
+    const float g = bf16_to_f32(demb[row * ld + e]);
+    const long id0 = dropped ? null_id : ids[(long)b * T + i0], id1 = dropped ? null_id : ids[(long)b * T + i1];
+    if (T == N) {
+      atomicAdd(gtable + id0 * E + e, g);
+    } else {
+      atomicAdd(gtable + id0 * E + e, (1.0f - lam) * g);
+      atomicAdd(gtable + id1 * E + e, lam * g);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- conv positional embedding
 // tile: 64 frames x 64 channels per block; thread (dl = tid&63, ng = tid>>6) computes 16 frames of channel dl.
 constexpr int CT = 64;
@@ -837,6 +922,27 @@ extern "C" int vbx_pack_embed_input(const float* x, const float* cond, const uin
   const long rows = (long)B * N;
   hipLaunchKernelGGL(pack_embed_kernel, dim3(grid_for(rows * D / 4)), dim3(256), 0, ST, x, cond, cond_mask, (u16*)out_f16,
                      (u16*)out_bf16, rows, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_pack_embed_input_text(const float* x, const float* cond, const uint8_t* cond_mask, const uint8_t* drop_mask,
+                                         const float* null_cond, const long* ids, int T, const float* table, int E, long null_id,
+                                         void* out_f16, void* out_bf16, int B, int N, int D, void* stream) {
+  VBX_REQUIRE(x && cond && ids && table && out_f16 && T > 0 && D % 8 == 0 && E > 0 && E % 8 == 0, "vbx_pack_embed_input_text: bad args");
+  VBX_REQUIRE(!drop_mask || null_cond, "vbx_pack_embed_input_text: a drop mask needs null_cond");
+  const long chunks = (long)B * N * (2 * D + E) / 8;
+  hipLaunchKernelGGL(pack_embed_text_kernel, dim3(grid_for(chunks)), dim3(256), 0, ST, x, cond, cond_mask, drop_mask, null_cond, ids, T,
+                     table, E, null_id, (u16*)out_f16, (u16*)out_bf16, B, N, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, int T, const uint8_t* drop_mask, long null_id,
+                                float* gtable, int B, int N, int E, void* stream) {
+  VBX_REQUIRE(demb_bf16 && ids && gtable && T > 0 && E > 0 && ld >= E, "vbx_cond_emb_bwd: bad args");
+  hipLaunchKernelGGL(cond_emb_bwd_kernel, dim3(grid_for((long)B * N * E)), dim3(256), 0, ST, (const u16*)demb_bf16, ld, ids, T,
+                     drop_mask, null_id, gtable, B, N, E);
   VBX_LAUNCH_CHECK();
   return 0;
 }

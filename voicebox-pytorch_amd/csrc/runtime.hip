@@ -35,12 +35,13 @@ struct Carver {
 };
 
 struct Dims {
-  int B, N, R, Np, D, H, I, F, Fp, Th, L, ks, J;
+  int B, N, R, Np, D, H, I, F, Fp, Th, L, ks, J, E, Ke;  // Ke = to_embed input width 2*D + E
   long M, M0;
 };
 Dims dims_of(const vbx_model* m) {
   Dims d;
   d.B = m->B; d.N = m->N; d.R = m->R; d.Np = m->N + m->R; d.D = m->D; d.H = m->H; d.I = m->H * 64;
+  d.E = m->E; d.Ke = 2 * m->D + m->E;
   d.F = m->F; d.Fp = ((m->F + 63) / 64) * 64; d.Th = m->Th; d.L = m->L; d.ks = m->ksize; d.J = m->L * 4 * m->D;
   d.M = (long)d.B * d.Np; d.M0 = (long)d.B * d.N;
   return d;
@@ -52,7 +53,7 @@ struct WLayer {
   float* b1;
 };
 struct WPack {
-  u16 *embh, *pred, *predh, *adah;
+  u16 *embh, *embb, *pred, *predh, *adah;  // embb: bf16 copy of to_embed (dgrad into cond_emb, text-conditioned models only)
   float* bada;
   std::vector<WLayer> layer;
   size_t bytes;
@@ -60,7 +61,8 @@ struct WPack {
 void carve_wpack(const vbx_model* m, WPack& w) {
   const Dims d = dims_of(m);
   Carver c(m->wpack);
-  w.embh = c.take<u16>((size_t)d.D * 2 * d.D);
+  w.embh = c.take<u16>((size_t)d.D * d.Ke);
+  w.embb = d.E ? c.take<u16>((size_t)d.D * d.Ke) : nullptr;
   w.pred = c.take<u16>((size_t)d.D * d.D);
   w.predh = c.take<u16>((size_t)d.D * d.D);
   w.adah = c.take<u16>((size_t)d.J * d.Th);
@@ -99,7 +101,7 @@ struct Acts {
   // backward scratch
   float *dx, *dq, *dk, *delta, *slabs, *npart, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
-  u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp;
+  u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
   float* gl_ds;
   size_t slab_floats;
   size_t bytes;
@@ -120,8 +122,8 @@ void carve_acts(const vbx_model* m, Acts& a) {
   const Dims d = dims_of(m);
   Carver c(m->act);
   const bool tr = m->training != 0;
-  a.embed_in = tr ? c.take<u16>((size_t)d.M0 * 2 * d.D) : nullptr;
-  a.embed_inh = c.take<u16>((size_t)d.M0 * 2 * d.D);
+  a.embed_in = tr ? c.take<u16>((size_t)d.M0 * d.Ke) : nullptr;
+  a.embed_inh = c.take<u16>((size_t)d.M0 * d.Ke);
   a.e = c.take<float>((size_t)d.M0 * d.D);
   a.four = c.take<float>((size_t)d.B * d.D);
   a.pre = c.take<float>((size_t)d.B * d.Th);
@@ -190,7 +192,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
       if (n > sf) sf = n;
     };
     upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
-    upd(d.D, 2 * d.D, d.M0); upd(d.D, d.D, d.M0);
+    upd(d.D, d.Ke, d.M0); upd(d.D, d.D, d.M0);
     if (m->gateloop) upd(3 * d.D, d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(sf);
@@ -211,6 +213,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.tscratch = c.take<float>((size_t)vbx_time_embed_bwd_scratch_floats(d.B, d.D));
     a.gl_ds = m->gateloop ? c.take<float>((size_t)d.M * d.D) : nullptr;
     a.gl_dp = m->gateloop ? c.take<u16>((size_t)d.M * 3 * d.D) : nullptr;
+    a.demb = d.E ? c.take<u16>((size_t)d.M0 * d.E) : nullptr;
   }
   a.bytes = al256(c.off);
 }
@@ -227,6 +230,7 @@ int check_model(const vbx_model* m) {
   VBX_REQUIRE(m->H > 0 && m->H % 2 == 0, "vbx_model: heads must be even (dim_head is fixed at 64)");
   VBX_REQUIRE(m->Th % 8 == 0 && m->L > 0 && m->B > 0 && m->N > 0 && m->R >= 0 && m->F > 0, "vbx_model: bad dims");
   VBX_REQUIRE(m->ksize == 31, "vbx_model: conv_pos_embed_kernel_size must be 31");
+  VBX_REQUIRE(m->E >= 0 && m->E % 8 == 0 && (m->E == 0 || (m->V1 > 0 && !m->stack_only)), "vbx_model: bad dim_cond_emb / table size");
   const long DT = (long)m->D * m->Th;
   for (int l = 0; l < m->L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
@@ -295,7 +299,7 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
   const float* P = m->params;
   const long* G = m->off;
   if (!m->stack_only) {
-    CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, d.D, 2 * d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, d.Ke, w.embb, w.embh, d.D, d.Ke, 0, 0, stream));
     CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, d.D, d.D, 0, 0, stream));
   }
   for (int l = 0; l < d.L; l++) {
@@ -337,8 +341,14 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     if (!m->plain_norm) CK(vbx_adaln_proj_fwd(io->cond, w.adah, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, stream));
   } else {
   // to_embed(cat(x, cond * ~cond_mask))   (voicebox_pytorch.py:1035,1075-1078)
-  CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
-  CK(gemm_nt(a.embed_inh, 2 * d.D, w.embh, 2 * d.D, (int)d.M0, d.D, 2 * d.D, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
+  if (d.E) {
+    VBX_REQUIRE(io->cond_ids && io->T > 0, "vbx_model_forward: a text-conditioned model needs cond_ids");
+    CK(vbx_pack_embed_input_text(io->x, io->cond, io->cond_mask, io->drop_mask, io->null_cond, io->cond_ids, io->T,
+                                 P + G[VBX_P_CEMB], d.E, io->null_id, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
+  } else {
+    CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
+  }
+  CK(gemm_nt(a.embed_inh, d.Ke, w.embh, d.Ke, (int)d.M0, d.D, d.Ke, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
              nullptr, nullptr, st));
   // conv_embed(x) + x, register tokens in place   (:1080, :422-425)
   CK(vbx_convpos_fwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a.xs[0],
@@ -539,7 +549,18 @@ extern "C" int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, vo
   CK(vbx_convpos_bwd(a.e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, a.dx, a.dpre, a.de, a.deb, a.wpart,
                      d.R ? Gd + G[VBX_P_REG] : nullptr, d.B, d.N, d.R, d.D, d.ks, stream));
   CK(vbx_conv_wgrad_finalize(a.wpart, vbx_convpos_bwd_chunks(d.B, d.N), d.D, d.ks, Gd + G[VBX_P_CONVW], Gd + G[VBX_P_CONVB], stream));
-  CK(wgrad(a.deb, d.D, a.embed_in, 2 * d.D, d.D, 2 * d.D, d.M0, a.slabs, Gd + G[VBX_P_EMBW], d.D, 2 * d.D, 0, 0, st));
+  CK(wgrad(a.deb, d.D, a.embed_in, d.Ke, d.D, d.Ke, d.M0, a.slabs, Gd + G[VBX_P_EMBW], d.D, d.Ke, 0, 0, st));
+  if (d.E) {
+    // d(cond_emb) = de . W_embed[:, D:D+E]  ->  scatter into the embedding table gradient   (:1055, :1075-1076)
+    WPack w;
+    carve_wpack(m, w);
+    CK(gemm_nn_bf16(a.deb, d.D, w.embb + d.D, d.Ke, (int)d.M0, d.E, d.D, a.demb, d.E, st));
+    if (hipMemsetAsync(Gd + G[VBX_P_CEMB], 0, (size_t)m->V1 * d.E * sizeof(float), st) != hipSuccess) {
+      vbx_set_error("vbx_model_backward_embed: memset of the embedding gradient failed");
+      return VBX_EINVAL;
+    }
+    CK(vbx_cond_emb_bwd(a.demb, d.E, io->cond_ids, io->T, io->drop_mask, io->null_id, Gd + G[VBX_P_CEMB], d.B, d.N, d.E, stream));
+  }
   CK(vbx_colsum_f32(a.de, (int)d.M0, d.D, d.D, Gd + G[VBX_P_EMBB], a.cs_scratch, stream));
   CK(vbx_time_embed_bwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], a.four, a.pre, a.dtemb, Gd + G[VBX_P_SINW],
                         Gd + G[VBX_P_T1W], Gd + G[VBX_P_T1B], a.tscratch, d.B, d.D, d.Th, stream));
@@ -563,7 +584,7 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
     ps.push_back(s);
   };
   if (!m->stack_only) {
-    add(G[VBX_P_EMBW], d.D, 2 * d.D, nullptr, w.embh, nullptr, 2 * d.D, 0, 0);
+    add(G[VBX_P_EMBW], d.D, d.Ke, w.embb, w.embh, nullptr, d.Ke, 0, 0);
     add(G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
   }
   for (int l = 0; l < d.L; l++) {

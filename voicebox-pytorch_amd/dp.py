@@ -124,8 +124,9 @@ class TrainStep:
         for eng in self.vb._engines.values():
             eng.packed_version = None
 
-    def step(self, x1, mask=None, lr=None):
-        """x1: (B_local, frames, dim) on this rank's GPU.  Returns the (un-synchronised) local loss tensor."""
+    def step(self, x1, mask=None, lr=None, cond_token_ids=None):
+        """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
+        Returns the (un-synchronised) local loss tensor."""
         vb, w = self.vb, self.wrapper
         dev = self.fp.flat.device
         st = _lib.current_stream
@@ -144,8 +145,18 @@ class TrainStep:
             frac = torch.zeros((B,), device=dev).float().uniform_(*vb.frac_lengths_mask)
         cond_mask = mask_from_frac_lengths(N, frac.to(dev))
         loss_mask = cond_mask if mask is None else (cond_mask & mask.to(dev))
+        text = None
+        if vb.condition_on_text:  # cond_drop_prob draw comes after the span-mask draws (voicebox_pytorch.py:1025,1040-1041)
+            from .masks import prob_mask_like
+
+            assert cond_token_ids is not None, "a text-conditioned model trains on cond_token_ids"
+            drop = None
+            if w.cond_drop_prob > 0.:
+                drop = take_draw("cond_drop")
+                drop = prob_mask_like((B,), w.cond_drop_prob, dev) if drop is None else drop.to(dev)
+            text = (cond_token_ids.to(dev), vb.null_cond_id, drop, vb.null_cond)
         eng = vb.engine(B, N, training=True)
-        loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask)
+        loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
         # --- backward with overlapped gradient exchange
         red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
                                 comm_stream=self.comm_stream)

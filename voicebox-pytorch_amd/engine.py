@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import P, I, F
 
 # enum mirrors of include/vbx.h
-G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW"]
+G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW", "CEMB"]
 L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B",
            "GLG", "GLW", "GLLNW", "GLLNB", "N1G", "N2G"]
 NG, NL = len(G_NAMES), len(L_NAMES)
@@ -20,12 +20,13 @@ class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
-                ("stack_only", I), ("plain_norm", I)]
+                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I)]
 
 
 class VbxIO(C.Structure):
     _fields_ = [("x", P), ("cond", P), ("cond_mask", P), ("attn_mask", P), ("attn_mask_p", P), ("loss_mask", P),
-                ("times", P), ("target", P), ("pred", P), ("loss", P), ("dx", P), ("dcond", P)]
+                ("times", P), ("target", P), ("pred", P), ("loss", P), ("cond_ids", P), ("T", I), ("null_id", C.c_long),
+                ("drop_mask", P), ("null_cond", P), ("dx", P), ("dcond", P)]
 
 
 class VbxAdamSeg(C.Structure):
@@ -87,7 +88,7 @@ class FlatParams:
         order = ["PREDW", "FNG"]
         for l in reversed(range(depth)):
             order += [f"L{l}.{n}" for n in L_NAMES if f"L{l}.{n}" in named_slots]
-        tail = ["EMBW", "EMBB", "CONVW", "CONVB", "REG", "SINW", "T1W", "T1B"]
+        tail = ["EMBW", "EMBB", "CEMB", "CONVW", "CONVB", "REG", "SINW", "T1W", "T1B"]
         order += tail
         self.order = [s for s in order if s in named_slots]
         self.slots = named_slots
@@ -160,6 +161,7 @@ class Engine:
         m.training = 1 if training else 0
         m.gateloop = 1 if cfg.get("gateloop") else 0
         m.stack_only = 1 if cfg.get("stack_only") else 0
+        m.E, m.V1 = int(cfg.get("E", 0)), int(cfg.get("V1", 0))
         m.plain_norm = 1 if cfg.get("plain_norm") else 0
         self.off_table = flat.offset_table()
         m.off = C.cast(self.off_table, P)
@@ -207,9 +209,10 @@ class Engine:
         self.packed_version = (flat.data_ptr(), flat._version)  # this engine's operand copies were refreshed in the same pass
 
     # -- forward
-    def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None):
+    def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None, text=None):
         """All tensors on self.device, fp32 contiguous / bool.  Returns the loss tensor (1,) if target is given,
-        else the prediction (B,N,D)."""
+        else the prediction (B,N,D).  text (text-conditioned models): (ids int64 (B,T), null_id, drop_mask bool (B,) or None,
+        null_cond fp32 (D,))."""
         self.bind_params()
         B, N, D = self.B, self.N, self.cfg["D"]
         x, cond = x.contiguous(), cond.contiguous()
@@ -234,7 +237,16 @@ class Engine:
             io.target = io.loss_mask = io.loss = None
             pred = pred_out if pred_out is not None else torch.empty(B, N, D, dtype=torch.float32, device=self.device)
             io.pred = pred.data_ptr()
-        self._keep = (x, cond, cm, am, amp, lm, times, target, pred)  # keep inputs alive until backward
+        if self.cfg.get("E", 0):
+            ids, null_id, drop, null_cond = text
+            ids = ids.to(torch.int64).contiguous()
+            drop8 = drop.to(torch.uint8).contiguous() if drop is not None else None
+            null_cond = null_cond.detach().to(torch.float32).contiguous()
+            io.cond_ids, io.T, io.null_id = ids.data_ptr(), int(ids.shape[1]), int(null_id)
+            io.drop_mask = drop8.data_ptr() if drop8 is not None else None
+            io.null_cond = null_cond.data_ptr()
+            text = (ids, drop8, null_cond)
+        self._keep = (x, cond, cm, am, amp, lm, times, target, pred, text)  # keep inputs alive until backward
         self.generation += 1
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
         return self.loss if target is not None else pred

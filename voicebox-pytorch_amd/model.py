@@ -306,8 +306,8 @@ class _VoiceBoxLossFn(torch.autograd.Function):
     vbx_model_backward_{head,layer,embed} into a fresh flat gradient buffer whose views are returned per parameter."""
 
     @staticmethod
-    def forward(ctx, vb, eng, x, cond, cond_mask, times, attn_mask, target, loss_mask, *params):
-        loss = eng.forward(x, cond, cond_mask, times, attn_mask=attn_mask, target=target, loss_mask=loss_mask)
+    def forward(ctx, vb, eng, x, cond, cond_mask, times, attn_mask, target, loss_mask, text, *params):
+        loss = eng.forward(x, cond, cond_mask, times, attn_mask=attn_mask, target=target, loss_mask=loss_mask, text=text)
         ctx.vb, ctx.eng, ctx.gen = vb, eng, eng.generation
         return loss.clone().reshape(())
 
@@ -320,7 +320,7 @@ class _VoiceBoxLossFn(torch.autograd.Function):
         gflat = torch.zeros(vb._flat.numel, dtype=torch.float32, device=eng.device)
         gscale = gloss.detach().to(torch.float32).reshape(1).contiguous()
         eng.backward(gflat, gscale=gscale)
-        return (None,) * 9 + tuple(vb._flat.grad_views(gflat))
+        return (None,) * 10 + tuple(vb._flat.grad_views(gflat))
 
 
 class VoiceBox(nn.Module):
@@ -333,9 +333,8 @@ class VoiceBox(nn.Module):
         time_hidden_dim = default(time_hidden_dim, dim * 4)
         assert not (condition_on_text and not exists(num_cond_tokens)), \
             'number of conditioning tokens must be specified (whether phonemes or semantic token ids) if training conditional voicebox'
-        if condition_on_text:
-            raise NotImplementedError("text conditioning (to_cond_emb / CFG) is a 'next' row (SURVEY 8(f) #2); "
-                                      "construct with condition_on_text = False")
+        if condition_on_text and dim_cond_emb % 8 != 0:
+            raise NotImplementedError("dim_cond_emb must be a multiple of 8 (16-byte GEMM rows)")
         if exists(audio_enc_dec):
             raise NotImplementedError("audio codecs are out of scope of the hot path: feed latents directly")
         if dim_in != dim:
@@ -349,12 +348,17 @@ class VoiceBox(nn.Module):
         self.audio_enc_dec = None
         self.proj_in = nn.Identity()
         self.sinu_pos_emb = nn.Sequential(LearnedSinusoidalPosEmb(dim), nn.Linear(dim, time_hidden_dim), nn.SiLU())
-        self.dim_cond_emb = 0
-        self.condition_on_text = False
+        if not condition_on_text:  # voicebox_pytorch.py:922-926
+            dim_cond_emb = 0
+        self.dim_cond_emb = dim_cond_emb
+        self.condition_on_text = condition_on_text
         self.num_cond_tokens = num_cond_tokens
+        if condition_on_text:  # :931-934
+            self.null_cond_id = num_cond_tokens  # last token id is the null token of classifier-free guidance
+            self.to_cond_emb = nn.Embedding(num_cond_tokens + 1, dim_cond_emb)
         self.p_drop_prob = p_drop_prob
         self.frac_lengths_mask = frac_lengths_mask
-        self.to_embed = nn.Linear(dim_in * 2, dim)
+        self.to_embed = nn.Linear(dim_in * 2 + dim_cond_emb, dim)
         self.null_cond = nn.Parameter(torch.zeros(dim_in), requires_grad=False)
         self.conv_embed = ConvPositionEmbed(dim=dim, kernel_size=conv_pos_embed_kernel_size, groups=conv_pos_embed_groups)
         self.transformer = Transformer(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult,
@@ -366,7 +370,8 @@ class VoiceBox(nn.Module):
         self._cfg = dict(D=dim, H=heads, L=depth, F=int(dim * ff_mult * 2 / 3), Th=time_hidden_dim,
                          R=int(num_register_tokens), ksize=conv_pos_embed_kernel_size, qk_norm=bool(attn_qk_norm),
                          attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
-                         gateloop=bool(use_gateloop_layers))
+                         gateloop=bool(use_gateloop_layers), E=dim_cond_emb,
+                         V1=(num_cond_tokens + 1) if condition_on_text else 0)
         self._flat = None
         self._engines = {}
 
@@ -378,6 +383,8 @@ class VoiceBox(nn.Module):
              "CONVB": self.conv_embed.dw_conv1d[0].bias, "FNG": t.final_norm.gamma, "PREDW": self.to_pred.weight}
         if t.has_register_tokens:
             s["REG"] = t.register_tokens
+        if self.condition_on_text:
+            s["CEMB"] = self.to_cond_emb.weight
         t._layer_slots(s)
         return s
 
@@ -441,23 +448,38 @@ class VoiceBox(nn.Module):
         elif not exists(cond_mask):
             cond_mask = torch.ones((batch, seq_len), device=dev, dtype=torch.bool)
         cond_mask = cond_mask.to(dev)
+        # classifier-free guidance drop (:1040-1053) and the conditioning token ids (:1055-1066)
+        drop = None
         if cond_drop_prob > 0.:
-            # same failure as the reference on an unconditional model (:1050-1053)
-            raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
+            if not self.condition_on_text:
+                # same failure as the reference on an unconditional model (:1050-1053)
+                raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
+            drop = take_draw("cond_drop")
+            drop = prob_mask_like((batch,), cond_drop_prob, dev) if drop is None else drop.to(dev)
         if exists(self_attn_mask):
             self_attn_mask = self_attn_mask.to(dev)
+        text = None
+        if self.condition_on_text:
+            assert exists(cond_token_ids), "a text-conditioned VoiceBox needs cond_token_ids (batch, tokens)"
+            ids = cond_token_ids.to(dev)
+            if ids.shape[-1] != seq_len and exists(self_attn_mask) and self_attn_mask.shape[-1] != seq_len:
+                # :1064-1066 (interpolate_1d on the boolean mask, the reference's own torch ops)
+                m4 = self_attn_mask.float()[:, None, :, None]
+                self_attn_mask = torch.nn.functional.interpolate(m4, (seq_len, 1), mode="bilinear")[:, 0, :, 0].to(torch.bool)
+            text = (ids, self.null_cond_id, drop, self.null_cond)
         if not exists(target):
             eng = self.engine(batch, seq_len, training=False)
-            return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask)
+            return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask, text=text)
         target = target.to(dev, torch.float32)
         loss_mask = reduce_masks_with_and(cond_mask, self_attn_mask)  # :1099
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             eng = self.engine(batch, seq_len, training=True)
             fp = self._flat
             params = [fp.slots[s] for s in fp.order]
-            return _VoiceBoxLossFn.apply(self, eng, x, cond, cond_mask, times, self_attn_mask, target, loss_mask, *params)
+            return _VoiceBoxLossFn.apply(self, eng, x, cond, cond_mask, times, self_attn_mask, target, loss_mask, text, *params)
         eng = self.engine(batch, seq_len, training=False)
-        return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask, target=target, loss_mask=loss_mask).clone().reshape(())
+        return eng.forward(x, cond, cond_mask, times, attn_mask=self_attn_mask, target=target, loss_mask=loss_mask,
+                           text=text).clone().reshape(())
 
 
 # --------------------------------------------------------------------------------------- CFM wrapper
@@ -511,25 +533,41 @@ class ConditionalFlowMatcherWrapper(nn.Module):
             raise NotImplementedError("raw-audio conditioning needs an audio codec (out of scope)")
         num_cond_inputs = sum(map(exists, (texts, text_token_ids, semantic_token_ids, phoneme_ids)))
         assert num_cond_inputs <= 1
-        assert num_cond_inputs == 0, 'no conditioning inputs should be given if not conditioning on text'
-        assert exists(cond), "cond (B, frames, dim) is required"
-        if cond_scale != 1.:
-            # reference: second pass with cond_drop_prob = 1 -> AttributeError on an unconditional model
-            raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
-        self.voicebox.eval()
+        cond_token_ids = None
         dev = self.device
+        if self.condition_on_text:  # :1208-1255
+            if exists(texts) or exists(text_token_ids):
+                raise NotImplementedError("text -> semantic tokens needs a TextToSemantic module (out of scope): pass semantic_token_ids")
+            if exists(phoneme_ids):
+                raise NotImplementedError("phoneme ids need a DurationPredictor to be aligned to frames (out of scope, SURVEY 8(f) #4)")
+            assert exists(semantic_token_ids), "a text-conditioned model samples from semantic_token_ids (batch, tokens)"
+            cond_token_ids = semantic_token_ids.to(dev)
+            target_len = cond_token_ids.shape[-1]
+            if exists(cond):  # curtail_or_pad(cond, cond_target_length) (:109-119, :1253)
+                n = cond.shape[-2]
+                cond = cond[..., :target_len, :] if n > target_len else torch.nn.functional.pad(cond, (0, 0, 0, target_len - n))
+            else:
+                raise NotImplementedError("cond = None needs audio_enc_dec.latent_dim (codecs are out of scope): pass cond")
+        else:
+            assert num_cond_inputs == 0, 'no conditioning inputs should be given if not conditioning on text'
+            if cond_scale != 1.:
+                # reference: second pass with cond_drop_prob = 1 -> AttributeError on an unconditional model
+                raise AttributeError("'VoiceBox' object has no attribute 'null_cond_id'")
+        assert exists(cond), "cond (B, frames, dim) is required"
+        self.voicebox.eval()
         cond = cond.to(dev, torch.float32)
         y0 = take_draw("y0")
         y0 = torch.randn_like(cond) if y0 is None else y0.to(dev, torch.float32)
         B, N, _ = cond.shape
-        key = (B, N, steps, bool(use_graph))
+        T = cond_token_ids.shape[-1] if exists(cond_token_ids) else 0
+        key = (B, N, steps, bool(use_graph), T, float(cond_scale) != 1.)
         smp = self._samplers.get(key)
         if smp is None:
             if len(self._samplers) >= 2:
                 self._samplers.pop(next(iter(self._samplers)))
-            smp = MidpointSampler(self.voicebox, B, N, steps, use_graph=use_graph)
+            smp = MidpointSampler(self.voicebox, B, N, steps, use_graph=use_graph, tokens=T, guided=float(cond_scale) != 1.)
             self._samplers[key] = smp
-        return smp.run(y0, cond, cond_mask)
+        return smp.run(y0, cond, cond_mask, cond_token_ids=cond_token_ids, cond_scale=float(cond_scale))
 
     def forward(self, x1, *, mask=None, semantic_token_ids=None, phoneme_ids=None, cond=None, cond_mask=None,
                 input_sampling_rate=None):  # voicebox_pytorch.py:1332-1427
@@ -548,6 +586,14 @@ class ConditionalFlowMatcherWrapper(nn.Module):
         flow = torch.empty_like(x1)
         _lib.call("vbx_cfm_inputs", x1, x0.contiguous(), times.contiguous(), float(self.sigma), w, flow, batch,
                   x1[0].numel(), _lib.current_stream())  # :1408-1410
+        cond_token_ids = None
+        if self.condition_on_text:  # :1374-1390 (no TextToSemantic module here: ids are given)
+            if exists(semantic_token_ids):
+                assert not exists(phoneme_ids), 'phoneme ids are not needed for conditioning with spear-tts text-to-semantic'
+                cond_token_ids = semantic_token_ids
+            else:
+                assert exists(phoneme_ids)
+                cond_token_ids = phoneme_ids
         self.voicebox.train()  # :1414
         return self.voicebox(w, cond=cond, cond_mask=cond_mask, times=times, target=flow, self_attn_mask=mask,
-                             cond_token_ids=None, cond_drop_prob=self.cond_drop_prob)
+                             cond_token_ids=cond_token_ids, cond_drop_prob=self.cond_drop_prob)

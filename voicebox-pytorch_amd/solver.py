@@ -15,7 +15,7 @@ from . import _lib
 
 
 class MidpointSampler:
-    def __init__(self, voicebox, B, N, steps, use_graph=True):
+    def __init__(self, voicebox, B, N, steps, use_graph=True, tokens=0, guided=False):
         assert steps >= 2, "need at least two time points"
         self.vb, self.B, self.N, self.steps = voicebox, B, N, steps
         self.eng = voicebox.engine(B, N, training=False)
@@ -33,13 +33,34 @@ class MidpointSampler:
         self.cmask = torch.ones(B, N, dtype=torch.bool, device=dev)
         self.times = torch.zeros(B, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        # text-conditioned models: static token ids; classifier-free guidance (forward_with_cond_scale, :972-985) runs a
+        # second, fully dropped evaluation (cond -> null_cond, ids -> null_cond_id) and mixes null + (logits - null) * scale
+        self.tokens, self.guided = int(tokens), bool(guided)
+        if self.tokens:
+            self.ids = torch.zeros(B, self.tokens, dtype=torch.int64, device=dev)
+            self.drop_all = torch.ones(B, dtype=torch.uint8, device=dev)
+        if self.guided:
+            assert self.tokens, "guidance needs a text-conditioned model"
+            self.f_null = torch.zeros(B, N, D, device=dev)
+            self.f_diff = torch.zeros(B, N, D, device=dev)
+            self.g_table = torch.tensor([-1.0, 1.0], device=dev)  # [-1, cond_scale]
         self.graph = None
         self.use_graph = use_graph
-        self.nfe = 2 * (steps - 1)
+        self.nfe = 2 * (steps - 1) * (2 if self.guided else 1)
 
     def _bind(self, x):
         # point the engine's io at the static buffers (x = y or ymid), prediction written to self.f
-        self.eng.forward(x, self.cond, self.cmask, self.times, pred_out=self.f)
+        if not self.tokens:
+            self.eng.forward(x, self.cond, self.cmask, self.times, pred_out=self.f)
+            return
+        vb = self.vb
+        self.eng.forward(x, self.cond, self.cmask, self.times, pred_out=self.f, text=(self.ids, vb.null_cond_id, None, vb.null_cond))
+        if self.guided:
+            st, n = _lib.current_stream, self.f.numel()
+            self.eng.forward(x, self.cond, self.cmask, self.times, pred_out=self.f_null,
+                             text=(self.ids, vb.null_cond_id, self.drop_all, vb.null_cond))
+            _lib.call("vbx_axpy_dev", self.f, self.f_null, self.g_table, 0, self.f_diff, n, st())   # logits - null
+            _lib.call("vbx_axpy_dev", self.f_null, self.f_diff, self.g_table, 1, self.f, n, st())   # null + scale * diff
 
     def _interval(self):
         st = _lib.current_stream
@@ -66,7 +87,7 @@ class MidpointSampler:
             self._interval()
         self.graph = g
 
-    def run(self, y0, cond=None, cond_mask=None):
+    def run(self, y0, cond=None, cond_mask=None, cond_token_ids=None, cond_scale=1.0):
         # eval semantics of the reference: cond_mask None -> everything masked -> cond is zeroed (:1028-1035)
         if cond is not None:
             self.cond.copy_(cond)
@@ -74,6 +95,10 @@ class MidpointSampler:
             self.cmask.copy_(cond_mask.to(self.cmask.device))
         else:
             self.cmask.fill_(True)
+        if self.tokens:
+            self.ids.copy_(cond_token_ids.to(self.ids.device))
+        if self.guided:
+            self.g_table[1] = float(cond_scale)
         self.eng.bind_params()  # re-pack weights if they changed since the last call
         if self.use_graph and self.graph is None:
             self._capture()
