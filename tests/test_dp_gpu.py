@@ -14,6 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+dev = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -100,3 +101,77 @@ def test_train_step_world2_on_one_gpu():
     assert err <= 1e-6 * max(scale, 1e-6) + 1e-9, (err, scale)
     assert moved > 0 and moved < 2e-3  # Adam moved every weight by at most ~lr
     assert 1.0 < loss < 10.0
+
+
+def test_trainer_accumulation_and_reference_checkpoint_format(tmp_path, golden):
+    """VoiceBoxTrainer (trainer.py:60-321 mirror): gradient accumulation equals one step on the concatenated batch, and the
+    checkpoint is the reference's {'model','optim','scheduler'} with a torch.optim.Adam-loadable optimizer state."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+
+    def make():
+        vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(g["state"], strict=False)
+        return vb.to(dev), None
+
+    x1 = g["x1"].to(dev)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    # (a) two micro-batches of 1, weights 1/2  ==  one batch of 2 (loss = mean over the batch of per-sample masked means)
+    vb_a, _ = make()
+    ts_a = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb_a), lr=1e-3)
+    for i in range(2):
+        with rng_override(**{k: v[i:i + 1] for k, v in draws.items()}):
+            ts_a.accumulate(x1[i:i + 1], 0.5)
+    ts_a.apply_accumulated()
+    vb_b, _ = make()
+    ts_b = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb_b), lr=1e-3)
+    with rng_override(**draws):
+        ts_b.step(x1)
+    pb = dict(vb_b.named_parameters())
+    for k, p in vb_a.named_parameters():
+        if p.requires_grad:
+            ua, ub = p.detach() - g["state"][k].to(dev), pb[k].detach() - g["state"][k].to(dev)
+            assert float((ua - ub).norm() / ub.norm().clamp(min=1e-20)) < 5e-2, k
+
+    # (b) the driver: 3 steps with accumulation, checkpoints every step
+    class Latents(torch.utils.data.Dataset):
+        def __len__(self):
+            return 16
+
+        def __getitem__(self, i):
+            return torch.randn(40, 64, generator=torch.Generator().manual_seed(i))
+
+    vb, _ = make()
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    tr = vbx.VoiceBoxTrainer(wrapper, batch_size=2, dataset=Latents(), num_train_steps=3, num_warmup_steps=2, grad_accum_every=2,
+                             valid_frac=0.25, log_every=1, save_results_every=2, save_model_every=1, results_folder=str(tmp_path),
+                             force_clear_prev_results=True)
+    losses = []
+    tr.train(log_fn=lambda logs: losses.append(logs["loss"]))
+    assert len(losses) == 3 and all(l == l and l < 10 for l in losses)
+    ck = tmp_path / "voicebox.2.pt"
+    assert ck.exists()
+    pkg = torch.load(str(ck), map_location="cpu")
+    assert set(pkg) == {"model", "optim", "scheduler"}
+    assert set(pkg["model"]) == set(wrapper.state_dict())
+    # loadable by the reference's optimizer / scheduler objects
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in wrapper.parameters()]
+    opt = torch.optim.Adam(ref_params, lr=3e-4, betas=(0.9, 0.99))
+    opt.load_state_dict(pkg["optim"])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=3)
+    sched.load_state_dict(pkg["scheduler"])
+    n_state = sum(1 for p in wrapper.parameters() if p.requires_grad)
+    assert len(pkg["optim"]["state"]) == n_state
+    # resume: Adam moments and step counter come back
+    vb2, _ = make()
+    tr2 = vbx.VoiceBoxTrainer(vbx.ConditionalFlowMatcherWrapper(voicebox=vb2), batch_size=2, dataset=Latents(), num_train_steps=6,
+                              grad_accum_every=1, valid_frac=0.25, results_folder=str(tmp_path / "r2"))
+    tr2.load(str(ck))
+    assert int(tr2.steps.item()) == 3 and tr2.train_step_fn.steps == 3
+    assert torch.equal(tr2.train_step_fn.m, tr.train_step_fn.m) and torch.equal(tr2.train_step_fn.v, tr.train_step_fn.v)
+    for (k, a), (_, b) in zip(vb2.state_dict().items(), vb.state_dict().items()):
+        assert torch.equal(a, b), k
+    tr2.train_step()

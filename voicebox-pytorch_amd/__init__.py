@@ -9,8 +9,9 @@ __all__ = ["_lib"]
 try:  # model classes need torch; keep `_lib` importable on its own
     from .masks import mask_from_frac_lengths, mask_from_start_end_indices, prob_mask_like, reduce_masks_with_and  # noqa: F401
     from .model import VoiceBox, ConditionalFlowMatcherWrapper, Transformer, Attend  # noqa: F401
+    from .trainer import VoiceBoxTrainer  # noqa: F401
 
-    __all__ += ["VoiceBox", "ConditionalFlowMatcherWrapper", "Transformer", "Attend", "mask_from_frac_lengths",
+    __all__ += ["VoiceBox", "ConditionalFlowMatcherWrapper", "Transformer", "Attend", "VoiceBoxTrainer", "mask_from_frac_lengths",
                 "mask_from_start_end_indices", "prob_mask_like", "reduce_masks_with_and"]
 except ModuleNotFoundError as _e:  # pragma: no cover - only while the package is being bootstrapped
     if "masks" not in str(_e) and "model" not in str(_e):

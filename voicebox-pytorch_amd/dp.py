@@ -124,9 +124,36 @@ class TrainStep:
         for eng in self.vb._engines.values():
             eng.packed_version = None
 
-    def step(self, x1, mask=None, lr=None, cond_token_ids=None):
-        """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
-        Returns the (un-synchronised) local loss tensor."""
+    # -- gradient accumulation with a deferred exchange (VoiceBoxTrainer.train_step, trainer.py:258-272: every micro-batch but
+    #    the last runs under accelerator.no_sync, the loss is divided by grad_accum_every)
+    def accumulate(self, x1, weight, mask=None, cond_token_ids=None):
+        """forward + backward of one micro-batch; gradients * weight are added to the accumulation buffer (no exchange)."""
+        if getattr(self, "gacc", None) is None:
+            self.gacc = torch.zeros_like(self.gflat)
+            self.acc_coef = torch.zeros(1, device=self.gflat.device)
+            self.acc_pending = False
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=None)
+        self.acc_coef.fill_(float(weight))
+        n = self.gflat.numel()
+        _lib.call("vbx_axpy_dev", self.gacc, self.gflat, self.acc_coef, 0, self.gacc, n, _lib.current_stream())
+        self.acc_pending = True
+        return loss
+
+    def apply_accumulated(self, lr=None):
+        """all-reduce (sum) of the accumulated gradients, clip, Adam; clears the accumulator."""
+        assert getattr(self, "acc_pending", False), "nothing accumulated"
+        self.gflat.copy_(self.gacc)
+        self.gacc.zero_()
+        self.acc_pending = False
+        if self.world > 1:
+            red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
+                                    comm_stream=self.comm_stream)
+            for i, rng in enumerate(self.fp.stage_ranges):
+                red.stage_done(i, rng)
+            red.finish()
+        self._clip_adam(self._last_eng, lr)
+
+    def _forward_backward(self, x1, mask, cond_token_ids, on_stage):
         vb, w = self.vb, self.wrapper
         dev = self.fp.flat.device
         st = _lib.current_stream
@@ -157,12 +184,13 @@ class TrainStep:
             text = (cond_token_ids.to(dev), vb.null_cond_id, drop, vb.null_cond)
         eng = vb.engine(B, N, training=True)
         loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
-        # --- backward with overlapped gradient exchange
-        red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
-                                comm_stream=self.comm_stream)
-        eng.backward(self.gflat, gscale=None, on_stage=red.stage_done if self.world > 1 else None)
-        red.finish()
+        eng.backward(self.gflat, gscale=None, on_stage=on_stage)
+        self._last_eng = eng
+        return loss
+
+    def _clip_adam(self, eng, lr):
         # --- clip (global norm of the rank-averaged gradient) + Adam, all on device, no host sync
+        st = _lib.current_stream
         n = self.gflat.numel()
         if lr is None and self.lr_schedule is not None:
             lr = self.lr_schedule.rate_for_step(self.steps)
@@ -177,4 +205,14 @@ class TrainStep:
         else:  # A/B: plain Adam, the next forward repacks every weight
             _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
                       float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
+
+    def step(self, x1, mask=None, lr=None, cond_token_ids=None):
+        """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
+        Returns the (un-synchronised) local loss tensor."""
+        # --- backward with overlapped gradient exchange
+        red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
+                                comm_stream=self.comm_stream)
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.world > 1 else None)
+        red.finish()
+        self._clip_adam(self._last_eng, lr)
         return loss
