@@ -208,10 +208,10 @@ VBX_DEV int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 // Per-thread, loop-invariant description of the LDS-DMA pieces of one operand (hoisted out of the k-loop: the 8192^3
 // profile of the first version showed 3 non-MFMA VALU instructions per MFMA, almost all address arithmetic).
-template <int MODE, int OUTER>
+template <int MODE, int OUTER, int NTHR = 256>
 struct DmaPlan {
   static_assert(MODE == 0 || OUTER == 128, "K-strided stages are 128 wide");
-  static constexpr int N = OUTER / 64;  // DMA instructions per thread per stage
+  static constexpr int N = OUTER * 4 / NTHR;  // DMA instructions per thread per stage (OUTER*4 sixteen-byte slots)
   const u16* base[N];                   // source of k-tile 0
   int kq[N];                            // MODE 0: k offset of the piece inside the tile; MODE 1: k row of the piece
   bool ok[N];                           // outer index in range
@@ -220,7 +220,7 @@ struct DmaPlan {
     kstride = (MODE == 0) ? 1 : ld;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      const int s = i * 256 + tid;  // 16-byte slot inside the operand stage (lane-linear: slot = base + lane)
+      const int s = i * NTHR + tid;  // 16-byte slot inside the operand stage (lane-linear: slot = base + lane)
       if (MODE == 0) {
         const int p = s >> 3, x = (s & 7) ^ (p & 7);
         const int r = 2 * p + (x >> 2);
@@ -243,7 +243,7 @@ struct DmaPlan {
     for (int i = 0; i < N; i++) {
       const bool in = ok[i] && (k0 + kq[i] < kend);
       const u16* src = in ? base[i] + (long)k0 * kstride : reinterpret_cast<const u16*>(g_zero_page);
-      char* wave_dst = dst + (i * 256 + (tid & ~63)) * 16;  // the DMA adds lane*16
+      char* wave_dst = dst + (i * NTHR + (tid & ~63)) * 16;  // the DMA adds lane*16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
     }
@@ -555,6 +555,97 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_w256(GemmParams p, Epi epi
   }
 }
 
+// ---- 128 x 256 tile, EIGHT waves of 64 x 64 (512 threads): the operand intensity of gemm_kernel_w256 (85 FLOP/B) with the
+// per-wave register footprint of gemm_kernel_v2 (64 accumulator VGPRs) and twice the waves to run the epilogue: 2 workgroups per
+// CU = 16 waves.  NT only.
+template <class Epi, bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_w256x8(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int kend = p.K;
+  const int nt = (kend + BK2 - 1) / BK2;
+
+  DmaPlan<0, 128, 512> da;
+  DmaPlan<0, 256, 512> db;
+  da.init(p.A, p.lda, m0, p.M, tid);
+  db.init(p.B, p.ldb, n0, p.N, tid);
+  FragPlan<0> fa, fb;
+  fa.init(smem, wm * 64, lane);
+  fb.init(smem, wn * 64, lane);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; s++) {
+    if (s < nt) {
+      da.issue(smem + s * W256_STAGE, s * BK2, kend, tid);
+      db.issue(smem + s * W256_STAGE + OP_BYTES, s * BK2, kend, tid);
+    }
+  }
+  auto step = [&](auto stg_c, int t) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int NXT = (STG + NST - 1) % NST;
+    if (nt - 1 - t >= NST - 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // 3 DMA instructions per thread per stage
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NST - 1 < nt) {
+      da.issue(smem + NXT * W256_STAGE, (t + NST - 1) * BK2, kend, tid);
+      db.issue(smem + NXT * W256_STAGE + OP_BYTES, (t + NST - 1) * BK2, kend, tid);
+    }
+    bf16x8 af[4], bfr[4];
+    s16x4 dl, dh;
+    fa.template read<STG * W256_STAGE, 0>(af[0], dl, dh);
+    fa.template read<STG * W256_STAGE, 1>(af[1], dl, dh);
+    fa.template read<STG * W256_STAGE, 2>(af[2], dl, dh);
+    fa.template read<STG * W256_STAGE, 3>(af[3], dl, dh);
+    fb.template read<STG * W256_STAGE + OP_BYTES, 0>(bfr[0], dl, dh);
+    fb.template read<STG * W256_STAGE + OP_BYTES, 1>(bfr[1], dl, dh);
+    fb.template read<STG * W256_STAGE + OP_BYTES, 2>(bfr[2], dl, dh);
+    fb.template read<STG * W256_STAGE + OP_BYTES, 3>(bfr[3], dl, dh);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+  };
+  for (int t = 0; t < nt; t += 3) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
+  }
+  // ---- epilogue: per 64-row half the two 128-column quarters are staged side by side; threads 0-255 run the functor on the
+  // first quarter, 256-511 on the second
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int qsel = tid >> 8, tq = tid & 255;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    __syncthreads();
+    if (wm == h) {
+      float* Cq = Cs + (wn >> 1) * 64 * CS_LD + (wn & 1) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) Cq[(i * 16 + (lane >> 4) * 4 + rr) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+    }
+    __syncthreads();
+    if (n0 + qsel * 128 < p.N) epi(Cs + qsel * 64 * CS_LD, m0 + h * 64, n0 + qsel * 128, tq, 0, p.M, p.N, 64);
+  }
+}
+
 VBX_DEV void load8(const float* Cs, int row, int cc, float v[8]) {
   const float4 a = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8);
   const float4 b = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8 + 4);
@@ -768,6 +859,25 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     // of 3 workgroups per CU the ~14 us VALU epilogues (GEGLU, qk-norm + rotary) overlap less and the train step came out
     // 1 % SLOWER, sampling unchanged -- so the 128x128 kernel stays the default.
     static const char* w256 = getenv("VBX_GEMM_W256");
+    // 128x256 tiles with eight 64x64 waves: opt-in.  Back-to-back launches of the same GEMM (tools/gemm_bench.py) run 16 % faster
+    // (FeedForward-in 45.4 -> 38.3 us, 625 TF/s) -- but there the next launch's workgroups hide the tail of the previous one.  In
+    // the model the next kernel is a dependent one, the coarser tiles (780 instead of 1560, 2 per CU) leave a longer tail, and the
+    // 128-forward sample came out 3 % SLOWER (375 -> 387 ms); the train step is unchanged.  Measure GEMM variants in situ.
+    static const char* w8 = getenv("VBX_GEMM_W256X8");
+    // 2: every NT GEMM wider than one tile (tests); 1: only the wide forward GEMMs (to_qkv, FeedForward-in)
+    const int w8v = w8 ? atoi(w8) : 0;
+    const bool wide8 = (w8v == 2 ? p.N > 128 : (w8v == 1 && p.N >= 2048)) && !legacy && splits == 1;
+    if (wide8) {
+      static bool attr8 = false;
+      auto kern8 = gemm_kernel_w256x8<Epi, F16>;
+      if (!attr8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern8), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W256_LDS);
+        attr8 = true;
+      }
+      hipLaunchKernelGGL(kern8, dim3(p.tiles_m * cdiv(p.N, 256)), dim3(512), GEMM_W256_LDS, st, p, epi);
+      VBX_LAUNCH_CHECK();
+      return 0;
+    }
     const bool wide = w256 && atoi(w256) != 0 && p.N > 128;
     if (wide && !legacy && splits == 1) {
       static bool attrw = false;
