@@ -646,6 +646,126 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_w256x8(GemmParams p, Epi e
   }
 }
 
+// ---- 160 x 128 tile, 2x2 waves of 80 x 64, ONE workgroup per CU with a 5-slot ring.  For the N = dim GEMMs (to_out,
+// FeedForward-out, the dgrads into the residual width) at M = 8 x 1040 = 8320 rows: 128-row tiles give 65 x 4 = 260 workgroups,
+// i.e. 4 CUs get TWO tiles and the kernel lasts as long as those (FeedForward-out: 37 us for 11.6 GFLOP); 8320 = 52 x 160 gives
+// 208 equal tiles, one per CU, in one round.  A single resident workgroup needs the deeper ring to keep the same number of
+// operand bytes in flight (4 stages x 18 KiB vs 3 workgroups x 2 x 16 KiB).  MA == 0 (A is K-contiguous); B either way.
+constexpr int V4_NST = 5;
+constexpr int V4_A_BYTES = 12288;                      // [192][32] 16-bit window, rows 160..191 never read
+constexpr int V4_STAGE = V4_A_BYTES + OP_BYTES;        // 20 KiB
+constexpr int GEMM_V4_LDS = V4_NST * V4_STAGE;         // 100 KiB
+template <int MB, class Epi, bool F16>
+__global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * 160, n0 = tn * BN;
+  const int kend = p.K;
+  const int nt = (kend + BK2 - 1) / BK2;
+
+  DmaPlan<0, 192> da;  // 3 DMA instructions per thread; window rows >= 160 are pointed at the zero page
+  DmaPlan<MB, 128> db;
+  da.init(p.A, p.lda, m0, min(p.M, m0 + 160), tid);
+  db.init(p.B, p.ldb, n0, p.N, tid);
+  // DS immediates are 16-bit: slots 0-2 are addressed from the ring base, slots 3-4 from a second base 60 KiB further
+  FragPlan<0> fa, fa2;
+  FragPlan<MB> fb, fb2;
+  fa.init(smem, wm * 80, lane);
+  fb.init(smem, wn * 64, lane);
+  fa2.init(smem + 3 * V4_STAGE, wm * 80, lane);
+  fb2.init(smem + 3 * V4_STAGE, wn * 64, lane);
+
+  f32x4 acc[5][4];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < V4_NST - 1; s++) {
+    if (s < nt) {
+      da.issue(smem + s * V4_STAGE, s * BK2, kend, tid);
+      db.issue(smem + s * V4_STAGE + V4_A_BYTES, s * BK2, kend, tid);
+    }
+  }
+  // (A software-pipelined variant -- fragments of k-tile t+1 requested before the MFMAs of t, two register sets -- was measured
+  //  SLOWER in situ: it has to wait for k-tile t+1 one iteration earlier, which costs more than the exposed LDS round trip.)
+  auto step = [&](auto stg_c, int t) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int NXT = (STG + V4_NST - 1) % V4_NST;
+    // 5 DMA instructions per thread per stage; tile t has landed once at most min(NST-2, tiles left) younger stages are pending
+    const int younger = min(V4_NST - 2, nt - 1 - t);
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + V4_NST - 1 < nt) {
+      da.issue(smem + NXT * V4_STAGE, (t + V4_NST - 1) * BK2, kend, tid);
+      db.issue(smem + NXT * V4_STAGE + V4_A_BYTES, (t + V4_NST - 1) * BK2, kend, tid);
+    }
+    bf16x8 af[5], bfr[4];
+    s16x4 dl, dh, blo[4], bhi[4];
+    constexpr int SO = (STG % 3) * V4_STAGE;  // offset from the base that covers this slot
+    const FragPlan<0>& pa = STG < 3 ? fa : fa2;
+    const FragPlan<MB>& pb = STG < 3 ? fb : fb2;
+    pa.template read<SO, 0>(af[0], dl, dh);
+    pa.template read<SO, 1>(af[1], dl, dh);
+    pa.template read<SO, 2>(af[2], dl, dh);
+    pa.template read<SO, 3>(af[3], dl, dh);
+    pa.template read<SO, 4>(af[4], dl, dh);
+    pb.template read<SO + V4_A_BYTES, 0>(bfr[0], blo[0], bhi[0]);
+    pb.template read<SO + V4_A_BYTES, 1>(bfr[1], blo[1], bhi[1]);
+    pb.template read<SO + V4_A_BYTES, 2>(bfr[2], blo[2], bhi[2]);
+    pb.template read<SO + V4_A_BYTES, 3>(bfr[3], blo[3], bhi[3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (MB == 1) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
+        bfr[s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+  };
+  for (int t = 0; t < nt; t += 5) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
+    if (t + 3 < nt) step(std::integral_constant<int, 3>{}, t + 3);
+    if (t + 4 < nt) step(std::integral_constant<int, 4>{}, t + 4);
+  }
+  // ---- epilogue in five 32-row chunks (wave rows 0-79 / 80-159: chunk 2 takes 16 rows from each)
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int trow = wm * 80 + i * 16;  // tile row of this fragment
+      if ((trow >> 5) == c) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            Cs[(trow - 32 * c + (lane >> 4) * 4 + rr) * CS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][rr];
+      }
+    }
+    __syncthreads();
+    epi(Cs, m0 + c * 32, n0, tid, 0, p.M, p.N, 32);
+  }
+}
+
 VBX_DEV void load8(const float* Cs, int row, int cc, float v[8]) {
   const float4 a = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8);
   const float4 b = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8 + 4);
@@ -887,6 +1007,24 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
         attrw = true;
       }
       hipLaunchKernelGGL(kernw, dim3(p.tiles_m * cdiv(p.N, 256)), dim3(256), GEMM_W256_LDS, st, p, epi);
+      VBX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if constexpr (MA == 0) {
+    // one-round 160-row tiles when 128-row tiles would put two on a few CUs (see gemm_kernel_bm160).  VBX_GEMM_BM160=0/1: A/B.
+    static const char* b160 = getenv("VBX_GEMM_BM160");
+    const long t128 = (long)p.tiles_m * tiles_n, t160 = (long)cdiv(p.M, 160) * tiles_n;
+    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && t160 <= 256;
+    if (use160) {
+      static bool attr160 = false;
+      auto k160 = gemm_kernel_bm160<MB, Epi, F16>;
+      if (!attr160) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k160), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V4_LDS);
+        attr160 = true;
+      }
+      p.tiles_m = cdiv(p.M, 160);
+      hipLaunchKernelGGL(k160, dim3(p.tiles_m * tiles_n), dim3(256), GEMM_V4_LDS, st, p, epi);
       VBX_LAUNCH_CHECK();
       return 0;
     }
