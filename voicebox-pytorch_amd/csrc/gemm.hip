@@ -651,12 +651,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_w256x8(GemmParams p, Epi e
 // i.e. 4 CUs get TWO tiles and the kernel lasts as long as those (FeedForward-out: 37 us for 11.6 GFLOP); 8320 = 52 x 160 gives
 // 208 equal tiles, one per CU, in one round.  A single resident workgroup needs the deeper ring to keep the same number of
 // operand bytes in flight (4 stages x 18 KiB vs 3 workgroups x 2 x 16 KiB).  MA == 0 (A is K-contiguous); B either way.
-constexpr int V4_NST = 5;
 constexpr int V4_A_BYTES = 12288;                      // [192][32] 16-bit window, rows 160..191 never read
 constexpr int V4_STAGE = V4_A_BYTES + OP_BYTES;        // 20 KiB
-constexpr int GEMM_V4_LDS = V4_NST * V4_STAGE;         // 100 KiB
-template <int MB, class Epi, bool F16>
-__global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi epi) {
+constexpr int GEMM_V4_LDS = 5 * V4_STAGE;              // 100 KiB (5-slot ring); the 3-slot form uses 60 KiB
+// NST_ = 5: one workgroup per CU (100 KiB).  NST_ = 3: 60 KiB -> two workgroups per CU, for the wide GEMMs whose 128-row tile
+// count leaves a long tail (to_qkv: 1560 tiles = 6.09 per CU -> 7 rounds; 1248 tiles of 160 rows = 4.9 -> 5 rounds of 1.125).
+template <int MB, class Epi, bool F16, int NST_>
+__global__ __launch_bounds__(256, NST_ == 5 ? 1 : 2) void gemm_kernel_bm160(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -678,8 +679,10 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi ep
   FragPlan<MB> fb, fb2;
   fa.init(smem, wm * 80, lane);
   fb.init(smem, wn * 64, lane);
-  fa2.init(smem + 3 * V4_STAGE, wm * 80, lane);
-  fb2.init(smem + 3 * V4_STAGE, wn * 64, lane);
+  if (NST_ > 3) {
+    fa2.init(smem + 3 * V4_STAGE, wm * 80, lane);
+    fb2.init(smem + 3 * V4_STAGE, wn * 64, lane);
+  }
 
   f32x4 acc[5][4];
 #pragma unroll
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi ep
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-  for (int s = 0; s < V4_NST - 1; s++) {
+  for (int s = 0; s < NST_ - 1; s++) {
     if (s < nt) {
       da.issue(smem + s * V4_STAGE, s * BK2, kend, tid);
       db.issue(smem + s * V4_STAGE + V4_A_BYTES, s * BK2, kend, tid);
@@ -698,17 +701,17 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi ep
   //  SLOWER in situ: it has to wait for k-tile t+1 one iteration earlier, which costs more than the exposed LDS round trip.)
   auto step = [&](auto stg_c, int t) {
     constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + V4_NST - 1) % V4_NST;
+    constexpr int NXT = (STG + NST_ - 1) % NST_;
     // 5 DMA instructions per thread per stage; tile t has landed once at most min(NST-2, tiles left) younger stages are pending
-    const int younger = min(V4_NST - 2, nt - 1 - t);
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    const int younger = min(NST_ - 2, nt - 1 - t);
+    if (NST_ == 5 && younger >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if (NST_ == 5 && younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + V4_NST - 1 < nt) {
-      da.issue(smem + NXT * V4_STAGE, (t + V4_NST - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * V4_STAGE + V4_A_BYTES, (t + V4_NST - 1) * BK2, kend, tid);
+    if (t + NST_ - 1 < nt) {
+      da.issue(smem + NXT * V4_STAGE, (t + NST_ - 1) * BK2, kend, tid);
+      db.issue(smem + NXT * V4_STAGE + V4_A_BYTES, (t + NST_ - 1) * BK2, kend, tid);
     }
     bf16x8 af[5], bfr[4];
     s16x4 dl, dh, blo[4], bhi[4];
@@ -738,12 +741,14 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_bm160(GemmParams p, Epi ep
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
   };
-  for (int t = 0; t < nt; t += 5) {
+  for (int t = 0; t < nt; t += NST_) {
     step(std::integral_constant<int, 0>{}, t);
     if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
     if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-    if (t + 3 < nt) step(std::integral_constant<int, 3>{}, t + 3);
-    if (t + 4 < nt) step(std::integral_constant<int, 4>{}, t + 4);
+    if (NST_ == 5) {
+      if (t + 3 < nt) step(std::integral_constant<int, 3 % NST_>{}, t + 3);
+      if (t + 4 < nt) step(std::integral_constant<int, 4 % NST_>{}, t + 4);
+    }
   }
   // ---- epilogue in five 32-row chunks (wave rows 0-79 / 80-159: chunk 2 takes 16 rows from each)
   float* Cs = reinterpret_cast<float*>(smem);
@@ -1018,13 +1023,29 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && t160 <= 256;
     if (use160) {
       static bool attr160 = false;
-      auto k160 = gemm_kernel_bm160<MB, Epi, F16>;
+      auto k160 = gemm_kernel_bm160<MB, Epi, F16, 5>;
       if (!attr160) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k160), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V4_LDS);
         attr160 = true;
       }
       p.tiles_m = cdiv(p.M, 160);
       hipLaunchKernelGGL(k160, dim3(p.tiles_m * tiles_n), dim3(256), GEMM_V4_LDS, st, p, epi);
+      VBX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if constexpr (MA == 0 && MB == 0) {
+    // wide forward GEMMs: 160-row tiles, 3-slot ring, 2 workgroups per CU.  VBX_GEMM_BM160W=0/1: A/B.
+    static const char* b160w = getenv("VBX_GEMM_BM160W");
+    if ((b160w ? atoi(b160w) != 0 : false) && !legacy && splits == 1 && p.N >= 2048) {
+      static bool attrw = false;
+      auto k160w = gemm_kernel_bm160<MB, Epi, F16, 3>;
+      if (!attrw) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k160w), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V4_STAGE);
+        attrw = true;
+      }
+      p.tiles_m = cdiv(p.M, 160);
+      hipLaunchKernelGGL(k160w, dim3(p.tiles_m * tiles_n), dim3(256), 3 * V4_STAGE, st, p, epi);
       VBX_LAUNCH_CHECK();
       return 0;
     }
