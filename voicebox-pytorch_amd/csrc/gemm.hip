@@ -653,6 +653,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_w256x8(GemmParams p, Epi e
 // operand bytes in flight (4 stages x 18 KiB vs 3 workgroups x 2 x 16 KiB).  MA == 0 (A is K-contiguous); B either way.
 constexpr int V4_A_BYTES = 12288;                      // [192][32] 16-bit window, rows 160..191 never read
 constexpr int V4_STAGE = V4_A_BYTES + OP_BYTES;        // 20 KiB
+constexpr int V8_A_BYTES = 16384;                      // 8-wave form: [256][32] window (2 DMA instructions x 512 threads)
+constexpr int V8_STAGE = V8_A_BYTES + OP_BYTES;        // 24 KiB
+constexpr int GEMM_V8_LDS = 5 * V8_STAGE;              // 120 KiB
 constexpr int GEMM_V4_LDS = 5 * V4_STAGE;              // 100 KiB (5-slot ring); the 3-slot form uses 60 KiB
 // NST_ = 5: one workgroup per CU (100 KiB).  NST_ = 3: 60 KiB -> two workgroups per CU, for the wide GEMMs whose 128-row tile
 // count leaves a long tail (to_qkv: 1560 tiles = 6.09 per CU -> 7 rounds; 1248 tiles of 160 rows = 4.9 -> 5 rounds of 1.125).
@@ -768,6 +771,119 @@ __global__ __launch_bounds__(256, NST_ == 5 ? 1 : 2) void gemm_kernel_bm160(Gemm
     }
     __syncthreads();
     epi(Cs, m0 + c * 32, n0, tid, 0, p.M, p.N, 32);
+  }
+}
+
+// ---- 160 x 128 tile with EIGHT waves of 80 x 32 (512 threads), one workgroup per CU, 5-slot ring: two waves per SIMD, so one
+// wave's MFMAs run while the other waits for its LDS fragments (with four waves that round trip is exposed on every k-step).
+template <int MB, class Epi, bool F16>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_bm160x8(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * 160, n0 = tn * BN;
+  const int kend = p.K;
+  const int nt = (kend + BK2 - 1) / BK2;
+  constexpr int NST_ = 5;
+
+  DmaPlan<0, 256, 512> da;  // 2 DMA instructions per thread over a 256-row window; rows >= 160 point at the zero page
+  DmaPlan<MB, 128, 512> db;
+  da.init(p.A, p.lda, m0, min(p.M, m0 + 160), tid);
+  db.init(p.B, p.ldb, n0, p.N, tid);
+  // DS immediates are 16-bit: one base per pair of 24-KiB slots
+  FragPlan<0> fa, fa2, fa3;
+  FragPlan<MB> fb, fb2, fb3;
+  fa.init(smem, wm * 80, lane);
+  fb.init(smem, wn * 32, lane);
+  fa2.init(smem + 2 * V8_STAGE, wm * 80, lane);
+  fb2.init(smem + 2 * V8_STAGE, wn * 32, lane);
+  fa3.init(smem + 4 * V8_STAGE, wm * 80, lane);
+  fb3.init(smem + 4 * V8_STAGE, wn * 32, lane);
+
+  f32x4 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST_ - 1; s++) {
+    if (s < nt) {
+      da.issue(smem + s * V8_STAGE, s * BK2, kend, tid);
+      db.issue(smem + s * V8_STAGE + V8_A_BYTES, s * BK2, kend, tid);
+    }
+  }
+  auto step = [&](auto stg_c, int t) {
+    constexpr int STG = decltype(stg_c)::value;
+    constexpr int NXT = (STG + NST_ - 1) % NST_;
+    const int younger = min(NST_ - 2, nt - 1 - t);  // 3 DMA instructions per thread per stage
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NST_ - 1 < nt) {
+      da.issue(smem + NXT * V8_STAGE, (t + NST_ - 1) * BK2, kend, tid);
+      db.issue(smem + NXT * V8_STAGE + V8_A_BYTES, (t + NST_ - 1) * BK2, kend, tid);
+    }
+    bf16x8 af[5], bfr[2];
+    s16x4 dl, dh, blo[2], bhi[2];
+    constexpr int SO = (STG % 2) * V8_STAGE;
+    const FragPlan<0>& pa = STG < 2 ? fa : (STG < 4 ? fa2 : fa3);
+    const FragPlan<MB>& pb = STG < 2 ? fb : (STG < 4 ? fb2 : fb3);
+    pa.template read<SO, 0>(af[0], dl, dh);
+    pa.template read<SO, 1>(af[1], dl, dh);
+    pa.template read<SO, 2>(af[2], dl, dh);
+    pa.template read<SO, 3>(af[3], dl, dh);
+    pa.template read<SO, 4>(af[4], dl, dh);
+    pb.template read<SO + V8_A_BYTES, 0>(bfr[0], blo[0], bhi[0]);
+    pb.template read<SO + V8_A_BYTES, 1>(bfr[1], blo[1], bhi[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (MB == 1) {
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
+        bfr[s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+  };
+  for (int t = 0; t < nt; t += 5) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
+    if (t + 3 < nt) step(std::integral_constant<int, 3>{}, t + 3);
+    if (t + 4 < nt) step(std::integral_constant<int, 4>{}, t + 4);
+  }
+  // ---- epilogue: 64-row chunks [0,64) [64,128) [128,160); threads 0-255 run the functor on the first 32 rows of a chunk,
+  // threads 256-511 on the second 32
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int half = tid >> 8, tq = tid & 255;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int trow = wm * 80 + i * 16;
+      if ((trow >> 6) == c) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            Cs[(trow - 64 * c + (lane >> 4) * 4 + rr) * CS_LD + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][rr];
+      }
+    }
+    __syncthreads();
+    if (c < 2 || half == 0) epi(Cs + half * 32 * CS_LD, m0 + c * 64 + half * 32, n0, tq, 0, p.M, p.N, 32);
   }
 }
 
@@ -1021,6 +1137,20 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     static const char* b160 = getenv("VBX_GEMM_BM160");
     const long t128 = (long)p.tiles_m * tiles_n, t160 = (long)cdiv(p.M, 160) * tiles_n;
     const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && t160 <= 256;
+    // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
+    static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
+    if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
+      static bool attr8 = false;
+      auto k8 = gemm_kernel_bm160x8<MB, Epi, F16>;
+      if (!attr8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V8_LDS);
+        attr8 = true;
+      }
+      p.tiles_m = cdiv(p.M, 160);
+      hipLaunchKernelGGL(k8, dim3(p.tiles_m * tiles_n), dim3(512), GEMM_V8_LDS, st, p, epi);
+      VBX_LAUNCH_CHECK();
+      return 0;
+    }
     if (use160) {
       static bool attr160 = false;
       auto k160 = gemm_kernel_bm160<MB, Epi, F16, 5>;
