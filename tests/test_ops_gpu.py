@@ -244,7 +244,8 @@ def test_gemm_geglu_epilogue(L):
 
 # ----------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("Bsz,Np,n0,rpb,D,adaptive", [(2, 40, 0, 40, 64, True), (8, 1040, 0, 1040, 512, True),
-                                                     (2, 56, 16, 40, 256, False), (3, 33, 0, 33, 1024, True)])
+                                                     (2, 56, 16, 40, 256, False), (3, 33, 0, 33, 1024, True),
+                                                     (2, 19, 0, 19, 2048, True)])
 def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
     g = torch.Generator().manual_seed(D + Np)
     x = torch.randn(Bsz, Np, D, generator=g)

@@ -441,211 +441,6 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
   }
 }
 
-// ---- 128 x 256 tile variant (NT only): 4 waves of 64 x 128.  The 128x128 kernel is bound by the L2->LDS operand stream
-// (ablations above); a 128x256 tile moves 24 KiB per k-step for twice the MFMA work (85 instead of 64 FLOP/B).
-// 3-slot ring of 24 KiB stages = 72 KiB -> 2 workgroups per CU; 128 accumulator VGPRs per lane.
-constexpr int W256_STAGE = OP_BYTES + 2 * OP_BYTES;   // A [128][32] | B [256][32]
-constexpr int GEMM_W256_LDS = NST * W256_STAGE;       // 72 KiB; also holds two 64x128 fp32 C quarter tiles
-static_assert(GEMM_W256_LDS >= 2 * 64 * CS_LD * 4, "two C quarter tiles must fit");
-template <class Epi, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_w256(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * 128, n0 = tn * 256;
-  const int kend = p.K;
-  const int nt = (kend + BK2 - 1) / BK2;
-
-  DmaPlan<0, 128> da;
-  DmaPlan<0, 256> db;
-  da.init(p.A, p.lda, m0, p.M, tid);
-  db.init(p.B, p.ldb, n0, p.N, tid);
-  FragPlan<0> fa, fb;
-  fa.init(smem, wm * 64, lane);
-  fb.init(smem, wn * 128, lane);
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NST - 1; s++) {
-    if (s < nt) {
-      da.issue(smem + s * W256_STAGE, s * BK2, kend, tid);
-      db.issue(smem + s * W256_STAGE + OP_BYTES, s * BK2, kend, tid);
-    }
-  }
-  auto step = [&](auto stg_c, int t) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + NST - 1) % NST;
-    if (nt - 1 - t >= NST - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // 6 DMA instructions per stage
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NST - 1 < nt) {
-      da.issue(smem + NXT * W256_STAGE, (t + NST - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * W256_STAGE + OP_BYTES, (t + NST - 1) * BK2, kend, tid);
-    }
-    bf16x8 af[4], bfr[8];
-    s16x4 dl, dh;
-    fa.template read<STG * W256_STAGE, 0>(af[0], dl, dh);
-    fa.template read<STG * W256_STAGE, 1>(af[1], dl, dh);
-    fa.template read<STG * W256_STAGE, 2>(af[2], dl, dh);
-    fa.template read<STG * W256_STAGE, 3>(af[3], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 0>(bfr[0], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 1>(bfr[1], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 2>(bfr[2], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 3>(bfr[3], dl, dh);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // second half of the B fragments lands under the first 16 MFMAs
-    fb.template read<STG * W256_STAGE + OP_BYTES, 4>(bfr[4], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 5>(bfr[5], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 6>(bfr[6], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 7>(bfr[7], dl, dh);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 4; j < 8; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-  };
-  for (int t = 0; t < nt; t += 3) {
-    step(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-  }
-  // ---- epilogue: per 64-row half, both 128-column quarters are staged side by side and handed to the 128-wide functors
-  float* Cs = reinterpret_cast<float*>(smem);
-  if (p.abl & 64) {  // ablation: no epilogue at all (keep the accumulators alive)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 8; j++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 123.456f) Cs[tid] = t;
-    return;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    __syncthreads();
-    if (wm == h) {
-      float* Cq = Cs + wn * 64 * CS_LD;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) Cq[(i * 16 + (lane >> 4) * 4 + rr) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
-    }
-    __syncthreads();
-    if (p.abl & 32) continue;
-    epi(Cs, m0 + h * 64, n0, tid, 0, p.M, p.N, 64);
-    if (n0 + 128 < p.N) epi(Cs + 64 * CS_LD, m0 + h * 64, n0 + 128, tid, 0, p.M, p.N, 64);
-  }
-}
-
-// ---- 128 x 256 tile, EIGHT waves of 64 x 64 (512 threads): the operand intensity of gemm_kernel_w256 (85 FLOP/B) with the
-// per-wave register footprint of gemm_kernel_v2 (64 accumulator VGPRs) and twice the waves to run the epilogue: 2 workgroups per
-// CU = 16 waves.  NT only.
-template <class Epi, bool F16>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_w256x8(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * 128, n0 = tn * 256;
-  const int kend = p.K;
-  const int nt = (kend + BK2 - 1) / BK2;
-
-  DmaPlan<0, 128, 512> da;
-  DmaPlan<0, 256, 512> db;
-  da.init(p.A, p.lda, m0, p.M, tid);
-  db.init(p.B, p.ldb, n0, p.N, tid);
-  FragPlan<0> fa, fb;
-  fa.init(smem, wm * 64, lane);
-  fb.init(smem, wn * 64, lane);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NST - 1; s++) {
-    if (s < nt) {
-      da.issue(smem + s * W256_STAGE, s * BK2, kend, tid);
-      db.issue(smem + s * W256_STAGE + OP_BYTES, s * BK2, kend, tid);
-    }
-  }
-  auto step = [&](auto stg_c, int t) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + NST - 1) % NST;
-    if (nt - 1 - t >= NST - 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // 3 DMA instructions per thread per stage
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NST - 1 < nt) {
-      da.issue(smem + NXT * W256_STAGE, (t + NST - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * W256_STAGE + OP_BYTES, (t + NST - 1) * BK2, kend, tid);
-    }
-    bf16x8 af[4], bfr[4];
-    s16x4 dl, dh;
-    fa.template read<STG * W256_STAGE, 0>(af[0], dl, dh);
-    fa.template read<STG * W256_STAGE, 1>(af[1], dl, dh);
-    fa.template read<STG * W256_STAGE, 2>(af[2], dl, dh);
-    fa.template read<STG * W256_STAGE, 3>(af[3], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 0>(bfr[0], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 1>(bfr[1], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 2>(bfr[2], dl, dh);
-    fb.template read<STG * W256_STAGE + OP_BYTES, 3>(bfr[3], dl, dh);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-  };
-  for (int t = 0; t < nt; t += 3) {
-    step(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-  }
-  // ---- epilogue: per 64-row half the two 128-column quarters are staged side by side; threads 0-255 run the functor on the
-  // first quarter, 256-511 on the second
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int qsel = tid >> 8, tq = tid & 255;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    __syncthreads();
-    if (wm == h) {
-      float* Cq = Cs + (wn >> 1) * 64 * CS_LD + (wn & 1) * 64;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) Cq[(i * 16 + (lane >> 4) * 4 + rr) * CS_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
-    }
-    __syncthreads();
-    if (n0 + qsel * 128 < p.N) epi(Cs + qsel * 64 * CS_LD, m0 + h * 64, n0 + qsel * 128, tq, 0, p.M, p.N, 64);
-  }
-}
-
 // ---- 160 x 128 tile, 2x2 waves of 80 x 64, ONE workgroup per CU with a 5-slot ring.  For the N = dim GEMMs (to_out,
 // FeedForward-out, the dgrads into the residual width) at M = 8 x 1040 = 8320 rows: 128-row tiles give 65 x 4 = 260 workgroups,
 // i.e. 4 CUs get TWO tiles and the kernel lasts as long as those (FeedForward-out: 37 us for 11.6 GFLOP); 8320 = 52 x 160 gives
@@ -1094,44 +889,11 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     attr_set = true;
   }
   const int tiles_n = cdiv(p.N, BN);
-  if constexpr (MA == 0 && MB == 0) {
-    // 128x256 tiles: opt-in (VBX_GEMM_W256=1).  Measured on the benchmark shapes: the main loop alone is 30 % faster
-    // (727 -> 935 TF/s from the K sweep), the isolated to_qkv / FeedForward-in launches 3-8 % faster, but with 2 instead
-    // of 3 workgroups per CU the ~14 us VALU epilogues (GEGLU, qk-norm + rotary) overlap less and the train step came out
-    // 1 % SLOWER, sampling unchanged -- so the 128x128 kernel stays the default.
-    static const char* w256 = getenv("VBX_GEMM_W256");
-    // 128x256 tiles with eight 64x64 waves: opt-in.  Back-to-back launches of the same GEMM (tools/gemm_bench.py) run 16 % faster
-    // (FeedForward-in 45.4 -> 38.3 us, 625 TF/s) -- but there the next launch's workgroups hide the tail of the previous one.  In
-    // the model the next kernel is a dependent one, the coarser tiles (780 instead of 1560, 2 per CU) leave a longer tail, and the
-    // 128-forward sample came out 3 % SLOWER (375 -> 387 ms); the train step is unchanged.  Measure GEMM variants in situ.
-    static const char* w8 = getenv("VBX_GEMM_W256X8");
-    // 2: every NT GEMM wider than one tile (tests); 1: only the wide forward GEMMs (to_qkv, FeedForward-in)
-    const int w8v = w8 ? atoi(w8) : 0;
-    const bool wide8 = (w8v == 2 ? p.N > 128 : (w8v == 1 && p.N >= 2048)) && !legacy && splits == 1;
-    if (wide8) {
-      static bool attr8 = false;
-      auto kern8 = gemm_kernel_w256x8<Epi, F16>;
-      if (!attr8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern8), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W256_LDS);
-        attr8 = true;
-      }
-      hipLaunchKernelGGL(kern8, dim3(p.tiles_m * cdiv(p.N, 256)), dim3(512), GEMM_W256_LDS, st, p, epi);
-      VBX_LAUNCH_CHECK();
-      return 0;
-    }
-    const bool wide = w256 && atoi(w256) != 0 && p.N > 128;
-    if (wide && !legacy && splits == 1) {
-      static bool attrw = false;
-      auto kernw = gemm_kernel_w256<Epi, F16>;
-      if (!attrw) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernw), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W256_LDS);
-        attrw = true;
-      }
-      hipLaunchKernelGGL(kernw, dim3(p.tiles_m * cdiv(p.N, 256)), dim3(256), GEMM_W256_LDS, st, p, epi);
-      VBX_LAUNCH_CHECK();
-      return 0;
-    }
-  }
+  // Tried and removed (numbers from the same-run A/Bs): 128x256 tiles with 4 waves of 64x128 -- main loop 30 % faster in a K
+  // sweep (727 -> 935 TF/s), isolated to_qkv / FeedForward-in launches 3-8 % faster, train step 1 % SLOWER (2 instead of 3
+  // workgroups per CU, the ~14 us VALU epilogues overlap less); the same tile with 8 waves of 64x64 -- back-to-back launches
+  // 16 % faster (FeedForward-in 45.4 -> 38.3 us), 128-forward sample 3 % SLOWER (375 -> 387 ms); 160-row tiles with a 3-slot
+  // ring for the wide GEMMs -- sample 1.5 % slower.  GEMM variants have to be judged in situ.
   if constexpr (MA == 0) {
     // one-round 160-row tiles when 128-row tiles would put two on a few CUs (see gemm_kernel_bm160).  VBX_GEMM_BM160=0/1: A/B.
     static const char* b160 = getenv("VBX_GEMM_BM160");
@@ -1160,22 +922,6 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
       }
       p.tiles_m = cdiv(p.M, 160);
       hipLaunchKernelGGL(k160, dim3(p.tiles_m * tiles_n), dim3(256), GEMM_V4_LDS, st, p, epi);
-      VBX_LAUNCH_CHECK();
-      return 0;
-    }
-  }
-  if constexpr (MA == 0 && MB == 0) {
-    // wide forward GEMMs: 160-row tiles, 3-slot ring, 2 workgroups per CU.  VBX_GEMM_BM160W=0/1: A/B.
-    static const char* b160w = getenv("VBX_GEMM_BM160W");
-    if ((b160w ? atoi(b160w) != 0 : false) && !legacy && splits == 1 && p.N >= 2048) {
-      static bool attrw = false;
-      auto k160w = gemm_kernel_bm160<MB, Epi, F16, 3>;
-      if (!attrw) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k160w), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V4_STAGE);
-        attrw = true;
-      }
-      p.tiles_m = cdiv(p.M, 160);
-      hipLaunchKernelGGL(k160w, dim3(p.tiles_m * tiles_n), dim3(256), 3 * V4_STAGE, st, p, epi);
       VBX_LAUNCH_CHECK();
       return 0;
     }

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // u = x/|x| ; y = sqrt(D) u*gamma + beta
 // dgamma[b] += sqrt(D) u*dy ; dbeta[b] += dy ; du = sqrt(D) gamma*dy ; dx = (du - u (u.du)) / |x|
 // grid (chunks, B); each block handles 16 rows of one batch; partials -> part[b][chunk][2][D]
-constexpr int NB_WAVES = 8;  // waves per block of the backward kernel (16-row chunk -> 2 rows per wave)
+// NB_WAVES = waves per block of the backward kernel (16-row chunk -> 2 rows per wave with 8 waves; 4 waves when the
+// [NB_WAVES][3][D] fp32 reduction buffer of 8 waves would exceed the 160 KiB of LDS, i.e. D > 1664)
+template <int NB_WAVES>
 __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            long gb_stride, const u16* __restrict__ dy,
                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out,
@@ -342,16 +344,20 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_bwd: bad row range");
   dim3 grid(cdiv(rows_per_batch, 16), B);
   VBX_REQUIRE(!colpart || dx_in, "vbx_rmsnorm_bwd: column sums need dx_in");
-  const size_t lds = (size_t)NB_WAVES * 3 * D * sizeof(float);
-  if (lds > 48 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
+  const bool eight = (size_t)8 * 3 * D * sizeof(float) <= 160 * 1024;
+  const size_t lds = (size_t)(eight ? 8 : 4) * 3 * D * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
   }
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(64 * NB_WAVES), lds, (hipStream_t)stream, x, gamma,
-                     gb_stride, (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
+  if (eight)
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, x, gamma, gb_stride, (const u16*)dy_bf16, dx_in,
+                       dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, gb_stride, (const u16*)dy_bf16, dx_in,
+                       dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }
