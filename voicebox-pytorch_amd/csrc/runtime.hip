@@ -107,15 +107,35 @@ struct Acts {
   size_t bytes;
 };
 
+// Split-K factor of a weight-gradient GEMM dW[I,J] (reduction over K = B*Np rows).  Cost model in microseconds, fitted to the
+// profiled launches: with W = tiles*s workgroups the busiest CU gets n = ceil(W/256) of them, which (n <= 3) run concurrently and
+// share the CU's L2->LDS stream -- a lone workgroup reaches ~60 % of the rate three reach together, two ~85 %; each k-step of 32
+// costs ~0.27 us per resident workgroup at full rate; the fp32 slabs cost a write + a read of s*I*J*4 bytes at ~4 TB/s.
+// VBX_WGRAD_TARGET=<workgroups> restores the plain "about that many workgroups" rule (A/B).
 int wgrad_splits(long I, long J, long K) {
   const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
-  static const long target = getenv("VBX_WGRAD_TARGET") ? atol(getenv("VBX_WGRAD_TARGET")) : 384;  // 384 measured best (768: +0.35 ms of slab traffic per step)  // workgroups wanted
-  long s = (target + tiles - 1) / tiles;
   const long smax = (K + 511) / 512;
-  if (s > smax) s = smax;
-  if (s > 16) s = 16;
-  if (s < 1) s = 1;
-  return (int)s;
+  static const long target = getenv("VBX_WGRAD_TARGET") ? atol(getenv("VBX_WGRAD_TARGET")) : 0;
+  if (target > 0) {
+    long s = (target + tiles - 1) / tiles;
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return (int)s;
+  }
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 16 && s <= smax; s++) {
+    const long W = tiles * s;
+    const long n = (W + 255) / 256;
+    const double eff = n >= 3 ? 1.0 : (n == 2 ? 0.85 : 0.6);
+    const double ksteps = (double)((K + s - 1) / s) / 32.0;
+    const double gemm = (double)n * ksteps * 0.27 / eff;
+    const double slab = (double)s * (double)I * (double)J * 8.0 / 4.0e6;
+    const double cost = gemm + slab;
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 void carve_acts(const vbx_model* m, Acts& a) {
