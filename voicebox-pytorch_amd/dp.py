@@ -120,9 +120,10 @@ class TrainStep:
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
         self.bucket_bytes = bucket_bytes
 
-    def _dirty(self):
+    def _dirty(self, keep=None):
         for eng in self.vb._engines.values():
-            eng.packed_version = None
+            if eng is not keep:
+                eng.packed_version = None
 
     # -- gradient accumulation with a deferred exchange (VoiceBoxTrainer.train_step, trainer.py:258-272: every micro-batch but
     #    the last runs under accelerator.no_sync, the loss is divided by grad_accum_every)
@@ -198,11 +199,12 @@ class TrainStep:
         _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
         # Adam + refresh of the training engine's fp16/bf16 operand copies in one pass (other engines repack lazily)
-        self._dirty()
         if os.environ.get("VBX_FUSED_ADAM", "1") != "0":
             eng.adam_step_packed(self.gflat, self.m, self.v, float(lr if lr is not None else self.lr), self.betas[0], self.betas[1],
                                  self.eps, self.steps, self.coef)
+            self._dirty(keep=eng)
         else:  # A/B: plain Adam, the next forward repacks every weight
+            self._dirty()
             _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
                       float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
 
