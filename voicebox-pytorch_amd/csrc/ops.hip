@@ -840,9 +840,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, long n, float* __restrict__ scratch) {
   __shared__ float red[4];
-  float s = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
-  s = wave_sum(s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long n4 = (((size_t)x & 15) == 0) ? n / 4 : 0;  // 16-byte loads when the buffer allows (the flat gradient buffer does)
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s0 += x[i] * x[i];
+  float s = wave_sum((s0 + s1) + (s2 + s3));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
