@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: needed by RCCL on this driver for multi-process runs
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

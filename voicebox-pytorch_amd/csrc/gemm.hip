@@ -898,7 +898,8 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     // one-round 160-row tiles when 128-row tiles would put two on a few CUs (see gemm_kernel_bm160).  VBX_GEMM_BM160=0/1: A/B.
     static const char* b160 = getenv("VBX_GEMM_BM160");
     const long t128 = (long)p.tiles_m * tiles_n, t160 = (long)cdiv(p.M, 160) * tiles_n;
-    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && t160 <= 256;
+    static const bool all160 = getenv("VBX_GEMM_BM160ALL") != nullptr;  // experiment: also the multi-round GEMMs
+    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && (t160 <= 256 || all160);
     // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
     static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
     if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
