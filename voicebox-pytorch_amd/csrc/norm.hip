@@ -15,55 +15,47 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
                                                            const float* __restrict__ beta, long gb_stride,
                                                            u16* __restrict__ y, u16* __restrict__ y16, int B, int Np, int n0,
                                                            int rpb, int D, float* __restrict__ y32) {
+  // one wave per row; the row, its gamma and its beta are all requested before the reduction so that a single memory round
+  // trip is exposed per row (FWD_ROWS is kept for the A/B record: two rows per wave in flight measured 9 -> 14 us)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
   const long rows = (long)B * rpb;
   for (long r0 = ((long)blockIdx.x * 4 + wave) * FWD_ROWS; r0 < rows; r0 += (long)gridDim.x * 4 * FWD_ROWS) {
-    float4 v[FWD_ROWS][MAXC];
-    float ss[FWD_ROWS];
-    int bb[FWD_ROWS];
-#pragma unroll
-    for (int k = 0; k < FWD_ROWS; k++) {
-      const long ri = min(r0 + k, rows - 1);
-      const int b = (int)(ri / rpb), j = (int)(ri - (long)b * rpb);
-      bb[k] = b;
-      const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
-      ss[k] = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXC; i++) {
-        const int c = lane + 64 * i;
-        if (c < D4) v[k][i] = xr[c];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < FWD_ROWS; k++) {
-#pragma unroll
-      for (int i = 0; i < MAXC; i++) {
-        const int c = lane + 64 * i;
-        if (c < D4) ss[k] += v[k][i].x * v[k][i].x + v[k][i].y * v[k][i].y + v[k][i].z * v[k][i].z + v[k][i].w * v[k][i].w;
-      }
-      ss[k] = wave_sum(ss[k]);
-    }
 #pragma unroll
     for (int k = 0; k < FWD_ROWS; k++) {
       const long ri = r0 + k;
       if (ri >= rows) break;
-      const float r = sqrtD / fmaxf(sqrtf(ss[k]), 1e-12f);
-      const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)bb[k] * gb_stride);
-      const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)bb[k] * gb_stride) : nullptr;
+      const int b = (int)(ri / rpb), j = (int)(ri - (long)b * rpb);
+      const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
+      const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
+      const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)b * gb_stride) : nullptr;
+      float4 v[MAXC], g[MAXC], bt[MAXC];
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+          v[i] = xr[c];
+          g[i] = g4[c];
+          bt[i] = b4 ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const int c = lane + 64 * i;
+        if (c < D4) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      }
+      ss = wave_sum(ss);
+      const float r = sqrtD / fmaxf(sqrtf(ss), 1e-12f);
       uint2* yr = y ? reinterpret_cast<uint2*>(y + ri * D) : nullptr;
       uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + ri * D) : nullptr;
 #pragma unroll
       for (int i = 0; i < MAXC; i++) {
         const int c = lane + 64 * i;
         if (c < D4) {
-          const float4 g = g4[c];
-          float4 o = make_float4(v[k][i].x * r * g.x, v[k][i].y * r * g.y, v[k][i].z * r * g.z, v[k][i].w * r * g.w);
-          if (b4) {
-            const float4 bv = b4[c];
-            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-          }
+          const float4 o = make_float4(v[i].x * r * g[i].x + bt[i].x, v[i].y * r * g[i].y + bt[i].y, v[i].z * r * g[i].z + bt[i].z,
+                                       v[i].w * r * g[i].w + bt[i].w);
           if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
           if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
           if (y32) reinterpret_cast<float4*>(y32 + ri * D)[c] = o;
