@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvbx_hip.so")
+LIB_PATH = os.environ.get("VBX_LIB_PATH") or os.path.join(_HERE, "lib", "libvbx_hip.so")  # override: A/B builds of the library
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
