@@ -126,6 +126,14 @@ int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* k
 /* backward of MultiheadRMSNorm + rotary (voicebox_pytorch.py:286-287,199): consumes dq/dk fp32
  * [B,H,Np,64] and the saved q16/k16 + rnorm, writes d(raw q|k) bf16 into dqkv[(b*Np+n)*ld + which*H*64
  * + h*64 + d] and partial gamma grads gpart[2][vbx_qknorm_rope_bwd_gpart_rows(B)][H][64]. */
+/* vbx_attn_bwd with the backward of rotary + MultiheadRMSNorm (vbx_qknorm_rope_bwd) folded into the epilogues of its two kernels:
+ * no fp32 dq / dk round trip; writes d(qkv) bf16 [B*Np, ld] (q | k | v blocks of H*64 columns) directly.  gpart: partial gamma
+ * gradients [2][B * vbx_attn_bwd_fused_tiles(Np)][H][64] (q then k), to be summed over the rows (qk_scale > 0 only). */
+int vbx_attn_bwd_fused_tiles(int Np);
+int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
+                       const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, const float* q_rnorm,
+                       const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos, const float* rot_sin,
+                       float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* stream);
 int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
                         const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
                         const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np,

@@ -383,6 +383,59 @@ def test_qknorm_rope_bwd(L, qknorm):
         assert rel_err(gpart.sum(1), gam.grad) < 2e-3
 
 
+@pytest.mark.parametrize("Bsz,H,Np,qknorm,masked", [(2, 2, 1040, True, False), (2, 2, 77, True, True), (1, 2, 200, False, False)])
+def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked):
+    """vbx_attn_bwd_fused (rotary + qk-norm backward inside the dq / dkdv epilogues) against vbx_attn_bwd followed by
+    vbx_qknorm_rope_bwd on the same inputs: same d(qkv) up to the bf16 rounding of the output, same gamma gradients."""
+    scale = 10.0 if qknorm else 0.125
+    g = torch.Generator().manual_seed(Np)
+    pre = torch.randn(2, Bsz, H, Np, 64, generator=g)
+    gam = 1 + 0.2 * torch.randn(2, H, 64, generator=g)
+    fr, rc, rs = rot_tables(Np, 16 if Np > 16 else 0)
+    hats = []
+    for w in range(2):
+        y = restate.l2norm_scale(pre[w], 64) * gam[w][:, None, :] if qknorm else pre[w]
+        hats.append(restate.apply_rotary(fr, y))
+    rn = (1 / pre.norm(dim=-1)).float()
+    q16, k16 = hats[0].half().to(dev), hats[1].half().to(dev)
+    v = torch.randn(Bsz, H, Np, 64, generator=g).half().to(dev)
+    mask = None
+    if masked:
+        mask = torch.ones(Bsz, Np, dtype=torch.bool)
+        mask[0, Np - 9:] = False
+        mask = mask.to(dev)
+    out16 = torch.empty(Bsz, Np, H * 64, dtype=torch.float16, device=dev)
+    lse = torch.empty(Bsz, H, Np, device=dev)
+    L.call("vbx_attn_fwd", q16, k16, v, mask, out16, None, lse, Bsz, H, Np, scale, st())
+    dout = bf(torch.randn(Bsz, Np, H * 64, generator=g) * 1e-3).to(dev)
+    qb, kb, vb = bf(q16.float()), bf(k16.float()), bf(v.float())
+    I = H * 64
+    # two-pass
+    delta = torch.empty(Bsz, H, Np, device=dev)
+    dq, dk = torch.zeros(Bsz, H, Np, 64, device=dev), torch.zeros(Bsz, H, Np, 64, device=dev)
+    d1 = torch.zeros(Bsz * Np, 3 * I, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_attn_bwd", q16, k16, qb, kb, vb, mask, out16, 1, dout, lse, delta, dq, dk, d1.view(-1)[2 * I:].data_ptr(), 3 * I,
+           Bsz, H, Np, scale, st())
+    rows1 = L.lib().vbx_qknorm_rope_bwd_gpart_rows(Bsz)
+    gp1 = torch.zeros(2, rows1, H, 64, device=dev)
+    gq, gk = gam[0].float().to(dev), gam[1].float().to(dev)
+    L.call("vbx_qknorm_rope_bwd", dq, dk, q16, k16, rn[0].to(dev), rn[1].to(dev), gq, gk, rc.to(dev), rs.to(dev),
+           8.0 if qknorm else 0.0, d1, 3 * I, gp1, Bsz, H, Np, st())
+    # fused
+    d2 = torch.zeros(Bsz * Np, 3 * I, dtype=torch.bfloat16, device=dev)
+    rows2 = Bsz * L.lib().vbx_attn_bwd_fused_tiles(Np)
+    gp2 = torch.zeros(2, rows2, H, 64, device=dev)
+    L.call("vbx_attn_bwd_fused", q16, k16, qb, kb, vb, mask, out16, 1, dout, lse, delta, rn[0].to(dev), rn[1].to(dev), gq, gk,
+           rc.to(dev), rs.to(dev), 8.0 if qknorm else 0.0, d2, 3 * I, gp2, Bsz, H, Np, scale, st())
+    torch.cuda.synchronize()
+    assert torch.equal(d1[:, 2 * I:], d2[:, 2 * I:])  # dv: same code path
+    for blk in range(2):
+        a, b = d1[:, blk * I:(blk + 1) * I].float(), d2[:, blk * I:(blk + 1) * I].float()
+        assert rel_err(b, a) < 4e-3, (blk, rel_err(b, a))  # identical fp32 math, one bf16 rounding each
+    if qknorm:
+        assert rel_err(gp2.sum(1), gp1.sum(1)) < 1e-4
+
+
 # ----------------------------------------------------------------------------- small ops
 @pytest.mark.parametrize("masked", [False, True])
 def test_convpos_fwd_bwd(L, masked):

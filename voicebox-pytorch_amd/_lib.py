@@ -35,6 +35,8 @@ _PROTOS = {
     "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_attn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
     "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P],
+    "vbx_attn_bwd_fused": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P],
+    "vbx_attn_bwd_fused_tiles": [I],
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
     "vbx_pack_embed_input": [P, P, P, P, P, I, I, I, P],

@@ -137,6 +137,129 @@ VBX_DEV void store_rows_f32(char* wst, const f32x16 (&acc)[2], float scale, floa
   }
 }
 
+// Fused epilogue of the backward kernels (replaces store_rows_f32 + the separate vbx_qknorm_rope_bwd pass, i.e. a 68 MB fp32
+// write and re-read of dq|dk per layer): the wave's dX^T block is staged row-major in LDS as before, then every row goes through
+// the backward of rotary + MultiheadRMSNorm (voicebox_pytorch.py:193-199, 280-287, 320-328) and leaves as bf16 straight into the
+// d(qkv) operand of the projection's dgrad / wgrad.  8 lanes per row, a lane owns 8 dims d0..d0+7 and reads its rotary partner
+// chunk (d0 ^ 32) from LDS / global itself -- no cross-lane traffic except the 64-wide dot (quad-style xor 1,2,4).
+// The gamma gradient is reduced over the workgroup's rows and written as one partial record per (which, batch, tile, head).
+struct QKBwd {
+  const u16* xh;        // normalised + rotated q^ or k^ (fp16) [B,H,Np,64]
+  const float* rn;      // 1/|x| per row [B,H,Np] (qk-norm only)
+  const float* gam;     // gamma [H,64] (qk-norm only)
+  const float* rc;      // rotary cos / sin tables [Np,32]
+  const float* rs;
+  float qk_scale;       // 8 with qk-norm, 0 without
+  u16* dqkv;            // bf16 [B*Np, ld]
+  int ld, col0;         // column offset of this tensor's block inside a dqkv row (0 for q, H*64 for k)
+  float* gpart;         // [B][tiles][H][64] partial gamma gradients of this tensor (qk-norm only)
+};
+VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratch */, const f32x16 (&acc)[2], float scale,
+                               const QKBwd& f, bool active, int b, int h, int H, int tile, int ntiles, int row0, int Np, int lane,
+                               int wave) {
+  const long bh = (long)b * H + h;
+  float gacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) gacc[i] = 0.f;
+  if (active) {
+    const int rl = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int c = (db * 32 + 8 * g4 + 4 * hi) >> 2;
+        *reinterpret_cast<float4*>(wst + rl * 256 + ((c ^ (rl & 15)) << 4)) =
+            make_float4(acc[db][4 * g4] * scale, acc[db][4 * g4 + 1] * scale, acc[db][4 * g4 + 2] * scale, acc[db][4 * g4 + 3] * scale);
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int sub = lane & 7, d0 = sub * 8, dp0 = d0 ^ 32;
+    const float sgn = d0 < 32 ? 1.f : -1.f;  // transpose of rotate_half
+    float gm[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) gm[i] = (f.qk_scale > 0.f) ? f.gam[h * 64 + d0 + i] : 1.f;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3);
+      const int n = row0 + row;
+      const bool valid = n < Np;
+      const int nc = valid ? n : (Np - 1);
+      float g[8], gp[8], qh[8], qp[8];
+      {
+        const int c0 = d0 >> 2, c1 = dp0 >> 2;
+        const float4 a0 = *reinterpret_cast<const float4*>(wst + row * 256 + ((c0 ^ (row & 15)) << 4));
+        const float4 a1 = *reinterpret_cast<const float4*>(wst + row * 256 + (((c0 + 1) ^ (row & 15)) << 4));
+        const float4 p0 = *reinterpret_cast<const float4*>(wst + row * 256 + ((c1 ^ (row & 15)) << 4));
+        const float4 p1 = *reinterpret_cast<const float4*>(wst + row * 256 + (((c1 + 1) ^ (row & 15)) << 4));
+        g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
+        gp[0] = p0.x; gp[1] = p0.y; gp[2] = p0.z; gp[3] = p0.w; gp[4] = p1.x; gp[5] = p1.y; gp[6] = p1.z; gp[7] = p1.w;
+        const long ro = (bh * Np + nc) * 64;
+        const uint4 hq = *reinterpret_cast<const uint4*>(f.xh + ro + d0);
+        const uint4 hp = *reinterpret_cast<const uint4*>(f.xh + ro + dp0);
+        const unsigned w[4] = {hq.x, hq.y, hq.z, hq.w}, wp[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          qh[2 * i] = f16_to_f32((u16)(w[i] & 0xffff));
+          qh[2 * i + 1] = f16_to_f32((u16)(w[i] >> 16));
+          qp[2 * i] = f16_to_f32((u16)(wp[i] & 0xffff));
+          qp[2 * i + 1] = f16_to_f32((u16)(wp[i] >> 16));
+        }
+      }
+      const float* cp = f.rc + (long)nc * 32 + (d0 & 31);
+      const float* sp = f.rs + (long)nc * 32 + (d0 & 31);
+      float dy[8], yv[8], out[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        dy[i] = g[i] * cp[i] + sgn * gp[i] * sp[i];
+        yv[i] = qh[i] * cp[i] + sgn * qp[i] * sp[i];
+      }
+      if (f.qk_scale > 0.f) {
+        const float rinv = f.rn[bh * Np + nc];
+        float u[8], du[8], dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float sg = f.qk_scale * gm[i];
+          u[i] = (fabsf(sg) > 1e-20f) ? yv[i] / sg : 0.f;
+          if (valid) gacc[i] += dy[i] * u[i] * f.qk_scale;
+          du[i] = dy[i] * sg;
+          dot += u[i] * du[i];
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = (du[i] - u[i] * dot) * rinv;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = dy[i];
+      }
+      if (valid) {
+        u16* o = f.dqkv + ((long)b * Np + n) * f.ld + f.col0 + h * 64 + d0;
+        *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(out[0], out[1]), pack_bf16x2(out[2], out[3]),
+                                                  pack_bf16x2(out[4], out[5]), pack_bf16x2(out[6], out[7]));
+      }
+    }
+  }
+  if (f.qk_scale > 0.f && f.gpart) {  // gamma gradient: 8 row slots per wave -> lanes 0..7, then the four waves
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float v = gacc[i];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      gacc[i] = v;
+    }
+    __syncthreads();  // every wave is past its LDS staging reads
+    if (lane < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) red[wave * 64 + lane * 8 + i] = gacc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64)
+      f.gpart[(((long)b * ntiles + tile) * H + h) * 64 + threadIdx.x] =
+          red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
+  }
+}
+
 // Workgroup -> (128-row tile, head, batch).  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with a private
 // L2; the tiles of one (batch, head) all read the same K/V (or Q/dO) panels, so they are given ids that land on ONE XCD
 // and run back to back there.  With the plain (tile, h, b) grid the 9 tiles of a head sat on 9 different XCDs and every
@@ -829,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
                                                              const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              float* __restrict__ dq, int H, int Np, float scale2,
-                                                             float scale, int BH, int xmap) {
+                                                             float scale, int BH, int xmap, QKBwd fq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const AttnCoord co = attn_coord(H, Np, BH, xmap);
@@ -925,6 +1048,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
   }
 
   // the tile ring is dead after the loop's last barrier: each wave stages its 32x64 fp32 block in its own 8 KiB
+  if (fq.dqkv) {  // fused rotary + qk-norm backward -> bf16 d(qkv); the red scratch sits behind the four 8 KiB wave blocks
+    store_rows_qknorm(smem + wave * 8192, reinterpret_cast<float*>(smem + 4 * 8192), acc, scale, fq, active, b, h, H, co.tile,
+                      (Np + 127) >> 7, q0, Np, lane, wave);
+    return;
+  }
   if (active) store_rows_f32(smem + wave * 8192, acc, scale, dq + bh * Np * 64, q0, Np, lane);
 }
 
@@ -937,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
                                                                const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dk, u16* __restrict__ dv, int dv_ld, int H,
-                                                               int Np, float scale2, float scale, int BH, int xmap) {
+                                                               int Np, float scale2, float scale, int BH, int xmap, QKBwd fk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const AttnCoord co = attn_coord(H, Np, BH, xmap);
@@ -1050,9 +1178,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
     __syncthreads();
   }
 
+  if (fk.dqkv)  // fused rotary + qk-norm backward of dk (all waves: it ends with workgroup barriers)
+    store_rows_qknorm(smem + wave * 12288, reinterpret_cast<float*>(smem + 4 * 12288), adk, scale, fk, active, b, h, H, co.tile,
+                      (Np + 127) >> 7, key0, Np, lane, wave);
   if (active) {
     char* wst = smem + wave * 12288;  // 8 KiB fp32 dk block | 4 KiB bf16 dv block (ring is dead after the last barrier)
-    store_rows_f32(wst, adk, scale, dk + bh * Np * 64, key0, Np, lane);
+    if (!fk.dqkv) store_rows_f32(wst, adk, scale, dk + bh * Np * 64, key0, Np, lane);
     char* vst = wst + 8192;
     const int kl = lane & 31;
 #pragma unroll
@@ -1120,12 +1251,9 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   return 0;
 }
 
-extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
-                            const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
-                            float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
-                            void* stream) {
-  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
-  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
+static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
+                         const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, float* dq, float* dk,
+                         void* dv, int dv_ld, int B, int H, int Np, float scale, const QKBwd& fq, const QKBwd& fk, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
@@ -1145,11 +1273,40 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
-                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap);
+                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap, fq);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
                      (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
-                     scale * LOG2E, scale, BH, xmap);
+                     scale * LOG2E, scale, BH, xmap, fk);
   VBX_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                            const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
+                            float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
+                            void* stream) {
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
+  const QKBwd none{};
+  return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
+                       stream);
+}
+
+extern "C" int vbx_attn_bwd_fused_tiles(int Np) { return cdiv(Np, 128); }
+
+extern "C" int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                                  const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
+                                  float* delta, const float* q_rnorm, const float* k_rnorm, const float* q_gamma,
+                                  const float* k_gamma, const float* rot_cos, const float* rot_sin, float qk_scale, void* dqkv,
+                                  int ld, float* gpart, int B, int H, int Np, float scale, void* stream) {
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dqkv && rot_cos && rot_sin, "vbx_attn_bwd_fused: null pointer");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && ld % 8 == 0 && ld >= 3 * H * 64, "vbx_attn_bwd_fused: bad dims");
+  VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma && gpart), "vbx_attn_bwd_fused: qk-norm needs norms, gammas, gpart");
+  const int I = H * 64, tiles = cdiv(Np, 128);
+  QKBwd fq{(const u16*)q16, q_rnorm, q_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, 0, gpart};
+  QKBwd fk{(const u16*)k16, k_rnorm, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, I,
+           gpart ? gpart + (size_t)B * tiles * H * 64 : nullptr};
+  return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, nullptr, nullptr, (u16*)dqkv + 2 * I, ld, B, H, Np,
+                       scale, fq, fk, stream);
 }

@@ -222,7 +222,10 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
     a.cs_scratch = c.take<float>(cs);
-    a.gpart = c.take<float>((size_t)2 * vbx_qknorm_rope_bwd_gpart_rows(d.B) * d.H * 64);
+    {
+      const int r1 = vbx_qknorm_rope_bwd_gpart_rows(d.B), r2 = d.B * vbx_attn_bwd_fused_tiles(d.Np);
+      a.gpart = c.take<float>((size_t)2 * (r1 > r2 ? r1 : r2) * d.H * 64);
+    }
     a.tmp2d = c.take<float>(2 * d.D);
     a.ada_scratch = c.take<float>((size_t)vbx_adaln_proj_bwd_scratch_floats(d.B, d.Th, 4 * d.D));
     a.dpre = c.take<float>((size_t)d.M0 * d.D);
@@ -591,15 +594,27 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
   CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
+  static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
+  if (fused_qk) {
+    CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
+                          m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin,
+                          m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, stream));
+    if (m->qk_norm) {
+      const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
+      CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+    }
+  } else {
   CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
-                  a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, stream));
-  CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
-                         m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
-                         3 * d.I, a.gpart, d.B, d.H, d.Np, stream));
-  if (m->qk_norm) {
-    const int rows = vbx_qknorm_rope_bwd_gpart_rows(d.B);
-    CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
-    CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+                    a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, stream));
+    CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
+                           m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
+                           3 * d.I, a.gpart, d.B, d.H, d.Np, stream));
+    if (m->qk_norm) {
+      const int rows = vbx_qknorm_rope_bwd_gpart_rows(d.B);
+      CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+    }
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
