@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--intervals", type=int, default=64, help="sample mode: midpoint intervals (NFE = 2x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,7 +171,7 @@ def main():
     if args.mode == "train":
         from voicebox_pytorch_amd.dp import TrainStep
 
-        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5)
+        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
         step = lambda: ts.step(x)
         units_per_step = args.batch * args.frames
         flops_per_step_per_gpu = 3.0 * fwd_flops_per_frame(args.dim, args.depth, args.heads, args.frames, 16) * units_per_step

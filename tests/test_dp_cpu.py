@@ -38,7 +38,7 @@ def _oracle_flat_grads(fp, cfg, state, x1, x0, times, frac, rand):
     return g
 
 
-def _worker(rank, world, port, bucket_bytes, out):
+def _worker(rank, world, port, bucket_bytes, out, comm_dtype=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, bucket_bytes, out):
     times, frac, rand = torch.rand(B, generator=g), 0.7 + 0.3 * torch.rand(B, generator=g), torch.rand(B, generator=g)
     sl = slice(rank * B // world, (rank + 1) * B // world)
     gflat = _oracle_flat_grads(fp, cfg, state, x1[sl], x0[sl], times[sl], frac[sl], rand[sl])
-    red = GradBucketReducer(gflat, fp.stage_ranges, bucket_bytes=bucket_bytes)
+    red = GradBucketReducer(gflat, fp.stage_ranges, bucket_bytes=bucket_bytes, comm_dtype=comm_dtype)
     for i, rng in enumerate(fp.stage_ranges):  # backward order: head, layer L-1 .. 0, embed
         red.stage_done(i, rng)
     red.finish()
@@ -88,6 +88,23 @@ def test_bucketed_allreduce_equals_full_batch_gradient(bucket_bytes):
     assert err < 1e-5 * max(scale, 1.0), res
     assert lo == 0 and hi == numel  # buckets cover the whole flat buffer
     assert nbuckets == (4 if bucket_bytes == 1 else 1)  # depth 2: head, 2 layers, embed -> 4 stages
+
+
+def test_bf16_gradient_exchange_option():
+    """comm_dtype=torch.bfloat16 (optional wire compression): the reduced gradient equals the exact one to bf16 precision."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 1 << 30, out, torch.bfloat16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    err, scale, nbuckets, lo, hi, numel = res
+    assert err < 2 ** -7 * max(scale, 1e-6), res  # two bf16 roundings of values <= scale
+    assert lo == 0 and hi == numel
 
 
 def test_warmup_cosine_schedule_matches_trainer_rule():

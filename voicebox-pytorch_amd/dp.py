@@ -20,8 +20,11 @@ class GradBucketReducer:
     Device-agnostic (gloo on CPU in tests, RCCL on GPUs).  xGMI is point-to-point (ring all-reduce is per-link
     bound) so buckets are large: whole backward stages are merged until `bucket_bytes` is reached."""
 
-    def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None):
+    def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None, comm_dtype=None):
         self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
+        # optional gradient compression on the wire (DDP's bf16_compress_hook): halves the 4 B/param exchange; off by default
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self.staged = []
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.comm_stream = comm_stream
         self.pending_lo = None
@@ -41,9 +44,18 @@ class GradBucketReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if self.comm_dtype is not None:
+                    view = self._stage(lo, hi)
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if self.comm_dtype is not None:
+                view = self._stage(lo, hi)
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _stage(self, lo, hi):
+        buf = self.g[lo:hi].to(self.comm_dtype)
+        self.staged.append((lo, hi, buf))
+        return buf
 
     def stage_done(self, i, rng=None):
         lo, hi = rng if rng is not None else self.ranges[i]
@@ -63,6 +75,11 @@ class GradBucketReducer:
         for w in self.works:
             w.wait()  # makes the current stream wait for the collective
         self.works = []
+        for lo, hi, buf in self.staged:  # decompress the reduced buckets back into the fp32 gradient buffer
+            if self.comm_stream is not None:
+                buf.record_stream(torch.cuda.current_stream())
+            self.g[lo:hi].copy_(buf)
+        self.staged = []
 
 
 class WarmupCosineLR:
@@ -97,10 +114,11 @@ class WarmupCosineLR:
 
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
-                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None):
+                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None):
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         self.lr_schedule = lr_schedule  # e.g. WarmupCosineLR; an explicit `lr=` passed to step() wins
+        self.grad_comm_dtype = grad_comm_dtype  # None / torch.float32: exact fp32 exchange (the reference's DDP); torch.bfloat16 halves it
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -213,7 +231,7 @@ class TrainStep:
         Returns the (un-synchronised) local loss tensor."""
         # --- backward with overlapped gradient exchange
         red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
-                                comm_stream=self.comm_stream)
+                                comm_stream=self.comm_stream, comm_dtype=self.grad_comm_dtype)
         loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.world > 1 else None)
         red.finish()
         self._clip_adam(self._last_eng, lr)
