@@ -102,9 +102,10 @@ int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long 
 /* same, fp32 output rows [B*rows_per_batch, D] (final norm of a standalone Transformer.forward, :479) */
 int vbx_rmsnorm_fwd_f32(const float* x, const float* gamma, const float* beta, long gb_stride, float* y_f32, int B, int Np,
                         int n0, int rows_per_batch, int D, void* stream);
-/* backward: dx_out = dx_in (or 0 if NULL) + d/dx ; partial dgamma/dbeta sums per 16-row chunk:
- * part[b][chunk][2][D] (chunk count = ceil(rows_per_batch/16)).  dy is dense bf16 [B*rows, D].
+/* backward: dx_out = dx_in (or 0 if NULL) + d/dx ; partial dgamma/dbeta sums per row chunk:
+ * part[b][chunk][2][D] (chunk count = vbx_rmsnorm_bwd_chunks(rows_per_batch)).  dy is dense bf16 [B*rows, D].
  * dx tensors have the same (Np, n0) row addressing as x.  dxb: optional bf16 copy of dx_out (same addressing). */
+int vbx_rmsnorm_bwd_chunks(int rows_per_batch);
 int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
                     float* dx_out, void* dxb_bf16, float* part,
                     float* colpart /* optional [B][chunks][D]: per-chunk column sums of dx_in (a fused bias gradient) */,

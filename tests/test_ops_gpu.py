@@ -273,7 +273,7 @@ def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
     dx_in = torch.randn(Bsz, Np, D, generator=g)
     dx_out = torch.zeros(Bsz, Np, D, device=dev)
     dxb = torch.zeros(Bsz, Np, D, dtype=torch.bfloat16, device=dev)
-    chunks = (rpb + 15) // 16
+    chunks = L.lib().vbx_rmsnorm_bwd_chunks(rpb)
     part = torch.zeros(Bsz, chunks, 2, D, device=dev)
     cpart = torch.zeros(Bsz, chunks, D, device=dev)
     L.call("vbx_rmsnorm_bwd", xd, gd, stride, dy.to(dev), dx_in.to(dev), dx_out, dxb, part, cpart, Bsz, Np, n0, rpb, D, st())

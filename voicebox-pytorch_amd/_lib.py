@@ -32,6 +32,7 @@ _PROTOS = {
     "vbx_gemm": [C.POINTER(GemmDesc), P],
     "vbx_splitk_reduce": [P, I, I, I, P, I, I, I, I, I, I, P],
     "vbx_rmsnorm_fwd": [P, P, P, L, P, P, I, I, I, I, I, P],
+    "vbx_rmsnorm_bwd_chunks": [I],
     "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_attn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
     "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P],

@@ -68,10 +68,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // ---------------------------------------------------------------- backward
 // u = x/|x| ; y = sqrt(D) u*gamma + beta
 // dgamma[b] += sqrt(D) u*dy ; dbeta[b] += dy ; du = sqrt(D) gamma*dy ; dx = (du - u (u.du)) / |x|
-// grid (chunks, B); each block handles 16 rows of one batch; partials -> part[b][chunk][2][D]
+// grid (chunks, B); each block handles RB_ROWS rows of one batch; partials -> part[b][chunk][2][D]
+// RB_ROWS rows per block: 16 (default) or 8 (VBX_RMS_BWD_ROWS=8; one row per wave, twice the blocks -- measured in the same
+// run: train step 12.75 -> 12.99 ms, the doubled partial records cost more than the extra parallelism buys)
 // NB_WAVES = waves per block of the backward kernel (16-row chunk -> 2 rows per wave with 8 waves; 4 waves when the
 // [NB_WAVES][3][D] fp32 reduction buffer of 8 waves would exceed the 160 KiB of LDS, i.e. D > 1664)
-template <int NB_WAVES>
+template <int NB_WAVES, int RB_ROWS>
 __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            long gb_stride, const u16* __restrict__ dy,
                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out,
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
   float4 ag[MAXC], ab[MAXC], ac[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0); }
-  for (int k = 0; k < 16 / NB_WAVES; k++) {
-    const int j = chunk * 16 + wave + NB_WAVES * k;
+  for (int k = 0; k < RB_ROWS / NB_WAVES; k++) {
+    const int j = chunk * RB_ROWS + wave + NB_WAVES * k;
     if (j >= rpb) break;
     const long xrow = ((long)b * Np + n0 + j) * D;
     const long drow = ((long)b * rpb + j) * D;
@@ -328,28 +330,38 @@ extern "C" int vbx_rmsnorm_fwd_f32(const float* x, const float* gamma, const flo
   return rmsnorm_fwd_launch(x, gamma, beta, gb_stride, nullptr, nullptr, y_f32, B, Np, n0, rows_per_batch, D, stream);
 }
 
+static int rb_rows() {
+  static const int r = (getenv("VBX_RMS_BWD_ROWS") && atoi(getenv("VBX_RMS_BWD_ROWS")) == 8) ? 8 : 16;
+  return r;
+}
+extern "C" int vbx_rmsnorm_bwd_chunks(int rows_per_batch) { return cdiv(rows_per_batch, rb_rows()); }
+
 extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const void* dy_bf16, const float* dx_in,
                                float* dx_out, void* dxb_bf16, float* part, float* colpart, int B, int Np, int n0,
                                int rows_per_batch, int D, void* stream) {
   VBX_REQUIRE(x && gamma && dy_bf16 && dx_out && part, "vbx_rmsnorm_bwd: null pointer");
   VBX_REQUIRE(D % 4 == 0 && D <= 2048 && D > 0, "vbx_rmsnorm_bwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   VBX_REQUIRE(B > 0 && rows_per_batch > 0 && n0 >= 0 && n0 + rows_per_batch <= Np, "vbx_rmsnorm_bwd: bad row range");
-  dim3 grid(cdiv(rows_per_batch, 16), B);
+  dim3 grid(cdiv(rows_per_batch, rb_rows()), B);
   VBX_REQUIRE(!colpart || dx_in, "vbx_rmsnorm_bwd: column sums need dx_in");
   const bool eight = (size_t)8 * 3 * D * sizeof(float) <= 160 * 1024;
   const size_t lds = (size_t)(eight ? 8 : 4) * 3 * D * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  if (eight)
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, x, gamma, gb_stride, (const u16*)dy_bf16, dx_in,
-                       dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
-  else
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, x, gamma, gb_stride, (const u16*)dy_bf16, dx_in,
-                       dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);
+#define VBX_RB_LAUNCH(W, R)                                                                                                    \
+  do {                                                                                                                         \
+    static bool attr_ = false;                                                                                                 \
+    if (!attr_) {                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                                                   \
+      attr_ = true;                                                                                                            \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<W, R>), grid, dim3(64 * W), lds, (hipStream_t)stream, x, gamma, gb_stride,            \
+                       (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);          \
+  } while (0)
+  if (eight && rb_rows() == 8) VBX_RB_LAUNCH(8, 8);
+  else if (eight) VBX_RB_LAUNCH(8, 16);
+  else if (rb_rows() == 8) VBX_RB_LAUNCH(4, 8);
+  else VBX_RB_LAUNCH(4, 16);
+#undef VBX_RB_LAUNCH
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -216,8 +216,8 @@ void carve_acts(const vbx_model* m, Acts& a) {
     if (m->gateloop) upd(3 * d.D, d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(sf);
-    a.npart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * 2 * d.D);
-    a.cpart = c.take<float>((size_t)d.B * ((d.Np + 15) / 16) * d.D);
+    a.npart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // >= the LayerNorm backward's 16-row records
+    a.cpart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D);
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
@@ -546,7 +546,7 @@ static int backward_head_impl(const vbx_model* m, const vbx_io* io, const float*
   }
   CK(vbx_rmsnorm_bwd(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], 0, a.dhn, nullptr, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, d.R, d.N, d.D,
                      stream));
-  CK(vbx_reduce_norm_partials(a.npart, a.tmp2d, 0, d.B, (d.N + 15) / 16, d.D, 1, stream));
+  CK(vbx_reduce_norm_partials(a.npart, a.tmp2d, 0, d.B, vbx_rmsnorm_bwd_chunks(d.N), d.D, 1, stream));
   CK(vbx_sum_rows_f32(a.tmp2d, 1, d.D, Gd + G[VBX_P_FNG], d.D, 0, stream));
   return 0;
 }
@@ -566,7 +566,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const ALayer& y = a.layer[l];
   const float* ada_l = a.ada + (size_t)l * d.B * 4 * d.D;
   float* dada_l = a.dada + (size_t)l * d.B * 4 * d.D;
-  const int chunks = (d.Np + 15) / 16;
+  const int chunks = vbx_rmsnorm_bwd_chunks(d.Np), ln_chunks = (d.Np + 15) / 16;
   const int M = (int)d.M;
   const int S = m->gateloop ? 3 : 2;
   const float* x_in = a.xs[S * l + S - 2];   // input of the attention block
@@ -630,7 +630,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   if (m->gateloop) {
     // ---- GateLoop: a.dx is the gradient of x_gl = LayerNorm(s) + x0; the residual branch stays in a.dx
     CK(vbx_layernorm_bwd(y.gls, P + o[VBX_L_GLLNW], a.dx, a.gl_ds, a.npart, d.B, d.Np, d.D, 1e-5f, stream));
-    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));  // [B][dw|db]
+    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, ln_chunks, d.D, 0, stream));  // [B][dw|db]
     CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_GLLNW], 2 * d.D, 0, stream));
     CK(vbx_gateloop_scan_bwd(y.glp, y.glh, a.gl_ds, a.gl_dp, d.B, d.Np, d.D, stream));
     CK(gemm_nn_bf16(a.gl_dp, 3 * d.D, w.layer[l].glw, d.D, M, d.D, 3 * d.D, a.dhn, d.D, st));
