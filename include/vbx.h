@@ -246,6 +246,25 @@ int vbx_layernorm_fwd(const float* s, const float* w, const float* bias, const f
 int vbx_layernorm_bwd(const float* s, const float* w, const float* dy, float* ds, float* part, int B, int Np, int D, float eps,
                       void* stream);
 
+/* Several small column reductions in one launch: for job i, out[b][map(c)] = sum over r < rows of
+ * src[b*src_bstride + r*row_stride + c], c < cols, b < batches; map = identity or the GEGLU row un-interleave (rowmap = 1, F), columns
+ * mapping outside [0, dst_len) are dropped.  block0 is filled in by the library. */
+#define VBX_MR_MAX 8
+typedef struct {
+  const float* src;
+  float* dst;
+  long src_bstride, dst_bstride, row_stride;
+  int rows, cols, batches, dst_len, rowmap, F, block0, pad_;
+} vbx_mr_job;
+typedef struct {
+  vbx_mr_job job[VBX_MR_MAX];
+  int n;
+} vbx_mr_jobs;
+int vbx_multi_reduce(const vbx_mr_jobs* jobs, void* stream);
+/* first stage of vbx_colsum_bf16 only: scratch[vbx_colsum_slabs()][C] partial column sums (finish with vbx_multi_reduce) */
+int vbx_colsum_bf16_partials(const void* in_bf16, int M, int C, int ld, float* scratch, void* stream);
+int vbx_colsum_slabs(void);
+
 /* fused Adam (torch.optim.Adam semantics, no weight decay/amsgrad) over a flat fp32 buffer; grads are
  * pre-multiplied by *gscale (device scalar, e.g. clip coefficient) if non-NULL. */
 int vbx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

@@ -99,7 +99,7 @@ struct Acts {
   u16 *hf, *hfh;
   float *pred, *per_b;
   // backward scratch
-  float *dx, *dq, *dk, *delta, *slabs, *npart, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
+  float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
   float* gl_ds;
@@ -217,6 +217,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.slab_floats = sf;
     a.slabs = c.take<float>(sf);
     a.npart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // >= the LayerNorm backward's 16-row records
+    a.npart2 = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // attention pre-norm partials (batched reduce)
     a.cpart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D);
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
@@ -572,25 +573,29 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const float* x_in = a.xs[S * l + S - 2];   // input of the attention block
   const float* x_mid = a.xs[S * l + S - 1];  // input of the feed-forward block
 
+  static const bool batched = !(getenv("VBX_BATCH_REDUCE") && atoi(getenv("VBX_BATCH_REDUCE")) == 0);  // 0: one launch per reduction (A/B)
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
   CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st));
   CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
-  CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
+  if (batched) CK(vbx_colsum_bf16_partials(a.dh1, M, 2 * d.Fp, 2 * d.Fp, a.cs_scratch, stream));  // FeedForward[0].bias partials, reduced below
+  else CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
     CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D, stream));
-    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
-    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N2G], d.D, 0, stream));
+    if (!batched) {
+      CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+      CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N2G], d.D, 0, stream));
+    }
   } else {
     CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
                        stream));
-    CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+    if (!batched) CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
   }
-  CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
+  if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
   CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
@@ -599,7 +604,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
                           m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin,
                           m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, stream));
-    if (m->qk_norm) {
+    if (m->qk_norm && !batched) {
       const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
       CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
       CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
@@ -620,12 +625,40 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
-    CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
-    CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
-    CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N1G], d.D, 0, stream));
+    CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    if (!batched) {
+      CK(vbx_reduce_norm_partials(a.npart2, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+      CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N1G], d.D, 0, stream));
+    }
   } else {
-    CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
-    CK(vbx_reduce_norm_partials(a.npart, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+    CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    if (!batched) CK(vbx_reduce_norm_partials(a.npart2, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+  }
+  if (batched) {
+    // ---- every small reduction of the layer in ONE launch (they cost ~0.5 ms per step as separate launches)
+    vbx_mr_jobs jb{};
+    auto add = [&](const float* src, float* dst, int rows, int cols, long row_stride, int batches, long sbs, long dbs, int dst_len,
+                   int rowmap, int F) {
+      vbx_mr_job& j = jb.job[jb.n++];
+      j.src = src; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = row_stride; j.batches = batches;
+      j.src_bstride = sbs; j.dst_bstride = dbs; j.dst_len = dst_len; j.rowmap = rowmap; j.F = F;
+    };
+    const long rec = 2L * d.D;
+    if (m->plain_norm) {  // d(gamma) = first half of the records, summed over batch and chunks
+      add(a.npart, Gd + o[VBX_L_N2G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
+      add(a.npart2, Gd + o[VBX_L_N1G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
+    } else {              // per-batch d(gamma | beta) of the two adaLN norms -> dada_l [B][g1 b1 g2 b2]
+      add(a.npart, dada_l + 2 * d.D, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
+      add(a.npart2, dada_l, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
+    }
+    add(a.cpart, Gd + o[VBX_L_FF2B], d.B * chunks, d.D, d.D, 1, 0, 0, d.D, 0, 0);                               // FeedForward[3].bias
+    add(a.cs_scratch, Gd + o[VBX_L_FF1B], vbx_colsum_slabs(), 2 * d.Fp, 2L * d.Fp, 1, 0, 0, 2 * d.F, 1, d.F);   // FeedForward[0].bias
+    if (fused_qk && m->qk_norm) {
+      const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
+      add(a.gpart, Gd + o[VBX_L_QG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
+      add(a.gpart + (size_t)rows * d.H * 64, Gd + o[VBX_L_KG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
+    }
+    CK(vbx_multi_reduce(&jb, stream));
   }
   if (m->gateloop) {
     // ---- GateLoop: a.dx is the gradient of x_gl = LayerNorm(s) + x0; the residual branch stays in a.dx
