@@ -246,6 +246,18 @@ int vbx_layernorm_fwd(const float* s, const float* w, const float* bias, const f
 int vbx_layernorm_bwd(const float* s, const float* w, const float* dy, float* ds, float* part, int B, int Np, int D, float eps,
                       void* stream);
 
+/* Several vbx_splitk_reduce jobs in one launch (e.g. the four weight gradients of a layer, each with its own slab region). */
+#define VBX_SKR_MAX 6
+typedef struct {
+  const float* slabs;
+  float* dst;
+  int splits, M, N, dst_rows, dst_cols, dst_ld, rowmap, F, block0, pad_;
+} vbx_skr_job;
+typedef struct {
+  vbx_skr_job job[VBX_SKR_MAX];
+  int n;
+} vbx_skr_jobs;
+int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream);
 /* Several small column reductions in one launch: for job i, out[b][map(c)] = sum over r < rows of
  * src[b*src_bstride + r*row_stride + c], c < cols, b < batches; map = identity or the GEGLU row un-interleave (rowmap = 1, F), columns
  * mapping outside [0, dst_len) are dropped.  block0 is filled in by the library. */

@@ -969,6 +969,35 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
   }
 }
 
+// several split-K reductions in one launch (the four weight gradients of a layer): job j owns blocks [block0, next block0)
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs jobs) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < VBX_SKR_MAX; i++)
+    if (i < jobs.n && (int)blockIdx.x >= jobs.job[i].block0) j = i;
+  const vbx_skr_job jb = jobs.job[j];
+  const long total = (long)jb.M * jb.N;
+  const long i4 = ((long)(blockIdx.x - jb.block0) * 256 + threadIdx.x) * 4;  // N % 4 == 0: four columns of one row
+  if (i4 >= total) return;
+  const int r = (int)(i4 / jb.N), c = (int)(i4 - (long)r * jb.N);
+  int dr = r;
+  if (jb.rowmap == 1) dr = geglu_row_unmap(r, jb.F);
+  if (dr < 0 || dr >= jb.dst_rows) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < jb.splits; k++) {
+    const float4 v = *reinterpret_cast<const float4*>(jb.slabs + (long)k * total + i4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* o = jb.dst + (long)dr * jb.dst_ld + c;
+  if (c + 3 < jb.dst_cols && (jb.dst_ld & 3) == 0) {
+    *reinterpret_cast<float4*>(o) = s;
+  } else {
+    const float t[4] = {s.x, s.y, s.z, s.w};
+    for (int e = 0; e < 4; e++)
+      if (c + e < jb.dst_cols) o[e] = t[e];
+  }
+}
+
 }  // namespace
 
 extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
@@ -1041,6 +1070,21 @@ extern "C" int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, f
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, splits, M, N, dst,
                      dst_rows, dst_cols, (long)dst_ld, rowmap, F, accumulate);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream) {
+  VBX_REQUIRE(jobs && jobs->n > 0 && jobs->n <= VBX_SKR_MAX, "vbx_splitk_reduce_multi: bad job count");
+  vbx_skr_jobs j = *jobs;
+  int blocks = 0;
+  for (int i = 0; i < j.n; i++) {
+    VBX_REQUIRE(j.job[i].slabs && j.job[i].dst && j.job[i].splits >= 1 && j.job[i].M > 0 && j.job[i].N > 0 && j.job[i].N % 4 == 0,
+                "vbx_splitk_reduce_multi: bad job %d (N must be a multiple of 4)", i);
+    j.job[i].block0 = blocks;
+    blocks += cdiv((long)j.job[i].M * j.job[i].N / 4, 256);
+  }
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, j);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -215,7 +215,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     upd(d.D, d.Ke, d.M0); upd(d.D, d.D, d.M0);
     if (m->gateloop) upd(3 * d.D, d.D, d.M);
     a.slab_floats = sf;
-    a.slabs = c.take<float>(sf);
+    a.slabs = c.take<float>(4 * sf);  // four regions: the layer's weight-gradient slabs stay live until its batched reduce
     a.npart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // >= the LayerNorm backward's 16-row records
     a.npart2 = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // attention pre-norm partials (batched reduce)
     a.cpart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D);
@@ -340,7 +340,7 @@ int wgrad_join(hipStream_t st) {
 }
 // dW[I,J] = P[K,I]^T . Q[K,J]  -> grads (fp32, reference layout [dst_rows, dst_cols])
 int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, float* slabs, float* dst, int dst_rows,
-          int dst_cols, int rowmap, int F, hipStream_t st) {
+          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr) {
   vbx_gemm_desc g{};
   const int splits = wgrad_splits(I, J, K);
   g.mode = VBX_GEMM_TN; g.epilogue = VBX_EPI_SPLITK; g.M = I; g.N = J; g.K = (int)K; g.lda = ldp; g.ldb = ldq;
@@ -355,7 +355,13 @@ int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, fl
     run = ss.s;
   }
   CK(vbx_gemm(&g, run));
-  CK(vbx_splitk_reduce(slabs, splits, I, J, dst, dst_rows, dst_cols, dst_cols, rowmap, F, 0, run));
+  if (defer && J % 4 == 0 && defer->n < VBX_SKR_MAX) {  // reduced later, together with the layer's other weight gradients
+    vbx_skr_job& jb = defer->job[defer->n++];
+    jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
+    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F;
+  } else {
+    CK(vbx_splitk_reduce(slabs, splits, I, J, dst, dst_rows, dst_cols, dst_cols, rowmap, F, 0, run));
+  }
   if (ss.ok) {
     if (hipEventRecord(ss.done, ss.s) != hipSuccess) {
       vbx_set_error("wgrad: event record on the side stream failed");
@@ -574,14 +580,19 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const float* x_mid = a.xs[S * l + S - 1];  // input of the feed-forward block
 
   static const bool batched = !(getenv("VBX_BATCH_REDUCE") && atoi(getenv("VBX_BATCH_REDUCE")) == 0);  // 0: one launch per reduction (A/B)
+  // the four split-K weight-gradient reductions of the layer are deferred into one launch (own slab region each)
+  static const bool batch_wg = !(getenv("VBX_BATCH_WGRAD") && atoi(getenv("VBX_BATCH_WGRAD")) == 0) && !side_stream().ok;
+  vbx_skr_jobs wj{};
+  vbx_skr_jobs* wjp = batch_wg ? &wj : nullptr;
+  const size_t sfl = a.slab_floats;
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
-  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st));
+  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp));
   CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
   if (batched) CK(vbx_colsum_bf16_partials(a.dh1, M, 2 * d.Fp, 2 * d.Fp, a.cs_scratch, stream));  // FeedForward[0].bias partials, reduced below
   else CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
-  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st));
+  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
@@ -598,7 +609,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
-  CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st));
+  CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
@@ -622,7 +633,8 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
-  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st));
+  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp));
+  if (wj.n) CK(vbx_splitk_reduce_multi(&wj, stream));
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
     CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
