@@ -273,6 +273,11 @@ typedef struct {
   int n;
 } vbx_mr_jobs;
 int vbx_multi_reduce(const vbx_mr_jobs* jobs, void* stream);
+/* vbx_geglu_bwd that also writes per-slab column sums of dh1: scratch[vbx_geglu_bwd_colsum_slabs()][2*Fp] (same interleaved column
+ * order as dh1; finish with vbx_multi_reduce + the GEGLU row un-interleave) -- the FeedForward[0].bias gradient without a second
+ * pass over dh1 */
+int vbx_geglu_bwd_colsum_slabs(void);
+int vbx_geglu_bwd_colsum(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, float* scratch, void* stream);
 /* first stage of vbx_colsum_bf16 only: scratch[vbx_colsum_slabs()][C] partial column sums (finish with vbx_multi_reduce) */
 int vbx_colsum_bf16_partials(const void* in_bf16, int M, int C, int ld, float* scratch, void* stream);
 int vbx_colsum_slabs(void);

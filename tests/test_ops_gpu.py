@@ -723,3 +723,48 @@ def test_pack_embed_text_and_table_grad(L, T):
     L.call("vbx_cond_emb_bwd", demb.to(dev), E, ids.to(dev), T, drop.to(torch.uint8).to(dev), V, gt, Bsz, N, E, st())
     (emb_d.reshape(Bsz * N, E) * demb.double()).sum().backward()
     assert rel_err(gt, tab.grad) < 1e-5, rel_err(gt, tab.grad)
+
+
+# ----------------------------------------------------------------------------- batched reductions
+def test_geglu_bwd_colsum_and_multi_reduce(L):
+    """vbx_geglu_bwd_colsum == vbx_geglu_bwd, and its slab records reduced by vbx_multi_reduce (with the GEGLU row
+    un-interleave) give the column sums of the stored dh1 = the FeedForward[0].bias gradient."""
+    import ctypes as C
+
+    M, Fd, Fp = 333, 170, 192
+    g = torch.Generator().manual_seed(12)
+    h1 = bf(torch.randn(M, 2 * Fp, generator=g)).to(dev)
+    dg = bf(torch.randn(M, Fp, generator=g)).to(dev)
+    ref = torch.empty(M, 2 * Fp, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_geglu_bwd", h1, dg, ref, M, Fp, st())
+    got = torch.empty_like(ref)
+    slabs = L.lib().vbx_geglu_bwd_colsum_slabs()
+    scratch = torch.zeros(slabs, 2 * Fp, device=dev)
+    L.call("vbx_geglu_bwd_colsum", h1, dg, got, M, Fp, scratch, st())
+    assert torch.equal(got, ref)
+
+    class Job(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_bstride", C.c_long), ("dst_bstride", C.c_long),
+                    ("row_stride", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("batches", C.c_int), ("dst_len", C.c_int),
+                    ("rowmap", C.c_int), ("F", C.c_int), ("block0", C.c_int), ("pad_", C.c_int)]
+
+    class Jobs(C.Structure):
+        _fields_ = [("job", Job * 8), ("n", C.c_int)]
+
+    out = torch.zeros(2 * Fd, device=dev)
+    x = torch.randn(3, 37, 100, generator=g).to(dev)  # a second, batched job: per-batch sums over 37 rows of the first 64 columns
+    out2 = torch.zeros(3, 80, device=dev)
+    jobs = Jobs()
+    jobs.n = 2
+    j0, j1 = jobs.job[0], jobs.job[1]
+    j0.src, j0.dst, j0.rows, j0.cols, j0.row_stride, j0.batches = scratch.data_ptr(), out.data_ptr(), slabs, 2 * Fp, 2 * Fp, 1
+    j0.dst_len, j0.rowmap, j0.F = 2 * Fd, 1, Fd
+    j1.src, j1.dst, j1.rows, j1.cols, j1.row_stride, j1.batches = x.data_ptr(), out2.data_ptr(), 37, 64, 100, 3
+    j1.src_bstride, j1.dst_bstride, j1.dst_len = 37 * 100, 80, 64
+    lib = L.lib()
+    lib.vbx_multi_reduce.argtypes = [C.POINTER(Jobs), C.c_void_p]
+    assert lib.vbx_multi_reduce(C.byref(jobs), st()) == 0, lib.vbx_last_error()
+    cs = ref.float().sum(0).view(Fp // 64, 2, 64)
+    exp = torch.cat((cs[:, 0].reshape(-1)[:Fd], cs[:, 1].reshape(-1)[:Fd]))
+    assert rel_err(out, exp) < 1e-5
+    assert rel_err(out2[:, :64], x[:, :, :64].sum(1)) < 1e-6 and float(out2[:, 64:].abs().max()) == 0.0

@@ -63,6 +63,10 @@ _PROTOS = {
     "vbx_gateloop_scan_bwd": [P, P, P, P, I, I, I, P],
     "vbx_layernorm_fwd": [P, P, P, P, P, L, I, F, P],
     "vbx_layernorm_bwd": [P, P, P, P, P, I, I, I, F, P],
+    "vbx_geglu_bwd_colsum": [P, P, P, I, I, P, P],
+    "vbx_geglu_bwd_colsum_slabs": [],
+    "vbx_colsum_bf16_partials": [P, I, I, I, P, P],
+    "vbx_colsum_slabs": [],
     "vbx_geglu_bwd": [P, P, P, I, I, P],
     "vbx_colsum_bf16": [P, I, I, I, P, I, I, I, P, P],
     "vbx_colsum_f32": [P, I, I, I, P, P, P],

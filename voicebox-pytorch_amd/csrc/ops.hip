@@ -470,9 +470,8 @@ __global__ __launch_bounds__(256) void adaln_fwd_mfma_kernel(const float* __rest
 }
 
 // dW[j][t] = sum_b dada[b][j] temb[b][t] ; dbias[j] = sum_b dada[b][j]
-__global__ void adaln_bwd_w_kernel(const float* __restrict__ temb, const float* __restrict__ dada, float* __restrict__ dw,
-                                   float* __restrict__ dbias, int B, int Th, int J) {
-  const int j = blockIdx.y;
+VBX_DEV void adaln_bwd_w_role(const float* __restrict__ temb, const float* __restrict__ dada, float* __restrict__ dw,
+                                 float* __restrict__ dbias, int B, int Th, int J, int j) {
   const int t4 = blockIdx.x * blockDim.x + threadIdx.x;
   if (t4 * 4 >= Th) return;
   float4 s = make_float4(0, 0, 0, 0);
@@ -488,9 +487,8 @@ __global__ void adaln_bwd_w_kernel(const float* __restrict__ temb, const float* 
 }
 // partial dtemb over a slice of j: scratch[slice][b][t]
 constexpr int ADA_SLICES = 128;
-__global__ __launch_bounds__(256) void adaln_bwd_t_kernel(const u16* __restrict__ w, const float* __restrict__ dada,
-                                                          float* __restrict__ scratch, int B, int Th, int J, int bc) {
-  const int slice = blockIdx.y;
+VBX_DEV void adaln_bwd_t_role(const u16* __restrict__ w, const float* __restrict__ dada, float* __restrict__ scratch, int B, int Th,
+                                 int J, int slice) {
   const int per = (J + ADA_SLICES - 1) / ADA_SLICES;
   const int jb = slice * per, je = min(J, jb + per);
   const int t8 = blockIdx.x * blockDim.x + threadIdx.x;  // chunk of 8 t
@@ -523,6 +521,14 @@ __global__ __launch_bounds__(256) void adaln_bwd_t_kernel(const u16* __restrict_
       }
     }
   }
+}
+// one launch for both halves of the adaLN projection backward: blockIdx.y < J -> weight/bias gradient of output row j,
+// otherwise the d(time_emb) partial of slice blockIdx.y - J
+__global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict__ temb, const u16* __restrict__ w,
+                                                        const float* __restrict__ dada, float* __restrict__ dw,
+                                                        float* __restrict__ dbias, float* __restrict__ scratch, int B, int Th, int J) {
+  if ((int)blockIdx.y < J) adaln_bwd_w_role(temb, dada, dw, dbias, B, Th, J, blockIdx.y);
+  else adaln_bwd_t_role(w, dada, scratch, B, Th, J, blockIdx.y - J);
 }
 
 // out[j] (+)= sum_i in[i*ld + j]
@@ -570,6 +576,56 @@ __global__ void geglu_bwd_kernel(const u16* __restrict__ h1, const u16* __restri
 // ---------------------------------------------------------------- column sums
 // stage 1: block = 64 column groups (16 B each) x 4 row lanes over one of CS_SLABS row slabs -> scratch[slab][C]
 constexpr int CS_SLABS = 128;
+// geglu_bwd that also emits the column sums of dh1 (FeedForward[0].bias gradient) as per-slab partial records, so the
+// separate 47 MB colsum pass disappears.  grid (ceil(Fp/8/64), GB_SLABS); block = 64 eight-feature groups x 4 row lanes.
+constexpr int GB_SLABS = 512;
+__global__ __launch_bounds__(256) void geglu_bwd_colsum_kernel(const u16* __restrict__ h1, const u16* __restrict__ dg,
+                                                               u16* __restrict__ dh1, long M, int Fp, float* __restrict__ scratch) {
+  __shared__ float red[4][64][16];
+  const int cgi = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = (blockIdx.x * 64 + cgi) * 8;  // feature in [0, Fp)
+  const int slab = blockIdx.y;
+  const long per = (M + GB_SLABS - 1) / GB_SLABS;
+  const long rb = slab * per, re = min(M, rb + per);
+  float ax[8], ag[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { ax[k] = 0.f; ag[k] = 0.f; }
+  const int blk = f >> 6, c = f & 63;
+  if (f < Fp) {
+    for (long r = rb + rl; r < re; r += 4) {
+      const long xo = r * 2 * Fp + blk * 128 + c, go = xo + 64;
+      float xv[8], gv[8], dv[8], dx[8], dgt[8];
+      unpack8_bf16(*reinterpret_cast<const uint4*>(h1 + xo), xv);
+      unpack8_bf16(*reinterpret_cast<const uint4*>(h1 + go), gv);
+      unpack8_bf16(*reinterpret_cast<const uint4*>(dg + r * Fp + f), dv);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        dx[k] = dv[k] * gelu_erf(gv[k]);
+        dgt[k] = dv[k] * xv[k] * gelu_erf_grad(gv[k]);
+      }
+      const uint4 px = pack8(dx), pg = pack8(dgt);
+      *reinterpret_cast<uint4*>(dh1 + xo) = px;
+      *reinterpret_cast<uint4*>(dh1 + go) = pg;
+      float rx[8], rg[8];  // the sums are over the STORED (bf16) values, like the weight gradient that reads dh1
+      unpack8_bf16(px, rx);
+      unpack8_bf16(pg, rg);
+#pragma unroll
+      for (int k = 0; k < 8; k++) { ax[k] += rx[k]; ag[k] += rg[k]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) { red[rl][cgi][k] = ax[k]; red[rl][cgi][8 + k] = ag[k]; }
+  __syncthreads();
+  if (rl == 0 && f < Fp) {
+    float* o = scratch + (long)slab * 2 * Fp + blk * 128 + c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      o[k] = red[0][cgi][k] + red[1][cgi][k] + red[2][cgi][k] + red[3][cgi][k];
+      o[64 + k] = red[0][cgi][8 + k] + red[1][cgi][8 + k] + red[2][cgi][8 + k] + red[3][cgi][8 + k];
+    }
+  }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void colsum_stage1(const void* __restrict__ in, long M, int C, long ld, float* __restrict__ scratch) {
   constexpr int W = BF16 ? 8 : 4;  // columns per 16-byte load
@@ -1119,10 +1175,8 @@ extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return 
 extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
                                   float* dtemb, float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream) {
   VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
-  hipLaunchKernelGGL(adaln_bwd_w_kernel, dim3(cdiv(Th / 4, 256), J), dim3(256), 0, ST, temb, dada, dw, dbias, B, Th, J);
-  VBX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adaln_bwd_t_kernel, dim3(cdiv(Th / 8, 256), ADA_SLICES), dim3(256), 0, ST, (const u16*)w_bf16, dada,
-                     scratch, B, Th, J, 8);
+  hipLaunchKernelGGL(adaln_bwd_kernel, dim3(cdiv(Th / 4, 256), J + ADA_SLICES), dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw,
+                     dbias, scratch, B, Th, J);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 64)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
                      (long)B * Th, dtemb, (long)B * Th, accumulate_dtemb);
@@ -1141,6 +1195,16 @@ extern "C" int vbx_geglu_bwd(const void* h1_bf16, const void* dg_bf16, void* dh1
   VBX_REQUIRE(h1_bf16 && dg_bf16 && dh1_bf16 && Fp % 64 == 0, "vbx_geglu_bwd: bad args (Fp must be a multiple of 64)");
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((long)M * Fp / 8)), dim3(256), 0, ST, (const u16*)h1_bf16,
                      (const u16*)dg_bf16, (u16*)dh1_bf16, (long)M, Fp);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_geglu_bwd_colsum_slabs(void) { return GB_SLABS; }
+extern "C" int vbx_geglu_bwd_colsum(const void* h1_bf16, const void* dg_bf16, void* dh1_bf16, int M, int Fp, float* scratch,
+                                    void* stream) {
+  VBX_REQUIRE(h1_bf16 && dg_bf16 && dh1_bf16 && scratch && Fp % 64 == 0, "vbx_geglu_bwd_colsum: bad args (Fp must be a multiple of 64)");
+  hipLaunchKernelGGL(geglu_bwd_colsum_kernel, dim3(cdiv(Fp / 8, 64), GB_SLABS), dim3(256), 0, ST, (const u16*)h1_bf16,
+                     (const u16*)dg_bf16, (u16*)dh1_bf16, (long)M, Fp, scratch);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -222,6 +222,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
+    if (cs < (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp) cs = (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp;
     a.cs_scratch = c.take<float>(cs);
     {
       const int r1 = vbx_qknorm_rope_bwd_gpart_rows(d.B), r2 = d.B * vbx_attn_bwd_fused_tiles(d.Np);
@@ -588,9 +589,12 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
   CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp));
-  CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
-  if (batched) CK(vbx_colsum_bf16_partials(a.dh1, M, 2 * d.Fp, 2 * d.Fp, a.cs_scratch, stream));  // FeedForward[0].bias partials, reduced below
-  else CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
+  if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
+    CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
+  } else {
+    CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
+    CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
+  }
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
@@ -664,7 +668,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
       add(a.npart2, dada_l, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
     }
     add(a.cpart, Gd + o[VBX_L_FF2B], d.B * chunks, d.D, d.D, 1, 0, 0, d.D, 0, 0);                               // FeedForward[3].bias
-    add(a.cs_scratch, Gd + o[VBX_L_FF1B], vbx_colsum_slabs(), 2 * d.Fp, 2L * d.Fp, 1, 0, 0, 2 * d.F, 1, d.F);   // FeedForward[0].bias
+    add(a.cs_scratch, Gd + o[VBX_L_FF1B], vbx_geglu_bwd_colsum_slabs(), 2 * d.Fp, 2L * d.Fp, 1, 0, 0, 2 * d.F, 1, d.F);   // FeedForward[0].bias
     if (fused_qk && m->qk_norm) {
       const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
       add(a.gpart, Gd + o[VBX_L_QG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
