@@ -7,8 +7,8 @@ python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dim 1024 2>&1 | tail -1 > gpurun_out/bench_train_dim1024.json
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof9 -o run -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof9.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof9s -o run -- python $R/bench.py --mode sample --steps 1 --warmup 0 --intervals 8 --no-cpu-baseline > $R/gpurun_out/prof9s.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof10 -o run -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof10.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof10s -o run -- python $R/bench.py --mode sample --steps 1 --warmup 0 --intervals 8 --no-cpu-baseline > $R/gpurun_out/prof10s.log 2>&1
 # HBM traffic of the roofline kernel: separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), sample mode so that
 # every FeedForward-in GEMM launch has the same (inference) epilogue as the roofline launches
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o run -- python $R/bench.py --mode sample --steps 1 --warmup 0 --intervals 2 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
