@@ -177,3 +177,30 @@ def test_midpoint_tables_match_oracle_grid():
     assert len(set(dt.tolist())) > 1
     t65 = torch.linspace(0, 1, 65)
     assert len(set((t65[1:] - t65[:-1]).tolist())) == 1  # 64 intervals: dt = 1/64 exactly
+
+
+def test_interpolate_1d_index_rule():
+    """The token->frame resize of the text-conditioned path (csrc/ops.hip:interp_src) restated in numpy float32 and checked
+    against F.interpolate(mode='bilinear', align_corners=False) -- what interpolate_1d (voicebox_pytorch.py:89-107) calls."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    def interp_src(n, N, T):
+        if T == N:
+            return n, n, np.float32(0)
+        scale = np.float32(T) / np.float32(N)
+        src = scale * (np.float32(n) + np.float32(0.5)) - np.float32(0.5)
+        src = np.float32(0) if src < 0 else src
+        i0 = min(int(src), T - 1)
+        i1 = i0 + (1 if i0 < T - 1 else 0)
+        return i0, i1, np.float32(src - np.float32(i0))
+
+    g = torch.Generator().manual_seed(0)
+    for T, N in ((25, 40), (40, 40), (64, 40), (7, 1024), (1000, 96), (1, 5), (5, 1)):
+        e = torch.randn(1, 3, T, generator=g)
+        ref = F.interpolate(e[..., None], (N, 1), mode="bilinear")[..., 0]
+        got = torch.empty(1, 3, N)
+        for n in range(N):
+            i0, i1, lam = interp_src(n, N, T)
+            got[0, :, n] = (1 - float(lam)) * e[0, :, i0] + float(lam) * e[0, :, i1]
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (T, N, float((got - ref).abs().max()))
