@@ -157,6 +157,13 @@ int vbx_pack_embed_input_text(const float* x, const float* cond, const uint8_t* 
                               void* out_f16, void* out_bf16, int B, int N, int D, void* stream);
 int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, int T, const uint8_t* drop_mask, long null_id,
                      float* gtable, int B, int N, int E, void* stream);
+/* DurationPredictor front end (voicebox_pytorch.py:793-823): out fp16 [B*N, E+D] = [ to_phoneme_emb(max(ids,0)) | cond'' ] with
+ * cond'' = curtail_or_pad(where(drop[b], null_cond, cond * ~cond_mask), N); ids [B,N] (-1 = padding), cond fp32 [B,S,D],
+ * cond_mask [B,S] (may be NULL), drop_mask [B] (may be NULL).  Feeds vbx_gemm (to_embed, f16 operands). */
+int vbx_pack_phoneme_input(const long* ids, const float* table, int E, const float* cond, int S, const uint8_t* cond_mask,
+                           const uint8_t* drop_mask, const float* null_cond, void* out_f16, int B, int N, int D, void* stream);
+/* to_pred = Linear(dim, 1) + squeeze (voicebox_pytorch.py:672-675): out[r] = x[r,:] . w + bias[0]  (bias may be NULL). */
+int vbx_rowdot(const float* x, const float* w, const float* bias, float* out, long rows, int D, void* stream);
 /* standalone Transformer.forward (voicebox_pytorch.py:417-431, :476-477): residual stream [B,N+R,D] = register tokens (rows
  * n < R) followed by x [B,N,D]; backward: dx = rows n >= R of dxs, dreg[R,D] = sum over the batch of rows n < R. */
 int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream);

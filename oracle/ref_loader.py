@@ -24,6 +24,8 @@ arithmetic and are therefore restated here:
     or golden vector pins the sampler.
   * gateloop_transformer.SimpleGateLoopLayer (call sites :31,:399,:466) --
     restated in oracle/restate.py (GateLoopRestated); PARITY UNPINNED.
+  * naturalspeech2_pytorch...generate_mask_from_repeats (call site :690, DurationPredictor only) -- restated in
+    oracle/restate.py; PARITY UNPINNED.
 """
 import os
 import sys
@@ -98,8 +100,9 @@ def install_stubs():
                 BinLoss=_Placeholder, maximum_path=lambda *a, **k: None)
         _module("naturalspeech2_pytorch.utils")
         _module("naturalspeech2_pytorch.utils.tokenizer", Tokenizer=_Placeholder)
-        _module("naturalspeech2_pytorch.naturalspeech2_pytorch",
-                generate_mask_from_repeats=lambda *a, **k: None)
+        from oracle.restate import generate_mask_from_repeats  # restated third-party index logic (DurationPredictor :690)
+
+        _module("naturalspeech2_pytorch.naturalspeech2_pytorch", generate_mask_from_repeats=generate_mask_from_repeats)
     if "audiolm_pytorch" not in sys.modules:
         _module("audiolm_pytorch", EncodecWrapper=_Placeholder, HubertWithKmeans=_Placeholder)
     if "spear_tts_pytorch" not in sys.modules:

@@ -237,6 +237,42 @@ def gen_transformer(ref):
     torch.save(out, os.path.join(HERE, "transformer.pt"))
 
 
+def gen_duration(ref):
+    """DurationPredictor in eval mode (voicebox_pytorch.py:596-839; the Aligner / ForwardSumLoss members are third-party
+    placeholders, never called at inference): durations with and without classifier-free guidance, ragged phoneme padding
+    (-1), cond shorter AND longer than the phoneme sequence (curtail_or_pad), and the aligned phoneme ids (:689-692, which goes
+    through the restated third-party generate_mask_from_repeats -- parity unpinned for that helper)."""
+    out = {}
+    for name, S, kw in (("short_cond", 21, dict(attn_qk_norm=True)), ("long_cond", 40, dict(attn_qk_norm=False))):
+        torch.manual_seed(9)
+        dp = ref.DurationPredictor(num_phoneme_tokens=37, dim_phoneme_emb=32, dim=64, depth=2, dim_head=64, heads=2, **kw)
+        g = torch.Generator().manual_seed(13)
+        with torch.no_grad():
+            for n, prm in dp.named_parameters():
+                if n.endswith("gamma"):
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+            dp.null_cond.copy_(torch.randn(64, generator=g) * 0.5)  # a checkpoint may carry any value; exercise the drop path
+            dp.to_pred[0].weight.mul_(4.0)
+            dp.to_pred[0].bias.add_(2.5)  # durations around 2.5 frames so that clamp / int() / repeats are exercised
+        dp.eval()
+        state = {k: v.detach().clone() for k, v in dp.state_dict().items()}
+        b, n = 3, 28
+        ids = torch.randint(0, 37, (b, n), generator=g)
+        ids[1, 20:] = -1
+        ids[2, 9:] = -1
+        cond = torch.randn(b, S, 64, generator=g)
+        cond_mask = torch.rand(b, S, generator=g) < 0.3
+        with torch.no_grad():
+            d1 = dp(cond=cond, phoneme_ids=ids, cond_mask=cond_mask)
+            d_null = dp(cond=cond, phoneme_ids=ids, cond_mask=cond_mask, cond_drop_prob=1.0)
+            d3, aligned = dp.forward_with_cond_scale(cond=cond, phoneme_ids=ids, cond_mask=cond_mask, cond_scale=3.0,
+                                                     return_aligned_phoneme_ids=True)
+        out[name] = dict(kw=kw, state=state, ids=ids, cond=cond, cond_mask=cond_mask, d1=d1.clone(), d_null=d_null.clone(),
+                         d3=d3.clone(), aligned=aligned.clone())
+        print("duration", name, d1[0, :6].tolist(), tuple(aligned.shape))
+    torch.save(out, os.path.join(HERE, "duration.pt"))
+
+
 def gen_cfg1(ref):
     """BASELINE config 1/2: dim 512, depth 2, heads 16, B=2, N=1024.  Weights by the committed
     recipe oracle.restate.init_state_dict(seed=0) (too big to commit); only scalars/slices stored."""
@@ -261,7 +297,7 @@ def gen_cfg1(ref):
 
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
-    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "cfg1"]
+    which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
-         "transformer": gen_transformer, "cfg1": gen_cfg1}[w](ref)
+         "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1}[w](ref)

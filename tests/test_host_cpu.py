@@ -204,3 +204,37 @@ def test_interpolate_1d_index_rule():
             i0, i1, lam = interp_src(n, N, T)
             got[0, :, n] = (1 - float(lam)) * e[0, :, i0] + float(lam) * e[0, :, i1]
         assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (T, N, float((got - ref).abs().max()))
+
+
+def test_duration_predictor_host_logic(golden):
+    """DurationPredictor (voicebox_pytorch.py:596-727) without a GPU: reference state-dict keys load (aligner.* skipped), the
+    aligned-phoneme index logic is bit-exact on the reference's durations, unsupported front ends raise, compute refuses the CPU."""
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("duration")
+    for name, c in g.items():
+        dp = vbx.DurationPredictor(num_phoneme_tokens=37, dim_phoneme_emb=32, dim=64, depth=2, dim_head=64, heads=2, **c["kw"])
+        sd = dict(c["state"])
+        sd["aligner.key_layers.0.weight"] = torch.zeros(2)
+        res = dp.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys and all("inv_freq" in k for k in res.missing_keys), res
+        mine = {k for k in dp.state_dict() if "inv_freq" not in k}
+        assert mine == {k for k in c["state"] if "inv_freq" not in k}
+        assert not dp.null_cond.requires_grad
+        assert torch.equal(dp.align_phoneme_ids_with_durations(c["ids"], c["d3"]), c["aligned"]), name
+        dp.eval()
+        with pytest.raises(Exception) as ei:
+            dp(cond=c["cond"], phoneme_ids=c["ids"], cond_mask=c["cond_mask"])
+        assert "no CPU fallback" in str(ei.value)
+        with pytest.raises(NotImplementedError):
+            dp(cond=c["cond"], texts=["hello"])
+        with pytest.raises(NotImplementedError):
+            dp.train()(cond=c["cond"], phoneme_ids=c["ids"])
+    with pytest.raises(NotImplementedError):
+        vbx.DurationPredictor(dim=64, depth=2, heads=2)  # would need the espeak tokenizer
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=37, depth=2, dim_head=64, heads=2, dim_cond_emb=48, condition_on_text=True)
+    cfm = vbx.ConditionalFlowMatcherWrapper(voicebox=vb, duration_predictor=dp)
+    assert cfm.duration_predictor is dp
+    with pytest.raises(AssertionError):
+        vbx.ConditionalFlowMatcherWrapper(voicebox=vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2,
+                                                                condition_on_text=False), duration_predictor=dp)

@@ -725,6 +725,38 @@ def test_pack_embed_text_and_table_grad(L, T):
     assert rel_err(gt, tab.grad) < 1e-5, rel_err(gt, tab.grad)
 
 
+# ----------------------------------------------------------------------------- DurationPredictor front / back end
+@pytest.mark.parametrize("S", [17, 28, 40])
+def test_pack_phoneme_input_and_rowdot(L, S):
+    """[to_phoneme_emb(max(ids,0)) | curtail_or_pad(where(drop, null_cond, cond * ~cond_mask), N)] (voicebox_pytorch.py:793-823),
+    bit-exact up to the fp16 rounding of the stored operand; to_pred row dot (:672-675, :833)."""
+    Bsz, N, D, E, V = 3, 28, 64, 32, 37
+    g = torch.Generator().manual_seed(S)
+    cond = torch.randn(Bsz, S, D, generator=g)
+    cmask = torch.rand(Bsz, S, generator=g) < 0.4
+    null_cond = torch.randn(D, generator=g)
+    ids = torch.randint(0, V, (Bsz, N), generator=g)
+    ids[1, 20:] = -1
+    table = torch.randn(V, E, generator=g)
+    for drop in (None, torch.tensor([False, True, False])):
+        out16 = torch.empty(Bsz * N, E + D, dtype=torch.float16, device=dev)
+        L.call("vbx_pack_phoneme_input", ids.to(dev), table.to(dev), E, cond.to(dev), S, cmask.to(torch.uint8).to(dev),
+               drop.to(torch.uint8).to(dev) if drop is not None else None, null_cond.to(dev), out16, Bsz, N, D, st())
+        c2 = cond * (~cmask)[..., None]
+        if drop is not None:
+            c2 = torch.where(drop[:, None, None], null_cond, c2)
+        c2 = c2[:, :N] if S > N else F.pad(c2, (0, 0, 0, N - S))
+        ref = torch.cat((table[ids.clamp(min=0)], c2), dim=-1).reshape(Bsz * N, -1)
+        assert torch.equal(out16.float().cpu(), ref.half().float())
+    rows, Dd = 1000, 192
+    x, w, b = torch.randn(rows, Dd, generator=g), torch.randn(1, Dd, generator=g), torch.randn(1, generator=g)
+    out = torch.empty(rows, device=dev)
+    L.call("vbx_rowdot", x.to(dev), w.to(dev), b.to(dev), out, rows, Dd, st())
+    assert rel_err(out, x.double() @ w[0].double() + b.double()) < 1e-6
+    L.call("vbx_rowdot", x.to(dev), w.to(dev), None, out, rows, Dd, st())
+    assert rel_err(out, x.double() @ w[0].double()) < 1e-6
+
+
 # ----------------------------------------------------------------------------- batched reductions
 def test_geglu_bwd_colsum_and_multi_reduce(L):
     """vbx_geglu_bwd_colsum == vbx_geglu_bwd, and its slab records reduced by vbx_multi_reduce (with the GEGLU row

@@ -139,6 +139,31 @@ def test_standalone_transformer(golden):
             assert float((p[k].grad - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-3, (name, k)
 
 
+def test_duration_predictor_inference(golden):
+    """restate.duration_predictor_* vs the reference's DurationPredictor in eval mode (durations, CFG mix, aligned ids)."""
+    g = golden("duration")
+    for name, c in g.items():
+        cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64, num_register_tokens=0, qk_norm=c["kw"]["attn_qk_norm"])
+        p = c["state"]
+        with torch.no_grad():
+            d1 = restate.duration_predictor_forward(p, cfg, c["cond"], c["ids"], c["cond_mask"])
+            dn = restate.duration_predictor_forward(p, cfg, c["cond"], c["ids"], c["cond_mask"],
+                                                    cond_drop_mask=torch.ones(3, dtype=torch.bool))
+            d3 = restate.duration_predictor_with_cond_scale(p, cfg, c["cond"], c["ids"], c["cond_mask"], cond_scale=3.0)
+        for got, key in ((d1, "d1"), (dn, "d_null"), (d3, "d3")):
+            assert float((got - c[key]).abs().max()) < 1e-4, (name, key)
+        assert float((c["d1"] - c["d_null"]).abs().max()) > 1e-2, name  # the null condition changes the answer
+        # index logic: bit-exact on the reference's own durations
+        assert torch.equal(restate.align_phoneme_ids_with_durations(c["ids"], c["d3"]), c["aligned"]), name
+    # known answers of the repeat mask (a padded repeat_interleave)
+    m = restate.generate_mask_from_repeats(torch.tensor([[2, 1, 3], [1, 1, 1]]))
+    assert m.shape == (2, 3, 6)
+    assert m[0].int().tolist() == [[1, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1]]
+    assert m[1].int().tolist() == [[1, 0, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0]]
+    al = restate.align_phoneme_ids_with_durations(torch.tensor([[7, 9, 4]]), torch.tensor([[2.7, 0.2, 3.0]]))
+    assert al.tolist() == [[7, 7, 9, 4, 4, 4]]  # clamp(min=1) then int() truncation
+
+
 def test_cfg1_loss(golden):
     """BASELINE config 1 (dim 512, depth 2, B=2, N=1024) on CPU: restatement vs reference scalars."""
     g = golden("cfg1")

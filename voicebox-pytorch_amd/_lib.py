@@ -43,6 +43,8 @@ _PROTOS = {
     "vbx_pack_embed_input": [P, P, P, P, P, I, I, I, P],
     "vbx_pack_embed_input_text": [P, P, P, P, P, P, I, P, I, L, P, P, I, I, I, P],
     "vbx_cond_emb_bwd": [P, I, P, I, P, L, P, I, I, I, P],
+    "vbx_pack_phoneme_input": [P, P, I, P, I, P, P, P, P, I, I, I, P],
+    "vbx_rowdot": [P, P, P, P, L, I, P],
     "vbx_stack_input": [P, P, P, I, I, I, I, P],
     "vbx_stack_input_bwd": [P, P, P, I, I, I, I, P],
     "vbx_rmsnorm_fwd_f32": [P, P, P, L, P, I, I, I, I, I, P],

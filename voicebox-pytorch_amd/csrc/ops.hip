@@ -113,6 +113,55 @@ __global__ void pack_embed_text_kernel(const float* __restrict__ x, const float*
     if (outb) *reinterpret_cast<uint4*>(outb + oo) = pack8(v);
   }
 }
+// ---- DurationPredictor embed input (voicebox_pytorch.py:793-823): row (b, n) of N phoneme positions =
+// [ to_phoneme_emb(max(ids, 0)) | cond'' ],  cond'' = curtail_or_pad(where(drop[b], null_cond, cond * ~cond_mask), N):
+// frames n >= S are the zero padding of curtail_or_pad (:109-117), applied AFTER the drop (:797-804, :819).
+__global__ void pack_phoneme_kernel(const long* __restrict__ ids, const float* __restrict__ table, int E,
+                                    const float* __restrict__ cond, int S, const uint8_t* __restrict__ cmask,
+                                    const uint8_t* __restrict__ drop, const float* __restrict__ null_cond,
+                                    u16* __restrict__ out, int B, int N, int D) {
+  const int ce = E / 8, cpr = ce + D / 8;
+  const long total = (long)B * N * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cpr;
+    const int c = (int)(i - row * cpr);
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    float v[8];
+    if (c < ce) {
+      long id = ids[row];
+      id = id < 0 ? 0 : id;  // -1 = padding, clamped (:811)
+      const float* src = table + id * E + c * 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = src[k];
+    } else {
+      const int d = (c - ce) * 8;
+      const long crow = (long)b * S + n;
+      if (n >= S || (!(drop && drop[b]) && cmask && cmask[crow])) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = 0.f;
+      } else {
+        const float* src = (drop && drop[b]) ? null_cond + d : cond + crow * D + d;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[k];
+      }
+    }
+    *reinterpret_cast<uint4*>(out + row * (long)(E + D) + (long)c * 8) = pack8_h(v);
+  }
+}
+// to_pred = Linear(dim, 1) + Rearrange('... 1 -> ...') (:672-675): one wave per row.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + r * D + d), b = *reinterpret_cast<const float4*>(w + d);
+    s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s + (bias ? bias[0] : 0.f);
+}
 // gradient of the embedding table: scatter of d(cond_emb) [B*N, E] (bf16) through the same resize weights.  fp32 atomics:
 // like torch's embedding backward the accumulation order is not deterministic.
 __global__ void cond_emb_bwd_kernel(const u16* __restrict__ demb, int ld, const long* __restrict__ ids, int T,
@@ -1028,6 +1077,26 @@ extern "C" int vbx_pack_embed_input_text(const float* x, const float* cond, cons
   const long chunks = (long)B * N * (2 * D + E) / 8;
   hipLaunchKernelGGL(pack_embed_text_kernel, dim3(grid_for(chunks)), dim3(256), 0, ST, x, cond, cond_mask, drop_mask, null_cond, ids, T,
                      table, E, null_id, (u16*)out_f16, (u16*)out_bf16, B, N, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_pack_phoneme_input(const long* ids, const float* table, int E, const float* cond, int S,
+                                      const uint8_t* cond_mask, const uint8_t* drop_mask, const float* null_cond,
+                                      void* out_f16, int B, int N, int D, void* stream) {
+  VBX_REQUIRE(ids && table && cond && out_f16 && B > 0 && N > 0 && S > 0 && D % 8 == 0 && E > 0 && E % 8 == 0,
+              "vbx_pack_phoneme_input: bad args");
+  VBX_REQUIRE(!drop_mask || null_cond, "vbx_pack_phoneme_input: a drop mask needs null_cond");
+  const long chunks = (long)B * N * (D + E) / 8;
+  hipLaunchKernelGGL(pack_phoneme_kernel, dim3(grid_for(chunks)), dim3(256), 0, ST, ids, table, E, cond, S, cond_mask, drop_mask,
+                     null_cond, (u16*)out_f16, B, N, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_rowdot(const float* x, const float* w, const float* bias, float* out, long rows, int D, void* stream) {
+  VBX_REQUIRE(x && w && out && rows > 0 && D > 0 && D % 4 == 0, "vbx_rowdot: bad args");
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)cdiv(rows, 4L)), dim3(256), 0, ST, x, w, bias, out, rows, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -497,14 +497,19 @@ class ConditionalFlowMatcherWrapper(nn.Module):
         self.condition_on_text = voicebox.condition_on_text
         assert not (not self.condition_on_text and exists(text_to_semantic)), \
             'TextToSemantic should not be passed in if not conditioning on text'
-        if exists(text_to_semantic) or exists(duration_predictor):
-            raise NotImplementedError("text front-ends are out of scope of the hot path")
+        if exists(text_to_semantic):
+            raise NotImplementedError("TextToSemantic (spear-tts) is a third-party front end, out of scope: pass semantic_token_ids")
+        if exists(duration_predictor):
+            from .duration import DurationPredictor
+
+            assert isinstance(duration_predictor, DurationPredictor)
+            assert self.condition_on_text, 'a duration predictor aligns phoneme ids for a text-conditioned VoiceBox'
         if use_torchode:
             raise NotImplementedError("the adaptive torchode/Tsit5 path is replaced by the built-in fixed-step midpoint solver")
         if torchdiffeq_ode_method != 'midpoint':
             raise NotImplementedError("only the fixed-grid midpoint method (the reference default) is built")
         self.text_to_semantic = None
-        self.duration_predictor = None
+        self.duration_predictor = duration_predictor  # a submodule, as in the reference (:1147): its weights are in state_dict()
         self.cond_drop_prob = cond_drop_prob
         self.use_torchode = False
         self.odeint_kwargs = dict(atol=ode_atol, rtol=ode_rtol, method=torchdiffeq_ode_method)  # atol/rtol: unused by fixed grids
@@ -538,10 +543,17 @@ class ConditionalFlowMatcherWrapper(nn.Module):
         if self.condition_on_text:  # :1208-1255
             if exists(texts) or exists(text_token_ids):
                 raise NotImplementedError("text -> semantic tokens needs a TextToSemantic module (out of scope): pass semantic_token_ids")
-            if exists(phoneme_ids):
-                raise NotImplementedError("phoneme ids need a DurationPredictor to be aligned to frames (out of scope, SURVEY 8(f) #4)")
-            assert exists(semantic_token_ids), "a text-conditioned model samples from semantic_token_ids (batch, tokens)"
-            cond_token_ids = semantic_token_ids.to(dev)
+            if exists(semantic_token_ids):
+                assert not exists(phoneme_ids)
+                cond_token_ids = semantic_token_ids.to(dev)
+            else:  # :1231-1241: phoneme ids -> predicted durations -> one id per frame
+                assert exists(phoneme_ids), "a text-conditioned model samples from semantic_token_ids or phoneme_ids"
+                if not exists(self.duration_predictor):
+                    raise NotImplementedError("phoneme_ids need a DurationPredictor (pass duration_predictor=) to be aligned to frames")
+                assert exists(cond), "the duration predictor is conditioned on cond (B, frames, dim)"
+                self.duration_predictor.eval()
+                _, cond_token_ids = self.duration_predictor.forward_with_cond_scale(
+                    cond=cond, phoneme_ids=phoneme_ids, return_aligned_phoneme_ids=True)
             target_len = cond_token_ids.shape[-1]
             if exists(cond):  # curtail_or_pad(cond, cond_target_length) (:109-119, :1253)
                 n = cond.shape[-2]
