@@ -6,11 +6,18 @@
 namespace {
 
 constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
+// The row kernels are templated on NC = float4 chunks per lane actually needed (2: D <= 512, 4: D <= 1024, 8: D <= 2048): with
+// the arrays sized for D = 2048 the D = 512 instantiation carried 132 (forward) / 218 (backward) VGPRs -- 3 resp. 2 waves per
+// SIMD for kernels whose only job is to keep HBM requests in flight.
+#define VBX_NC_DISPATCH(D_, CALL) \
+  do {                            \
+    if ((D_) <= 512) { CALL(2); } else if ((D_) <= 1024) { CALL(4); } else { CALL(8); } \
+  } while (0)
 
 // ---------------------------------------------------------------- forward
 // y = x / max(|x|, 1e-12) * sqrt(D) * gamma[b] (+ beta[b])        (voicebox_pytorch.py:246-247, 270-276)
 // FWD_ROWS = rows per wave in flight (loads of all issued before any reduction)
-template <int FWD_ROWS>
+template <int FWD_ROWS, int NC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, long gb_stride,
                                                            u16* __restrict__ y, u16* __restrict__ y16, int B, int Np, int n0,
@@ -30,9 +37,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
       const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
       const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
       const float4* b4 = beta ? reinterpret_cast<const float4*>(beta + (long)b * gb_stride) : nullptr;
-      float4 v[MAXC], g[MAXC], bt[MAXC];
+      float4 v[NC], g[NC], bt[NC];
 #pragma unroll
-      for (int i = 0; i < MAXC; i++) {
+      for (int i = 0; i < NC; i++) {
         const int c = lane + 64 * i;
         if (c < D4) {
           v[i] = xr[c];
@@ -42,7 +49,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
       }
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < MAXC; i++) {
+      for (int i = 0; i < NC; i++) {
         const int c = lane + 64 * i;
         if (c < D4) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
       }
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
       uint2* yr = y ? reinterpret_cast<uint2*>(y + ri * D) : nullptr;
       uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + ri * D) : nullptr;
 #pragma unroll
-      for (int i = 0; i < MAXC; i++) {
+      for (int i = 0; i < NC; i++) {
         const int c = lane + 64 * i;
         if (c < D4) {
           const float4 o = make_float4(v[i].x * r * g[i].x + bt[i].x, v[i].y * r * g[i].y + bt[i].y, v[i].z * r * g[i].z + bt[i].z,
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // run: train step 12.75 -> 12.99 ms, the doubled partial records cost more than the extra parallelism buys)
 // NB_WAVES = waves per block of the backward kernel (16-row chunk -> 2 rows per wave with 8 waves; 4 waves when the
 // [NB_WAVES][3][D] fp32 reduction buffer of 8 waves would exceed the 160 KiB of LDS, i.e. D > 1664)
-template <int NB_WAVES, int RB_ROWS>
+template <int NB_WAVES, int RB_ROWS, int NC>
 __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            long gb_stride, const u16* __restrict__ dy,
                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out,
@@ -87,9 +94,9 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
   const int D4 = D >> 2;
   const float sqrtD = sqrtf((float)D);
   const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
-  float4 ag[MAXC], ab[MAXC], ac[MAXC];
+  float4 ag[NC], ab[NC], ac[NC];
 #pragma unroll
-  for (int i = 0; i < MAXC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0); }
+  for (int i = 0; i < NC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0); }
   for (int k = 0; k < RB_ROWS / NB_WAVES; k++) {
     const int j = chunk * RB_ROWS + wave + NB_WAVES * k;
     if (j >= rpb) break;
@@ -97,10 +104,10 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
     const long drow = ((long)b * rpb + j) * D;
     const float4* xr = reinterpret_cast<const float4*>(x + xrow);
     const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow);
-    float4 xv[MAXC], dv[MAXC];
+    float4 xv[NC], dv[NC];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         xv[i] = xr[c];
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         const float4 g = g4[c];
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
     float4* dout = reinterpret_cast<float4*>(dx_out + xrow);
     uint2* dbo = dxb ? reinterpret_cast<uint2*>(dxb + xrow) : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         float4 o = make_float4((dv[i].x - xv[i].x * dot) * inv, (dv[i].y - xv[i].y * dot) * inv,
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
   // cross-wave reduction of the gamma/beta partials
   float4* r4 = reinterpret_cast<float4*>(red);
 #pragma unroll
-  for (int i = 0; i < MAXC; i++) {
+  for (int i = 0; i < NC; i++) {
     const int c = lane + 64 * i;
     if (c < D4) {
       r4[(wave * 3 + 0) * D4 + c] = ag[i];
@@ -312,12 +319,16 @@ static int rmsnorm_fwd_launch(const float* x, const float* gamma, const float* b
   static const int rpw = getenv("VBX_RMS_ROWS") ? atoi(getenv("VBX_RMS_ROWS")) : 1;  // A/B: rows per wave in flight (2: 9 -> 14 us)
   int blocks = cdiv(rows, 4 * (rpw == 2 ? 2 : 1));
   if (blocks > 4096) blocks = 4096;
-  if (rpw == 2)
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32);
-  else
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride,
-                       (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32);
+#define VBX_RF_LAUNCH2(NC_)                                                                                                      \
+  hipLaunchKernelGGL((rmsnorm_fwd_kernel<2, NC_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride, \
+                     (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32)
+#define VBX_RF_LAUNCH1(NC_)                                                                                                      \
+  hipLaunchKernelGGL((rmsnorm_fwd_kernel<1, NC_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride, \
+                     (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32)
+  if (rpw == 2) VBX_NC_DISPATCH(D, VBX_RF_LAUNCH2);
+  else VBX_NC_DISPATCH(D, VBX_RF_LAUNCH1);
+#undef VBX_RF_LAUNCH1
+#undef VBX_RF_LAUNCH2
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -346,21 +357,28 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
   VBX_REQUIRE(!colpart || dx_in, "vbx_rmsnorm_bwd: column sums need dx_in");
   const bool eight = (size_t)8 * 3 * D * sizeof(float) <= 160 * 1024;
   const size_t lds = (size_t)(eight ? 8 : 4) * 3 * D * sizeof(float);
-#define VBX_RB_LAUNCH(W, R)                                                                                                    \
+#define VBX_RB_LAUNCH_NC(W, R, NC_)                                                                                             \
   do {                                                                                                                         \
     static bool attr_ = false;                                                                                                 \
     if (!attr_) {                                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<W, R>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<W, R, NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024);                                                                                   \
       attr_ = true;                                                                                                            \
     }                                                                                                                          \
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<W, R>), grid, dim3(64 * W), lds, (hipStream_t)stream, x, gamma, gb_stride,            \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<W, R, NC_>), grid, dim3(64 * W), lds, (hipStream_t)stream, x, gamma, gb_stride,       \
                        (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch, D);          \
+  } while (0)
+#define VBX_RB_LAUNCH(W, R)                                                 \
+  do {                                                                     \
+    if (D <= 512) VBX_RB_LAUNCH_NC(W, R, 2);                               \
+    else if (D <= 1024) VBX_RB_LAUNCH_NC(W, R, 4);                         \
+    else VBX_RB_LAUNCH_NC(W, R, 8);                                        \
   } while (0)
   if (eight && rb_rows() == 8) VBX_RB_LAUNCH(8, 8);
   else if (eight) VBX_RB_LAUNCH(8, 16);
   else if (rb_rows() == 8) VBX_RB_LAUNCH(4, 8);
   else VBX_RB_LAUNCH(4, 16);
+#undef VBX_RB_LAUNCH_NC
 #undef VBX_RB_LAUNCH
   VBX_LAUNCH_CHECK();
   return 0;
