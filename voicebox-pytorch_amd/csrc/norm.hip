@@ -342,7 +342,10 @@ extern "C" int vbx_rmsnorm_fwd_f32(const float* x, const float* gamma, const flo
 }
 
 static int rb_rows() {
-  static const int r = (getenv("VBX_RMS_BWD_ROWS") && atoi(getenv("VBX_RMS_BWD_ROWS")) == 8) ? 8 : 16;
+  static const int r = [] {
+    const int v = getenv("VBX_RMS_BWD_ROWS") ? atoi(getenv("VBX_RMS_BWD_ROWS")) : 16;
+    return (v == 8 || v == 32) ? v : 16;
+  }();
   return r;
 }
 extern "C" int vbx_rmsnorm_bwd_chunks(int rows_per_batch) { return cdiv(rows_per_batch, rb_rows()); }
@@ -375,8 +378,10 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
     else VBX_RB_LAUNCH_NC(W, R, 8);                                        \
   } while (0)
   if (eight && rb_rows() == 8) VBX_RB_LAUNCH(8, 8);
+  else if (eight && rb_rows() == 32) VBX_RB_LAUNCH(8, 32);
   else if (eight) VBX_RB_LAUNCH(8, 16);
   else if (rb_rows() == 8) VBX_RB_LAUNCH(4, 8);
+  else if (rb_rows() == 32) VBX_RB_LAUNCH(4, 32);
   else VBX_RB_LAUNCH(4, 16);
 #undef VBX_RB_LAUNCH_NC
 #undef VBX_RB_LAUNCH

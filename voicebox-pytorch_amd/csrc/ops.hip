@@ -519,20 +519,49 @@ __global__ __launch_bounds__(256) void adaln_fwd_mfma_kernel(const float* __rest
 }
 
 // dW[j][t] = sum_b dada[b][j] temb[b][t] ; dbias[j] = sum_b dada[b][j]
+// a block writes ADA_WROWS consecutive rows j: the B float4 of temb a thread needs are loaded once and reused per row
+constexpr int ADA_WROWS = 4;
 VBX_DEV void adaln_bwd_w_role(const float* __restrict__ temb, const float* __restrict__ dada, float* __restrict__ dw,
-                                 float* __restrict__ dbias, int B, int Th, int J, int j) {
+                                 float* __restrict__ dbias, int B, int Th, int J, int jblk) {
   const int t4 = blockIdx.x * blockDim.x + threadIdx.x;
   if (t4 * 4 >= Th) return;
-  float4 s = make_float4(0, 0, 0, 0);
-  float sb = 0.f;
-  for (int b = 0; b < B; b++) {
-    const float g = dada[(long)b * J + j];
-    const float4 t = *reinterpret_cast<const float4*>(temb + (long)b * Th + t4 * 4);
-    s.x += g * t.x; s.y += g * t.y; s.z += g * t.z; s.w += g * t.w;
-    sb += g;
+  const int j0 = jblk * ADA_WROWS;
+  if (B <= 8) {
+    float4 t[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+      t[b] = b < B ? *reinterpret_cast<const float4*>(temb + (long)b * Th + t4 * 4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < ADA_WROWS; r++) {
+      const int j = j0 + r;
+      if (j >= J) break;
+      float4 s = make_float4(0, 0, 0, 0);
+      float sb = 0.f;
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const float g = b < B ? dada[(long)b * J + j] : 0.f;
+        s.x += g * t[b].x; s.y += g * t[b].y; s.z += g * t[b].z; s.w += g * t[b].w;
+        sb += g;
+      }
+      *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
+      if (t4 == 0) dbias[j] = sb;
+    }
+    return;
   }
-  *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
-  if (t4 == 0) dbias[j] = sb;
+  for (int r = 0; r < ADA_WROWS; r++) {
+    const int j = j0 + r;
+    if (j >= J) break;
+    float4 s = make_float4(0, 0, 0, 0);
+    float sb = 0.f;
+    for (int b = 0; b < B; b++) {
+      const float g = dada[(long)b * J + j];
+      const float4 t = *reinterpret_cast<const float4*>(temb + (long)b * Th + t4 * 4);
+      s.x += g * t.x; s.y += g * t.y; s.z += g * t.z; s.w += g * t.w;
+      sb += g;
+    }
+    *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
+    if (t4 == 0) dbias[j] = sb;
+  }
 }
 // partial dtemb over a slice of j: scratch[slice][b][t]
 constexpr int ADA_SLICES = 128;
@@ -549,6 +578,7 @@ VBX_DEV void adaln_bwd_t_role(const u16* __restrict__ w, const float* __restrict
     for (int k = 0; k < 8; k++)
 #pragma unroll
       for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+#pragma unroll 4
     for (int j = jb; j < je; j++) {
       float wv[8];
       unpack8_f16(*reinterpret_cast<const uint4*>(w + (long)j * Th + t8 * 8), wv);
@@ -571,13 +601,15 @@ VBX_DEV void adaln_bwd_t_role(const u16* __restrict__ w, const float* __restrict
     }
   }
 }
-// one launch for both halves of the adaLN projection backward: blockIdx.y < J -> weight/bias gradient of output row j,
-// otherwise the d(time_emb) partial of slice blockIdx.y - J
+// one launch for both halves of the adaLN projection backward: blockIdx.y < ADA_SLICES -> the d(time_emb) partial of that slice,
+// otherwise the weight/bias gradient of output rows [ADA_WROWS * (blockIdx.y - ADA_SLICES), +ADA_WROWS)
 __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict__ temb, const u16* __restrict__ w,
                                                         const float* __restrict__ dada, float* __restrict__ dw,
                                                         float* __restrict__ dbias, float* __restrict__ scratch, int B, int Th, int J) {
-  if ((int)blockIdx.y < J) adaln_bwd_w_role(temb, dada, dw, dbias, B, Th, J, blockIdx.y);
-  else adaln_bwd_t_role(w, dada, scratch, B, Th, J, blockIdx.y - J);
+  // the few long-running d(time_emb) blocks (a serial loop over a slice of j) are dispatched first so that they overlap the
+  // write-bound weight-gradient blocks instead of forming the kernel's tail
+  if ((int)blockIdx.y < ADA_SLICES) adaln_bwd_t_role(w, dada, scratch, B, Th, J, blockIdx.y);
+  else adaln_bwd_w_role(temb, dada, dw, dbias, B, Th, J, blockIdx.y - ADA_SLICES);
 }
 
 // out[j] (+)= sum_i in[i*ld + j]
@@ -1244,7 +1276,7 @@ extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return 
 extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
                                   float* dtemb, float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream) {
   VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
-  hipLaunchKernelGGL(adaln_bwd_kernel, dim3(cdiv(Th / 4, 256), J + ADA_SLICES), dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw,
+  hipLaunchKernelGGL(adaln_bwd_kernel, dim3(cdiv(Th / 4, 256), cdiv(J, ADA_WROWS) + ADA_SLICES), dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw,
                      dbias, scratch, B, Th, J);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 64)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
