@@ -525,6 +525,27 @@ def test_time_embed_and_adaln(L):
     assert rel_err(dws, pr["sinu_pos_emb.0.weights"].grad) < 1e-4
 
 
+@pytest.mark.parametrize("Bsz,Th,J", [(8, 2048, 2048), (11, 264, 516), (2, 64, 8192), (1, 8, 4)])
+def test_adaln_proj_bwd_shapes(L, Bsz, Th, J):
+    """dW = dada^T temb, dbias, dtemb = dada W at the bench shape, with a batch > 8 (two LDS rounds), a J that is not a multiple
+    of the slice count, the largest J of the LDS-staged kernel (dim 2048) and a degenerate shape; both kernel versions agree."""
+    g = torch.Generator().manual_seed(Bsz + Th + J)
+    temb = torch.randn(Bsz, Th, generator=g)
+    W = (torch.randn(J, Th, generator=g) * 0.02).half()
+    dada = torch.randn(Bsz, J, generator=g)
+    dW = torch.empty(J, Th, device=dev)
+    dbias = torch.empty(J, device=dev)
+    dtemb = torch.empty(Bsz, Th, device=dev)
+    scratch = torch.full((L.lib().vbx_adaln_proj_bwd_scratch_floats(Bsz, Th, J),), float("nan"), device=dev)
+    L.call("vbx_adaln_proj_bwd", temb.to(dev), W.to(dev), dada.to(dev), dW, dbias, dtemb, scratch, Bsz, Th, J, 0, st())
+    assert rel_err(dW, dada.double().t() @ temb.double()) < 1e-5
+    assert rel_err(dbias, dada.double().sum(0)) < 1e-5
+    assert rel_err(dtemb, dada.double() @ W.double()) < 1e-5
+    keep = dtemb.clone()
+    L.call("vbx_adaln_proj_bwd", temb.to(dev), W.to(dev), dada.to(dev), dW, dbias, dtemb, scratch, Bsz, Th, J, 1, st())
+    assert rel_err(dtemb, 2 * keep) < 1e-6  # accumulate_dtemb
+
+
 def test_geglu_bwd_and_colsum(L):
     M, Fd, Fp = 100, 170, 192
     g = torch.Generator().manual_seed(6)

@@ -2,6 +2,7 @@
 // attention): embed packing, conv positional embedding, time embedding, adaLN projections, GEGLU
 // backward, column sums, masked MSE, CFM inputs, ODE axpy, weight packing, Adam, grad-norm.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -610,6 +611,111 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict_
   // write-bound weight-gradient blocks instead of forming the kernel's tail
   if ((int)blockIdx.y < ADA_SLICES) adaln_bwd_t_role(w, dada, scratch, B, Th, J, blockIdx.y);
   else adaln_bwd_w_role(temb, dada, dw, dbias, B, Th, J, blockIdx.y - ADA_SLICES);
+}
+
+// v2 of the same launch (default; VBX_ADALN_BWD=1 selects the kernel above for the A/B): the compiler turned v1's per-batch
+// guards into scalar branches with a wait after every load (one exposed memory round trip per row of the slice -- the
+// d(time_emb) blocks were the kernel's critical path at ~20 us).  Here the block's dada values sit in LDS, batch rows
+// beyond B carry a zero weight instead of a branch, and ADA_TG weight rows are requested before the first is consumed.
+constexpr int ADA_PER_MAX = 64;  // rows of one d(time_emb) slice held in LDS: J <= ADA_SLICES * 64
+constexpr int ADA_TG = 8;        // weight rows requested together by a d(time_emb) thread
+__global__ __launch_bounds__(256) void adaln_bwd_kernel_v2(const float* __restrict__ temb, const u16* __restrict__ w,
+                                                           const float* __restrict__ dada, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, float* __restrict__ scratch, int B, int Th,
+                                                           int J) {
+  __shared__ __attribute__((aligned(16))) float gsh[ADA_PER_MAX * 8];  // [row of the block][8 batch rows]
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.y < ADA_SLICES) {  // ---- d(time_emb) partial of one slice of j: scratch[slice][b][t]
+    if ((long)blockIdx.x * 256 * 8 >= Th) return;  // block-uniform
+    const int slice = blockIdx.y;
+    const int per = (J + ADA_SLICES - 1) / ADA_SLICES;
+    const int jb = slice * per, je = min(J, jb + per);
+    const int t8 = blockIdx.x * 256 + tid;
+    const bool tv = (long)t8 * 8 < Th;
+    const u16* wcol = w + (tv ? t8 : 0) * 8;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      __syncthreads();
+      for (int i = tid; i < per * 8; i += 256) {
+        const int j = jb + (i >> 3), b = b0 + (i & 7);
+        gsh[i] = (j < je && b < B) ? dada[(long)b * J + j] : 0.f;
+      }
+      __syncthreads();
+      float acc[8][8];
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+      for (int jj0 = 0; jj0 < per; jj0 += ADA_TG) {
+        uint4 wq[ADA_TG];
+#pragma unroll
+        for (int u = 0; u < ADA_TG; u++) wq[u] = *reinterpret_cast<const uint4*>(wcol + (long)min(jb + jj0 + u, J - 1) * Th);
+#pragma unroll
+        for (int u = 0; u < ADA_TG; u++) {
+          if (jj0 + u < per) {  // rows past the slice were clamped above and carry no weight
+            float wv[8];
+            unpack8_f16(wq[u], wv);
+            const float4 g0 = *reinterpret_cast<const float4*>(gsh + (jj0 + u) * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(gsh + (jj0 + u) * 8 + 4);
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+              for (int i = 0; i < 8; i++) acc[k][i] += gv[k] * wv[i];
+          }
+        }
+      }
+      if (tv) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (b0 + k < B) {
+            float* o = scratch + ((long)slice * B + b0 + k) * Th + (long)t8 * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- weight / bias gradient of rows [j0, j0 + ADA_WROWS)
+  const int j0 = ((int)blockIdx.y - ADA_SLICES) * ADA_WROWS;
+  const int t4 = blockIdx.x * 256 + tid;
+  const bool tv = (long)t4 * 4 < Th;
+  const float* tcol = temb + (tv ? t4 : 0) * 4;
+  float4 s[ADA_WROWS];
+  float sb[ADA_WROWS];
+#pragma unroll
+  for (int r = 0; r < ADA_WROWS; r++) { s[r] = make_float4(0.f, 0.f, 0.f, 0.f); sb[r] = 0.f; }
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    __syncthreads();
+    if (tid < 8 * ADA_WROWS) {
+      const int j = j0 + (tid >> 3), b = b0 + (tid & 7);
+      gsh[tid] = (j < J && b < B) ? dada[(long)b * J + j] : 0.f;
+    }
+    __syncthreads();
+    float4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const float4*>(tcol + (long)min(b0 + k, B - 1) * Th);  // weight 0 past B
+#pragma unroll
+    for (int r = 0; r < ADA_WROWS; r++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float g = gsh[r * 8 + k];
+        s[r].x += g * t[k].x; s[r].y += g * t[k].y; s[r].z += g * t[k].z; s[r].w += g * t[k].w;
+        sb[r] += g;
+      }
+    }
+  }
+  if (tv) {
+#pragma unroll
+    for (int r = 0; r < ADA_WROWS; r++) {
+      const int j = j0 + r;
+      if (j < J) {
+        *reinterpret_cast<float4*>(dw + (long)j * Th + (long)t4 * 4) = s[r];
+        if (t4 == 0) dbias[j] = sb[r];
+      }
+    }
+  }
 }
 
 // out[j] (+)= sum_i in[i*ld + j]
@@ -1276,8 +1382,12 @@ extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return 
 extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
                                   float* dtemb, float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream) {
   VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
-  hipLaunchKernelGGL(adaln_bwd_kernel, dim3(cdiv(Th / 4, 256), cdiv(J, ADA_WROWS) + ADA_SLICES), dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw,
-                     dbias, scratch, B, Th, J);
+  static const int ver = getenv("VBX_ADALN_BWD") ? atoi(getenv("VBX_ADALN_BWD")) : 2;
+  const dim3 grid(cdiv(Th / 4, 256), cdiv(J, ADA_WROWS) + ADA_SLICES);
+  if (ver != 1 && J <= ADA_SLICES * ADA_PER_MAX)
+    hipLaunchKernelGGL(adaln_bwd_kernel_v2, grid, dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw, dbias, scratch, B, Th, J);
+  else
+    hipLaunchKernelGGL(adaln_bwd_kernel, grid, dim3(256), 0, ST, temb, (const u16*)w_bf16, dada, dw, dbias, scratch, B, Th, J);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv((long)B * Th, 64)), dim3(256), 0, ST, scratch, (long)ADA_SLICES,
                      (long)B * Th, dtemb, (long)B * Th, accumulate_dtemb);
