@@ -528,7 +528,7 @@ def test_time_embed_and_adaln(L):
 @pytest.mark.parametrize("Bsz,Th,J", [(8, 2048, 2048), (11, 264, 516), (2, 64, 8192), (1, 8, 4)])
 def test_adaln_proj_bwd_shapes(L, Bsz, Th, J):
     """dW = dada^T temb, dbias, dtemb = dada W at the bench shape, with a batch > 8 (two LDS rounds), a J that is not a multiple
-    of the slice count, the largest J of the LDS-staged kernel (dim 2048) and a degenerate shape; both kernel versions agree."""
+    of the slice count, the largest J of the LDS-staged kernel (dim 2048) and a degenerate shape."""
     g = torch.Generator().manual_seed(Bsz + Th + J)
     temb = torch.randn(Bsz, Th, generator=g)
     W = (torch.randn(J, Th, generator=g) * 0.02).half()

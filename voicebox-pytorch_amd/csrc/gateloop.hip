@@ -101,6 +101,7 @@ __global__ __launch_bounds__(GL_CH* GL_CHUNKS) void gl_scan_bwd_kernel(const flo
 
 // ------------------------------------------------------------------ post LayerNorm (nn.LayerNorm(D), eps 1e-5) + residual
 constexpr int LN_MAXC = 8;  // float4 chunks per lane -> D <= 2048
+template <int NC>  // float4 chunks per lane actually needed (2: D <= 512, 4: D <= 1024, 8: D <= 2048), see norm.hip
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ resid,
                                                              float* __restrict__ y, long rows, int D, float eps) {
@@ -111,10 +112,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const float4* b4 = reinterpret_cast<const float4*>(bias);
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const float4* sr = reinterpret_cast<const float4*>(s + r * D);
-    float4 v[LN_MAXC];
+    float4 v[NC];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         v[i] = sr[c];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float mean = wave_sum(sum) * invD;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float4* rr = resid ? reinterpret_cast<const float4*>(resid + r * D) : nullptr;
     float4* yr = reinterpret_cast<float4*>(y + r * D);
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         const float4 g = w4[c], bb = b4[c];
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // xh = (s - mean) rstd;  dw += dy xh;  db += dy;  dxh = dy w;  ds = rstd (dxh - mean(dxh) - xh mean(dxh xh))
 // grid (chunks of 16 rows, B); partial records part[b][chunk][2][D] (dw | db), reduced by vbx_reduce_norm_partials.
 constexpr int LN_WAVES = 8;
+template <int NC>
 __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
                                                                        const float* __restrict__ dy, float* __restrict__ ds,
                                                                        float* __restrict__ part, int Np, int D, float eps) {
@@ -162,19 +164,19 @@ __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const floa
   const int D4 = D >> 2;
   const float invD = 1.0f / (float)D;
   const float4* w4 = reinterpret_cast<const float4*>(w);
-  float4 aw[LN_MAXC], ab[LN_MAXC];
+  float4 aw[NC], ab[NC];
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; i++) { aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  for (int i = 0; i < NC; i++) { aw[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
   for (int k = 0; k < 16 / LN_WAVES; k++) {
     const int j = blockIdx.x * 16 + wave + LN_WAVES * k;
     if (j >= Np) break;
     const long r = (long)blockIdx.y * Np + j;
     const float4* sr = reinterpret_cast<const float4*>(s + r * D);
     const float4* dr = reinterpret_cast<const float4*>(dy + r * D);
-    float4 v[LN_MAXC], g[LN_MAXC];
+    float4 v[NC], g[NC];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         v[i] = sr[c];
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const floa
     const float mean = wave_sum(sum) * invD;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const floa
     const float rstd = rsqrtf(wave_sum(var) * invD + eps);
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
         const float4 ww = w4[c];
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const floa
     m2 = wave_sum(m2) * invD;
     float4* dsr = reinterpret_cast<float4*>(ds + r * D);
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; i++) {
+    for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4)
         dsr[c] = make_float4(rstd * (g[i].x - m1 - v[i].x * m2), rstd * (g[i].y - m1 - v[i].y * m2),
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void layernorm_bwd_kernel(const floa
   }
   float4* r4 = reinterpret_cast<float4*>(red);
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; i++) {
+  for (int i = 0; i < NC; i++) {
     const int c = lane + 64 * i;
     if (c < D4) {
       r4[(wave * 2 + 0) * D4 + c] = aw[i];
@@ -264,7 +266,11 @@ extern "C" int vbx_layernorm_fwd(const float* s, const float* w, const float* bi
                                  float eps, void* stream) {
   VBX_REQUIRE(s && w && bias && y && rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "vbx_layernorm_fwd: bad args (D %% 4, D <= 2048)");
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, w, bias, resid, y, rows, D, eps);
+#define VBX_LNF(NC_) hipLaunchKernelGGL((layernorm_fwd_kernel<NC_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, s, w, bias, resid, y, rows, D, eps)
+  if (D <= 512) VBX_LNF(2);
+  else if (D <= 1024) VBX_LNF(4);
+  else VBX_LNF(8);
+#undef VBX_LNF
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -273,15 +279,21 @@ extern "C" int vbx_layernorm_bwd(const float* s, const float* w, const float* dy
                                  int B, int Np, int D, float eps, void* stream) {
   VBX_REQUIRE(s && w && dy && ds && part && B > 0 && Np > 0 && D > 0 && D % 4 == 0 && D <= 2048, "vbx_layernorm_bwd: bad args");
   const size_t lds = (size_t)LN_WAVES * 2 * D * sizeof(float);
-  if (lds > 48 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-  }
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(Np, 16), B), dim3(64 * LN_WAVES), lds, (hipStream_t)stream, s, w, dy, ds, part, Np,
-                     D, eps);
+#define VBX_LNB(NC_)                                                                                                          \
+  do {                                                                                                                       \
+    static bool attr = false;                                                                                                \
+    if (lds > 48 * 1024 && !attr) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                                                 \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NC_>), dim3(cdiv(Np, 16), B), dim3(64 * LN_WAVES), lds, (hipStream_t)stream, s, w, dy, \
+                       ds, part, Np, D, eps);                                                                                \
+  } while (0)
+  if (D <= 512) VBX_LNB(2);
+  else if (D <= 1024) VBX_LNB(4);
+  else VBX_LNB(8);
+#undef VBX_LNB
   VBX_LAUNCH_CHECK();
   return 0;
 }
