@@ -984,8 +984,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs j
   if (jb.rowmap == 1) dr = geglu_row_unmap(r, jb.F);
   if (dr < 0 || dr >= jb.dst_rows) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < jb.splits; k++) {
-    const float4 v = *reinterpret_cast<const float4*>(jb.slabs + (long)k * total + i4);
+  const float* sp = jb.slabs + i4;
+  int k = 0;
+  for (; k + 4 <= jb.splits; k += 4) {  // four slabs requested before the first is consumed (same summation order)
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(sp + (long)(k + u) * total);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; k < jb.splits; k++) {
+    const float4 v = *reinterpret_cast<const float4*>(sp + (long)k * total);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   float* o = jb.dst + (long)dr * jb.dst_ld + c;

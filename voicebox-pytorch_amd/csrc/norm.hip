@@ -195,10 +195,26 @@ __global__ __launch_bounds__(256) void reduce_norm_partials_kernel(const float* 
   if (idx < W) {
     if (sum_batch) {
       const long total = (long)B * chunks;
-      for (long c = cl; c < total; c += 4) s += part[c * W + idx];
+      long c = cl;
+      for (; c + 12 < total; c += 16) {  // four records in flight (same summation order)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = part[(c + 4 * u) * W + idx];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s += v[u];
+      }
+      for (; c < total; c += 4) s += part[c * W + idx];
     } else {
       const int b = blockIdx.y;
-      for (int c = cl; c < chunks; c += 4) s += part[((long)b * chunks + c) * W + idx];
+      int c = cl;
+      for (; c + 12 < chunks; c += 16) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = part[((long)b * chunks + c + 4 * u) * W + idx];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s += v[u];
+      }
+      for (; c < chunks; c += 4) s += part[((long)b * chunks + c) * W + idx];
     }
   }
   red[cl][il] = s;

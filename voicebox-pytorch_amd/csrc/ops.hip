@@ -332,7 +332,15 @@ __global__ void conv_wgrad_finalize_kernel(const float* __restrict__ wpart, int 
   const int d = idx >> 6, k = idx & 63;
   if (k >= ks && k != 63) return;
   float s = 0.f;
-  for (int c = 0; c < chunks; c++) s += wpart[((long)c * D + d) * 64 + k];
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {  // four records in flight (same summation order)
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = wpart[((long)(c + u) * D + d) * 64 + k];
+#pragma unroll
+    for (int u = 0; u < 4; u++) s += v[u];
+  }
+  for (; c < chunks; c++) s += wpart[((long)c * D + d) * 64 + k];
   if (k == 63) db[d] = s;
   else dw[(long)d * ks + k] = s;
 }
@@ -726,8 +734,17 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long j = blockIdx.x * 64L + cl;
   float s = 0.f;
-  if (j < cols)
-    for (long i = rl; i < rows; i += 4) s += in[i * ld + j];
+  if (j < cols) {
+    long i = rl;
+    for (; i + 12 < rows; i += 16) {  // four rows in flight (same summation order)
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = in[(i + 4 * u) * ld + j];
+#pragma unroll
+      for (int u = 0; u < 4; u++) s += v[u];
+    }
+    for (; i < rows; i += 4) s += in[i * ld + j];
+  }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && j < cols) {
@@ -866,7 +883,15 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(vbx_mr_jobs jobs) {
   float s = 0.f;
   if (c < jb.cols) {
     const float* p = jb.src + (long)b * jb.src_bstride + c;
-    for (int r = rl; r < jb.rows; r += 16) s += p[(long)r * jb.row_stride];
+    int r = rl;
+    for (; r + 48 < jb.rows; r += 64) {  // four rows requested before the first is consumed (same summation order)
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = p[(long)(r + 16 * u) * jb.row_stride];
+#pragma unroll
+      for (int u = 0; u < 4; u++) s += v[u];
+    }
+    for (; r < jb.rows; r += 16) s += p[(long)r * jb.row_stride];
   }
   red[rl][il] = s;
   __syncthreads();
@@ -887,7 +912,14 @@ __global__ void colsum_stage2(const float* __restrict__ scratch, int C, float* _
   if (rowmap == 1) dc = geglu_row_unmap(c, F);
   if (dc < 0 || dc >= out_len) return;
   float s = 0.f;
-  for (int k = 0; k < CS_SLABS; k++) s += scratch[(long)k * C + c];
+  static_assert(CS_SLABS % 4 == 0, "slab loop is unrolled by four");
+  for (int k = 0; k < CS_SLABS; k += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = scratch[(long)(k + u) * C + c];
+#pragma unroll
+    for (int u = 0; u < 4; u++) s += v[u];
+  }
   out[dc] = s;
 }
 
