@@ -82,12 +82,6 @@ VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-VBX_DEV f16x8 pack_frag_f16(const f32x16& p, int t2) {
-  f16x8 r;
-#pragma unroll
-  for (int s = 0; s < 8; s++) r[s] = (_Float16)p[8 * t2 + s];
-  return r;
-}
 VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
   bf16x8 r;
 #pragma unroll

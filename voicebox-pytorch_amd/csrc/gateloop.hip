@@ -100,7 +100,6 @@ __global__ __launch_bounds__(GL_CH* GL_CHUNKS) void gl_scan_bwd_kernel(const flo
 }
 
 // ------------------------------------------------------------------ post LayerNorm (nn.LayerNorm(D), eps 1e-5) + residual
-constexpr int LN_MAXC = 8;  // float4 chunks per lane -> D <= 2048
 template <int NC>  // float4 chunks per lane actually needed (2: D <= 512, 4: D <= 1024, 8: D <= 2048), see norm.hip
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ resid,

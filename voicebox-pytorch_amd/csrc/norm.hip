@@ -5,7 +5,6 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // float4 chunks per lane -> D <= 2048
 // The row kernels are templated on NC = float4 chunks per lane actually needed (2: D <= 512, 4: D <= 1024, 8: D <= 2048): with
 // the arrays sized for D = 2048 the D = 512 instantiation carried 132 (forward) / 218 (backward) VGPRs -- 3 resp. 2 waves per
 // SIMD for kernels whose only job is to keep HBM requests in flight.
