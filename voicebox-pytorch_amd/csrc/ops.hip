@@ -265,13 +265,13 @@ __global__ __launch_bounds__(256) void convpos_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dpre, float* __restrict__ de,
                                                           u16* __restrict__ deb, float* __restrict__ wpart, int N, int R,
                                                           int D) {
-  extern __shared__ float sm[];  // e tile [rows][64], dpre tile [rows][64], reduce [4][64][64]
+  extern __shared__ float sm[];  // e tile [rows][64] | dpre tile [rows][64]; afterwards the reduction buffer [4][64][33]
   constexpr int ks = KS;
+  static_assert(KS <= 31, "wacc holds the taps in [0, KS) and the bias gradient in [31]");
   const int half = ks / 2;
   const int rows = CT + ks - 1;
   float* te = sm;
   float* tp = sm + rows * 64;
-  float* red = tp + rows * 64;
   const int n0 = blockIdx.x * CT, dbase = blockIdx.y * 64, b = blockIdx.z;
   const int dl = threadIdx.x & 63, ng = threadIdx.x >> 6;
   const int d = dbase + dl;
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void convpos_bwd_kernel(const float* __restric
     tp[r * 64 + dl] = vp;
   }
   __syncthreads();
-  float wr[KS], wacc[64];
+  float wr[KS], wacc[32];
 #pragma unroll
-  for (int k = 0; k < 64; k++) wacc[k] = 0.f;
+  for (int k = 0; k < 32; k++) wacc[k] = 0.f;
   if (d < D) {
 #pragma unroll
     for (int k = 0; k < ks; k++) wr[k] = w[(long)d * ks + k];
@@ -307,19 +307,25 @@ __global__ __launch_bounds__(256) void convpos_bwd_kernel(const float* __restric
       const float dp = tp[(nl + half) * 64 + dl];
 #pragma unroll
       for (int k = 0; k < ks; k++) wacc[k] += dp * te[(nl + k) * 64 + dl];
-      wacc[63] += dp;
+      wacc[31] += dp;
     }
   }
+  // The tiles are dead once every thread has left the loop: their space becomes the cross-group reduction buffer
+  // (48 KiB of LDS per block instead of 112 KiB -> three blocks per CU).  Row pitch 33: conflict-free for the per-tap writes
+  // (lanes = channels) and for the reads below (lanes = taps), which make the partial-record stores 128-byte contiguous
+  // (they were 4-byte stores at a 256-byte stride).  Entries [KS, 62] of a record are never read (conv_wgrad_finalize).
+  __syncthreads();
+  float* red = sm;
 #pragma unroll
-  for (int k = 0; k < 64; k++) red[(ng * 64 + k) * 64 + dl] = wacc[k];
+  for (int k = 0; k < 32; k++) red[(ng * 64 + dl) * 33 + k] = wacc[k];
   __syncthreads();
   const long chunk = (long)b * gridDim.x + blockIdx.x;
-  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-    const int k = idx >> 6, c = idx & 63;
+  for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+    const int c = idx >> 5, k = idx & 31;
     if (dbase + c < D) {
-      const float s = red[(0 * 64 + k) * 64 + c] + red[(1 * 64 + k) * 64 + c] + red[(2 * 64 + k) * 64 + c] +
-                      red[(3 * 64 + k) * 64 + c];
-      wpart[(chunk * D + dbase + c) * 64 + k] = s;
+      const float s = red[(0 * 64 + c) * 33 + k] + red[(1 * 64 + c) * 33 + k] + red[(2 * 64 + c) * 33 + k] +
+                      red[(3 * 64 + c) * 33 + k];
+      wpart[(chunk * D + dbase + c) * 64 + (k == 31 ? 63 : k)] = s;
     }
   }
 }
@@ -1330,7 +1336,7 @@ extern "C" int vbx_convpos_bwd(const float* e, const float* w, const float* bias
   hipLaunchKernelGGL((convpos_fwd_kernel<1, 31>), grid, dim3(256), rows * 64 * sizeof(float), ST, e, w, bias, mask, dxs, dpre_tmp,
                      N, R, D);
   VBX_LAUNCH_CHECK();
-  const size_t lds = (size_t)(2 * rows * 64 + 4 * 64 * 64) * sizeof(float);
+  const size_t lds = (size_t)(2 * rows * 64) * sizeof(float);  // >= the [4][64][33] reduction buffer that reuses it
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_bwd_kernel<31>), hipFuncAttributeMaxDynamicSharedMemorySize,
