@@ -61,6 +61,19 @@ VBX_DEV void tile_r2s(const Stage2& s, char* tile, int tid) {
   }
 }
 
+// Same, with rows at or past row_lim stored as zeros.  The select sits HERE, where the staged registers are consumed anyway:
+// applied at load time (tile_g2r's zero_oob) it reads the loaded value at once, i.e. hipcc waits vmcnt(0) right after issuing
+// the prefetch and the whole global-load latency is exposed in every iteration instead of hiding behind the tile's MFMAs.
+VBX_DEV void tile_r2s_zero_oob(const Stage2& s, char* tile, int row0, int row_lim, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int c = tid + 256 * i;
+    uint4 v = s.v[i];
+    if (row0 + (c >> 3) >= row_lim) v = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(tile + swz_off(c >> 3, c & 7)) = v;
+  }
+}
+
 // K-contiguous fragment: row (lane&31) of the 32-row block, 8 elements at d = 16*t + 8*hi.
 template <class V8>
 VBX_DEV V8 row_frag(const char* tile, int blk32, int t, int lane) {
@@ -980,6 +993,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
   tile_g2r(sk, kbase, 64, 0, Np, false, tid);
   tile_g2r(skb, kbbase, 64, 0, Np, false, tid);
   tile_g2r(sv, vbase, 64, 0, Np, false, tid);
+  // Retire the per-lane fragment loads HERE.  Left alone, hipcc sinks them to just before the loop without a wait; the waits
+  // then land inside the loop body (vmcnt(3..0) in front of the first MFMAs that read dof[]) where, from the second iteration
+  // on, they stall on the NEXT tile's prefetch instead -- one exposed global-load latency per key tile.
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    asm volatile("" ::"v"(qf[t]));
+    asm volatile("" ::"v"(dof[t]));
+  }
+  asm volatile("" ::"v"(L2), "v"(dlt));
   tile_r2s(sk, smem, tid);
   tile_r2s(skb, smem + TILE16, tid);
   tile_r2s(sv, smem + 2 * TILE16, tid);
@@ -1099,11 +1121,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
   };
   tile_g2r(sq, qbase, 64, 0, Np, false, tid);
   tile_g2r(sqb, qbbase, 64, 0, Np, false, tid);
-  tile_g2r(sdo, dobase, H * 64, 0, Np, true, tid);
+  tile_g2r(sdo, dobase, H * 64, 0, Np, false, tid);  // rows past Np are zeroed when the tile is stored (tile_r2s_zero_oob)
   stage_stats(0);
+#pragma unroll
+  for (int t = 0; t < 4; t++) {  // retire the per-lane fragment loads before the loop (see attn_bwd_dq_kernel)
+    asm volatile("" ::"v"(kf[t]));
+    asm volatile("" ::"v"(vf[t]));
+  }
   tile_r2s(sq, smem, tid);
   tile_r2s(sqb, smem + TILE16, tid);
-  tile_r2s(sdo, smem + 2 * TILE16, tid);
+  tile_r2s_zero_oob(sdo, smem + 2 * TILE16, 0, Np, tid);
   if (tid < 128) reinterpret_cast<float*>(smem + 3 * TILE16)[tid] = sl;
   __syncthreads();
 
@@ -1116,7 +1143,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
     if (more) {
       tile_g2r(sq, qbase, 64, (qt + 1) * 64, Np, false, tid);
       tile_g2r(sqb, qbbase, 64, (qt + 1) * 64, Np, false, tid);
-      tile_g2r(sdo, dobase, H * 64, (qt + 1) * 64, Np, true, tid);
+      tile_g2r(sdo, dobase, H * 64, (qt + 1) * 64, Np, false, tid);
       stage_stats(qt + 1);
     }
     if (active) {
@@ -1166,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
       char* Qn = smem + ((qt + 1) & 1) * DKV_BUF;
       tile_r2s(sq, Qn, tid);
       tile_r2s(sqb, Qn + TILE16, tid);
-      tile_r2s(sdo, Qn + 2 * TILE16, tid);
+      tile_r2s_zero_oob(sdo, Qn + 2 * TILE16, (qt + 1) * 64, Np, tid);
       if (tid < 128) reinterpret_cast<float*>(Qn + 3 * TILE16)[tid] = sl;
     }
     __syncthreads();
