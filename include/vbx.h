@@ -84,6 +84,10 @@ typedef struct {
 } vbx_gemm_desc;
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
+/* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch (same kernel body, same results as n vbx_gemm calls): the weight-gradient
+ * GEMMs of a layer are 220-480 workgroups each -- separately they fill a third to two thirds of the chip.  EXPERIMENTAL: used by the
+ * runtime only under VBX_GROUP_WGRAD=1 until it has been measured in situ. */
+int vbx_gemm_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, void* stream);
 /* Sum split-K slabs [splits][M][N] and scatter into dst (fp32): dst[rowmap(i)][j] (+)= sum_s slab.
  * rowmap: 0 identity; 1 GEGLU de-interleave with (F, Fp): packed row p -> ((p%128)<64 ?
  * (p/128)*64+p%128 : F + (p/128)*64 + p%128-64), rows/cols beyond the valid range dropped. */

@@ -7,6 +7,7 @@ kernel's own error: fp32 accumulation order) with rtol 2e-3, and norms/elementwi
 precision (rel 2^-8).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -821,3 +822,32 @@ def test_geglu_bwd_colsum_and_multi_reduce(L):
     exp = torch.cat((cs[:, 0].reshape(-1)[:Fd], cs[:, 1].reshape(-1)[:Fd]))
     assert rel_err(out, exp) < 1e-5
     assert rel_err(out2[:, :64], x[:, :, :64].sum(1)) < 1e-6 and float(out2[:, 64:].abs().max()) == 0.0
+
+
+@pytest.mark.skipif(os.environ.get("VBX_TEST_EXPERIMENTAL") != "1",
+                    reason="vbx_gemm_tn_splitk_grouped is an unmeasured experiment (VBX_GROUP_WGRAD=1); run with VBX_TEST_EXPERIMENTAL=1")
+def test_grouped_splitk_gemm_equals_separate_launches(L):
+    """The four weight-gradient shapes of a dim-512 layer (and ragged ones) through ONE grouped launch: slabs bit-identical to
+    four vbx_gemm calls (same kernel body, same tile / split assignment)."""
+    g = torch.Generator().manual_seed(0)
+    for K, shapes in ((8320, ((3072, 512, 5), (512, 1024, 8), (2816, 512, 5), (512, 1408, 5))),
+                      (1000, ((264, 136, 3), (72, 520, 1), (128, 128, 2)))):
+        descs = (L.GemmDesc * len(shapes))()
+        keep, sep, grp = [], [], []
+        for i, (I, J, S) in enumerate(shapes):
+            Pm = bf(torch.randn(K, I, generator=g)).to(dev)
+            Qm = bf(torch.randn(K, J, generator=g)).to(dev)
+            a = torch.full((S, I, J), float("nan"), device=dev)
+            b = torch.full((S, I, J), float("nan"), device=dev)
+            gemm(L, L.VBX_GEMM_TN, L.VBX_EPI_SPLITK, Pm, Qm, I, J, K, C=a, splits=S)
+            d = descs[i]
+            d.mode, d.epilogue, d.M, d.N, d.K = L.VBX_GEMM_TN, L.VBX_EPI_SPLITK, I, J, K
+            d.A, d.B, d.C, d.lda, d.ldb, d.splits = Pm.data_ptr(), Qm.data_ptr(), b.data_ptr(), I, J, S
+            keep += [Pm, Qm]
+            sep.append(a)
+            grp.append(b)
+        rc = L.lib().vbx_gemm_tn_splitk_grouped(descs, len(shapes), st())
+        assert rc == 0, L.lib().vbx_last_error()
+        torch.cuda.synchronize()
+        for a, b in zip(sep, grp):
+            assert torch.equal(a, b)

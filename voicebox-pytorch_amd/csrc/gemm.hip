@@ -289,156 +289,51 @@ struct FragPlan {
 template <int MA, int MB, class Epi, bool F16, int BM_>
 __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WM = BM_ / 64, NT_ = (WM == 2) ? 4 : 2;
-  constexpr int DMAS = BM_ / 64 + 2;  // LDS-DMA instructions per thread per stage
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * BM_, n0 = tn * BN;
-  const int split = blockIdx.y;
-  const int kbeg = split * p.kchunk;
-  const int kend = min(p.K, kbeg + p.kchunk);
-  const int nt = (kend - kbeg + BK2 - 1) / BK2;
+#define VBX_BX_ blockIdx.x
+#define VBX_T_ gridDim.x
+#define VBX_SPLIT_ blockIdx.y
+#include "gemm_v2_body.inc"
+#undef VBX_BX_
+#undef VBX_T_
+#undef VBX_SPLIT_
+}
 
-  DmaPlan<MA, BM_> da;
-  DmaPlan<MB, 128> db;
-  da.init(p.A, p.lda, m0, p.M, tid);
-  db.init(p.B, p.ldb, n0, p.N, tid);
-  if (p.abl & 24) {  // ablation: operand tiles stored as contiguous 8 KiB k-tile images (what a tiled layout would stream)
-    const int nkt = (p.K + BK2 - 1) / BK2;
-    if (p.abl & 8) {
+// ---- several independent GEMMs of the same kind in ONE grid (first use: the four split-K weight-gradient GEMMs of a layer,
+// which as separate launches of 220-480 workgroups fill 0.29-0.63 of the chip's 768 slots each).  Job j owns the block ids
+// [block0[j], block0[j+1]); inside a job the ids run split-major with T8 = tiles rounded up to a multiple of 8 per split, so that
+// (block id % 8) -- the XCD the dispatcher picks -- equals (tile id % 8) as the XCD-aware tile order of the body assumes; the
+// up to 7 surplus workgroups per split exit at once.
+constexpr int GG_MAX = 4;
+template <class Epi>
+struct GroupedGemm {
+  int n;
+  int block0[GG_MAX + 1];
+  int T[GG_MAX];   // tiles of one split
+  int T8[GG_MAX];  // T rounded up to a multiple of 8
+  GemmParams p[GG_MAX];
+  Epi epi[GG_MAX];
+};
+template <int MA, int MB, class Epi, bool F16, int BM_>
+__global__ __launch_bounds__(256, 3) void gemm_kernel_v2_grouped(GroupedGemm<Epi> g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int j = 0;
 #pragma unroll
-      for (int i = 0; i < DmaPlan<MA, BM_>::N; i++) {
-        da.base[i] = p.A + ((long)tm * nkt * (BM_ * 32)) + (i * 256 + tid) * 8;
-        da.kstride = BM_;  // k0 * kstride = (k0/32) * BM_*32
-        da.ok[i] = true; da.kq[i] = 0;
-      }
-    }
-    if (p.abl & 16) {
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        db.base[i] = p.B + ((long)tn * nkt * 4096) + (i * 256 + tid) * 8;
-        db.kstride = 128;
-        db.ok[i] = true; db.kq[i] = 0;
-      }
-    }
-  }
-  FragPlan<MA> fa;
-  FragPlan<MB> fb;
-  fa.init(smem, wm * 64, lane);
-  fb.init(smem, wn * NT_ * 16, lane);
-
-  f32x4 acc[4][NT_];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < NT_; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NST - 1; s++) {
-    if (s < nt) {
-      da.issue(smem + s * STAGE_BYTES, kbeg + s * BK2, kend, tid);
-      db.issue(smem + s * STAGE_BYTES + OP_BYTES, kbeg + s * BK2, kend, tid);
-    }
-  }
-
-  // one k-tile; STG (the ring slot of tile t) is a compile-time constant so every LDS offset is an immediate
-  auto step = [&](auto stg_c, int t) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + NST - 1) % NST;  // slot of tile t-1 == slot tile t+NST-1 will use
-    // this thread's DMAs of tile t have landed once at most NST-2 younger stages (DMAS instructions each) are pending
-    if (nt - 1 - t >= NST - 2) {
-      if (DMAS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (!(p.abl & 4)) __builtin_amdgcn_s_barrier();  // tile t visible to all waves; everyone is done reading tile t-1
-    if (t + NST - 1 < nt && !(p.abl & 1)) {
-      da.issue(smem + NXT * STAGE_BYTES, kbeg + (t + NST - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * STAGE_BYTES + OP_BYTES, kbeg + (t + NST - 1) * BK2, kend, tid);
-    }
-    bf16x8 af[4], bfr[4];
-    s16x4 alo[4], ahi[4], blo[4], bhi[4];
-    if ((p.abl & 2) && t > 0) {  // ablation: skip the LDS fragment reads (registers keep whatever they hold)
-#pragma unroll
-      for (int s = 0; s < 4; s++) { asm volatile("" : "=v"(af[s])); asm volatile("" : "=v"(bfr[s])); }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < NT_; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-      return;
-    }
-    fa.template read<STG * STAGE_BYTES, 0>(af[0], alo[0], ahi[0]);
-    fa.template read<STG * STAGE_BYTES, 1>(af[1], alo[1], ahi[1]);
-    fa.template read<STG * STAGE_BYTES, 2>(af[2], alo[2], ahi[2]);
-    fa.template read<STG * STAGE_BYTES, 3>(af[3], alo[3], ahi[3]);
-    fb.template read<STG * STAGE_BYTES + OP_BYTES, 0>(bfr[0], blo[0], bhi[0]);
-    fb.template read<STG * STAGE_BYTES + OP_BYTES, 1>(bfr[1], blo[1], bhi[1]);
-    if (NT_ == 4) {
-      fb.template read<STG * STAGE_BYTES + OP_BYTES, 2>(bfr[2], blo[2], bhi[2]);
-      fb.template read<STG * STAGE_BYTES + OP_BYTES, 3>(bfr[3], blo[3], bhi[3]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (MA == 1) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        s16x8 v = {alo[s][0], alo[s][1], alo[s][2], alo[s][3], ahi[s][0], ahi[s][1], ahi[s][2], ahi[s][3]};
-        af[s] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-    if (MB == 1) {
-#pragma unroll
-      for (int s = 0; s < NT_; s++) {
-        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
-        bfr[s] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < NT_; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-  };
-  static_assert(NST == 3, "the k-loop below is unrolled for a 3-slot ring");
-  for (int t = 0; t < nt; t += 3) {
-    step(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-  }
-  // ---- epilogue: the fp32 C tile goes through LDS in 64-row halves (keeps the footprint at 48 KiB)
-  float* Cs = reinterpret_cast<float*>(smem);
-  if (p.abl & 64) {  // ablation: no epilogue at all (keep the accumulators alive)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < NT_; j++) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 123.456f) Cs[tid] = t;
-    return;
-  }
-#pragma unroll
-  for (int h = 0; h < WM; h++) {
-    __syncthreads();  // ring (h = 0) / previous half (h = 1) no longer read
-    if (wm == h) {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < NT_; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int row = i * 16 + (lane >> 4) * 4 + rr;
-            const int col = wn * NT_ * 16 + j * 16 + (lane & 15);
-            Cs[row * CS_LD + col] = acc[i][j][rr];
-          }
-    }
-    __syncthreads();
-    if (!(p.abl & 32)) epi(Cs, m0 + h * 64, n0, tid, split, p.M, p.N, 64);
-  }
+  for (int i = 1; i < GG_MAX; i++)
+    if (i < g.n && (int)blockIdx.x >= g.block0[i]) j = i;
+  const GemmParams p = g.p[j];
+  const Epi epi = g.epi[j];
+  const int glocal = (int)blockIdx.x - g.block0[j];
+  const int gsplit = glocal / g.T8[j];
+  const int gbx = glocal - gsplit * g.T8[j];
+  const int gT = g.T[j];
+  if (gbx >= gT) return;  // padding workgroup (block-uniform)
+#define VBX_BX_ gbx
+#define VBX_T_ gT
+#define VBX_SPLIT_ gsplit
+#include "gemm_v2_body.inc"
+#undef VBX_BX_
+#undef VBX_T_
+#undef VBX_SPLIT_
 }
 
 // ---- 160 x 128 tile, 2x2 waves of 80 x 64, ONE workgroup per CU with a 5-slot ring.  For the N = dim GEMMs (to_out,
@@ -1069,6 +964,45 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   }
   vbx_set_error("vbx_gemm: unsupported mode/epilogue combination (%d,%d)", d->mode, d->epilogue);
   return VBX_EUNSUPPORTED;
+}
+
+extern "C" int vbx_gemm_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, void* stream) {
+  VBX_REQUIRE(descs && n >= 1 && n <= GG_MAX, "vbx_gemm_tn_splitk_grouped: 1..%d jobs", GG_MAX);
+  static const int abl = getenv("VBX_GEMM_ABL") ? atoi(getenv("VBX_GEMM_ABL")) : 0;
+  GroupedGemm<EpiSplitK> g;
+  g.n = n;
+  int blocks = 0;
+  for (int i = 0; i < GG_MAX; i++) {
+    const vbx_gemm_desc* d = descs + (i < n ? i : 0);  // unused slots repeat job 0 (never selected)
+    if (i < n) {
+      VBX_REQUIRE(d->mode == VBX_GEMM_TN && d->epilogue == VBX_EPI_SPLITK, "vbx_gemm_tn_splitk_grouped: job %d is not TN / SPLITK", i);
+      VBX_REQUIRE(d->A && d->B && d->C && d->splits >= 1, "vbx_gemm_tn_splitk_grouped: job %d has a null pointer / no splits", i);
+      VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm_tn_splitk_grouped: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
+      VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->N % 8 == 0 && d->M % 8 == 0,
+                  "vbx_gemm_tn_splitk_grouped: lda, ldb, M, N must be multiples of 8");
+    }
+    GemmParams& p = g.p[i];
+    p.A = (const u16*)d->A; p.B = (const u16*)d->B;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
+    p.kchunk = cdiv(cdiv(d->K, d->splits), BK) * BK;  // as vbx_gemm's VBX_EPI_SPLITK case
+    p.tiles_m = cdiv(d->M, BM);
+    p.abl = abl;
+    g.epi[i] = EpiSplitK{(float*)d->C};
+    g.T[i] = p.tiles_m * cdiv(d->N, BN);
+    g.T8[i] = (g.T[i] + 7) & ~7;
+    g.block0[i] = blocks;
+    if (i < n) blocks += g.T8[i] * d->splits;
+  }
+  g.block0[GG_MAX] = blocks;
+  auto kern = gemm_kernel_v2_grouped<1, 1, EpiSplitK, false, 128>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), GEMM2_LDS, (hipStream_t)stream, g);
+  VBX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, float* dst, int dst_rows, int dst_cols,

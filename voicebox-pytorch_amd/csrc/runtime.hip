@@ -102,6 +102,7 @@ struct Acts {
   float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
+  u16* dxb2 = nullptr;  // VBX_GROUP_WGRAD=1 only: bf16 dx of the attention half, so that FeedForward-out's dx operand survives to the grouped launch
   float* gl_ds;
   size_t slab_floats;
   size_t bytes;
@@ -112,6 +113,17 @@ struct Acts {
 // share the CU's L2->LDS stream -- a lone workgroup reaches ~60 % of the rate three reach together, two ~85 %; each k-step of 32
 // costs ~0.27 us per resident workgroup at full rate; the fp32 slabs cost a write + a read of s*I*J*4 bytes at ~4 TB/s.
 // VBX_WGRAD_TARGET=<workgroups> restores the plain "about that many workgroups" rule (A/B).
+// EXPERIMENTAL (off by default, not yet measured): the four weight-gradient GEMMs of a layer as ONE grouped launch at the end of
+// the layer's backward (vbx_gemm_tn_splitk_grouped) instead of four launches of 220-480 workgroups interleaved with the dgrads.
+bool group_wgrad() {
+  static const bool on = getenv("VBX_GROUP_WGRAD") && atoi(getenv("VBX_GROUP_WGRAD")) == 1;
+  return on;
+}
+struct WgradGroup {
+  vbx_gemm_desc d[4];
+  int n = 0;
+};
+
 int wgrad_splits(long I, long J, long K) {
   const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
   const long smax = (K + 511) / 512;
@@ -239,6 +251,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.gl_ds = m->gateloop ? c.take<float>((size_t)d.M * d.D) : nullptr;
     a.gl_dp = m->gateloop ? c.take<u16>((size_t)d.M * 3 * d.D) : nullptr;
     a.demb = d.E ? c.take<u16>((size_t)d.M0 * d.E) : nullptr;
+    a.dxb2 = group_wgrad() ? c.take<u16>((size_t)d.M * d.D) : nullptr;
   }
   a.bytes = al256(c.off);
 }
@@ -341,11 +354,18 @@ int wgrad_join(hipStream_t st) {
 }
 // dW[I,J] = P[K,I]^T . Q[K,J]  -> grads (fp32, reference layout [dst_rows, dst_cols])
 int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, float* slabs, float* dst, int dst_rows,
-          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr) {
+          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr, WgradGroup* grp = nullptr) {
   vbx_gemm_desc g{};
   const int splits = wgrad_splits(I, J, K);
   g.mode = VBX_GEMM_TN; g.epilogue = VBX_EPI_SPLITK; g.M = I; g.N = J; g.K = (int)K; g.lda = ldp; g.ldb = ldq;
   g.A = P; g.B = Q; g.C = slabs; g.splits = splits;
+  if (grp && defer && J % 4 == 0 && defer->n < VBX_SKR_MAX && grp->n < 4) {  // GEMM and reduction both deferred to the layer's end
+    grp->d[grp->n++] = g;
+    vbx_skr_job& jb = defer->job[defer->n++];
+    jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
+    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F;
+    return 0;
+  }
   SideStream& ss = side_stream();
   hipStream_t run = st;
   if (ss.ok) {
@@ -585,10 +605,13 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   static const bool batch_wg = !(getenv("VBX_BATCH_WGRAD") && atoi(getenv("VBX_BATCH_WGRAD")) == 0) && !side_stream().ok;
   vbx_skr_jobs wj{};
   vbx_skr_jobs* wjp = batch_wg ? &wj : nullptr;
+  WgradGroup wgg;
+  WgradGroup* wgp = (batch_wg && group_wgrad() && a.dxb2) ? &wgg : nullptr;
+  u16* dxb_attn = wgp ? a.dxb2 : a.dxb;  // bf16 dx entering the attention half (see Acts::dxb2)
   const size_t sfl = a.slab_floats;
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
-  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp));
+  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp));
   if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
     CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
   } else {
@@ -596,24 +619,24 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   }
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
-  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp));
+  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
-    CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, dxb_attn, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D, stream));
     if (!batched) {
       CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
       CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N2G], d.D, 0, stream));
     }
   } else {
-    CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
+    CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, dxb_attn, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
                        stream));
     if (!batched) CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
   }
   if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
-  CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
-  CK(wgrad(a.dxb, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp));
+  CK(gemm_nn_bf16(dxb_attn, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
+  CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
@@ -637,7 +660,8 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
-  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp));
+  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp));
+  if (wgg.n) CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream));  // every operand is still live here (a.dxb: see dxb_attn)
   if (wj.n) CK(vbx_splitk_reduce_multi(&wj, stream));
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
