@@ -36,9 +36,9 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(HERE, "lib", s.replace(".hip", ".o"))
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "common.hpp")),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "vbx.h"))):
+        shared = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]  # headers / included bodies
+        shared.append(os.path.join(HERE, "..", "include", "vbx.h"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(src)] + [os.path.getmtime(f) for f in shared]):
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src, "-o", obj]
         if verbose:
