@@ -128,6 +128,9 @@ int wgrad_splits(long I, long J, long K) {
   const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
   const long smax = (K + 511) / 512;
   static const long target = getenv("VBX_WGRAD_TARGET") ? atol(getenv("VBX_WGRAD_TARGET")) : 0;
+  static const long fixed = getenv("VBX_WGRAD_SPLITS") ? atol(getenv("VBX_WGRAD_SPLITS")) : 0;  // A/B: the same split count for every
+  if (fixed > 0) return (int)(fixed > smax ? smax : (fixed > 16 ? 16 : fixed));                  // weight gradient (with VBX_GROUP_WGRAD=1
+                                                                                                 // occupancy no longer needs many splits)
   if (target > 0) {
     long s = (target + tiles - 1) / tiles;
     if (s > smax) s = smax;
