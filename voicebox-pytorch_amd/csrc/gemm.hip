@@ -590,18 +590,44 @@ VBX_DEV uint4 pack8_f16(const float v[8]) {
 }
 
 // ------------------------------------------------------------------------------- epilogues
+// Make the loads that produced v[] complete HERE (an empty asm that reads the registers).  The row passes below sit behind
+// `if (gr < M)` guards, so hipcc cannot know whether an earlier pass already waited for these registers and would wait again in
+// every pass -- with vmcnt(0), which also drains the previous pass's stores.
+VBX_DEV void retire8(const float (&v)[8]) {
+  asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+VBX_DEV void retire4(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+// v[0..7] = p[0..7] (p 16-byte aligned) or zeros
+VBX_DEV void gload8(const float* p, bool ok, float v[8]) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (ok) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// All epilogues load what does not depend on the row (bias, qk-norm gamma) ONCE per call and request the row-dependent operands
+// (residual) of several passes before the first is consumed: written naively, every pass of the row loop is a global load ->
+// s_waitcnt vmcnt(0) -> use chain (hipcc does not hoist loads out of the `if (gr < M)` guard), i.e. 4-12 exposed L2 round trips
+// per tile -- the GEGLU functor alone cost 14 of the FeedForward-in GEMM's 46 us.
 struct EpiBF16 {
   u16* C; long ldc; const float* bias;
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
+    const int cc = tid & 15;
+    const int gc = n0 + cc * 8;
+    float bv[8];
+    gload8(bias ? bias + gc : nullptr, bias && gc < N, bv);
+    retire8(bv);
     for (int it = 0; it < rows / 16; it++) {
-      const int row = it * 16 + (tid >> 4), cc = tid & 15;
-      const int gr = m0 + row, gc = n0 + cc * 8;
+      const int row = it * 16 + (tid >> 4);
+      const int gr = m0 + row;
       if (gr < M && gc < N) {
         float v[8];
         load8(Cs, row, cc, v);
         if (bias) {
 #pragma unroll
-          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
+          for (int i = 0; i < 8; i++) v[i] += bv[i];
         }
         *reinterpret_cast<uint4*>(C + (long)gr * ldc + gc) = pack8_bf16(v);
       }
@@ -612,25 +638,52 @@ struct EpiBF16 {
 struct EpiF32 {
   float* C; long ldc; const float* bias; const float* resid; u16* C2;
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
-    for (int it = 0; it < rows / 16; it++) {
-      const int row = it * 16 + (tid >> 4), cc = tid & 15;
-      const int gr = m0 + row, gc = n0 + cc * 8;
-      if (gr < M && gc < N) {
-        float v[8];
-        load8(Cs, row, cc, v);
-        const long o = (long)gr * ldc + gc;
-        if (bias) {
+    const int cc = tid & 15;
+    const int gc = n0 + cc * 8;
+    const bool colok = gc < N;
+    float bv[8];
+    gload8(bias ? bias + gc : nullptr, bias && colok, bv);
+    const int nit = rows / 16;
+    for (int it0 = 0; it0 < nit; it0 += 4) {  // up to four passes share one round of residual loads
+      float4 ra[4], rb[4];
 #pragma unroll
-          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
+      for (int u = 0; u < 4; u++) {
+        const int gr = m0 + (it0 + u) * 16 + (tid >> 4);
+        if (resid && it0 + u < nit && gr < M && colok) {
+          const long o = (long)gr * ldc + gc;
+          ra[u] = *reinterpret_cast<const float4*>(resid + o);
+          rb[u] = *reinterpret_cast<const float4*>(resid + o + 4);
+        } else {
+          ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (resid) {
-          const float4 a = *reinterpret_cast<const float4*>(resid + o);
-          const float4 b = *reinterpret_cast<const float4*>(resid + o + 4);
-          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+      retire8(bv);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        retire4(ra[u]);
+        retire4(rb[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int row = (it0 + u) * 16 + (tid >> 4);
+        const int gr = m0 + row;
+        if (it0 + u < nit && gr < M && colok) {
+          float v[8];
+          load8(Cs, row, cc, v);
+          const long o = (long)gr * ldc + gc;
+          if (bias) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] += bv[i];
+          }
+          if (resid) {
+            v[0] += ra[u].x; v[1] += ra[u].y; v[2] += ra[u].z; v[3] += ra[u].w;
+            v[4] += rb[u].x; v[5] += rb[u].y; v[6] += rb[u].z; v[7] += rb[u].w;
+          }
+          *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          if (C2) *reinterpret_cast<uint4*>(C2 + o) = pack8_bf16(v);
         }
-        *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        if (C2) *reinterpret_cast<uint4*>(C2 + o) = pack8_bf16(v);
       }
     }
   }
@@ -658,8 +711,18 @@ struct EpiSplitK {
 struct EpiGEGLU {
   u16* G; long ldg; const float* bias; u16* H1; long ldh; u16* Gb; int g_f16;
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
+    const int cc = tid & 7;          // G part: 8 threads per row (8 "x" columns and their 8 "gate" columns each)
+    const int ch = tid & 15;         // H1 part: 16 threads per row
+    const int gch = n0 + ch * 8;
+    float bx[8], bg[8], bh[8];       // N is a multiple of 128 here: n0 + 127 < N
+    gload8(bias + n0 + cc * 8, true, bx);
+    gload8(bias + n0 + 64 + cc * 8, true, bg);
+    gload8(bias + gch, H1 != nullptr, bh);
+    retire8(bx);
+    retire8(bg);
+    retire8(bh);
     for (int it = 0; it < rows / 32; it++) {
-      const int row = it * 32 + (tid >> 3), cc = tid & 7;
+      const int row = it * 32 + (tid >> 3);
       const int gr = m0 + row;
       if (gr < M) {
         float x[8], g[8], o[8];
@@ -667,8 +730,8 @@ struct EpiGEGLU {
         load8(Cs, row, cc + 8, g);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          const float xv = x[i] + bias[n0 + cc * 8 + i];
-          const float gv = g[i] + bias[n0 + 64 + cc * 8 + i];
+          const float xv = x[i] + bx[i];
+          const float gv = g[i] + bg[i];
           o[i] = gelu_erf(gv) * xv;
         }
         const long go = (long)gr * ldg + (n0 >> 1) + cc * 8;
@@ -678,14 +741,14 @@ struct EpiGEGLU {
     }
     if (H1) {
       for (int it = 0; it < rows / 16; it++) {
-        const int row = it * 16 + (tid >> 4), cc = tid & 15;
-        const int gr = m0 + row, gc = n0 + cc * 8;
+        const int row = it * 16 + (tid >> 4);
+        const int gr = m0 + row;
         if (gr < M) {
           float v[8];
-          load8(Cs, row, cc, v);
+          load8(Cs, row, ch, v);
 #pragma unroll
-          for (int i = 0; i < 8; i++) v[i] += bias[gc + i];
-          *reinterpret_cast<uint4*>(H1 + (long)gr * ldh + gc) = pack8_bf16(v);
+          for (int i = 0; i < 8; i++) v[i] += bh[i];
+          *reinterpret_cast<uint4*>(H1 + (long)gr * ldh + gch) = pack8_bf16(v);
         }
       }
     }
