@@ -729,8 +729,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
 #undef VBX_V3_ROLE_HOOK
 }
 
+#ifdef VBX_EXPERIMENTAL_V3R
 // ============================================================================ forward, v3r: v3 + a role for the ragged tile
-// EXPERIMENTAL (VBX_ATTN_RAGGED=1; written after the round's GPU time was used up -- not yet run).  With Np = 1040 every head
+// EXPERIMENTAL: compiled only with -DVBX_EXPERIMENTAL_V3R (VBX_BUILD_EXPERIMENTAL=1 python build.py) and used only under
+// VBX_ATTN_RAGGED=1; written after the round's GPU time was used up -- not yet run.  (Kept out of the default library because the
+// role is a real function call, the only one in the code object.)  With Np = 1040 every head
 // has a ninth query tile holding only the 16 register tokens.  In v3 that workgroup walks all 17 key tiles behind the shared
 // ring with one active wave: its lifetime is the 17-step DMA -> barrier -> compute chain, and because the 128 such workgroups do
 // not fit the 1024 slots they run as a second round (~15 of the kernel's 64 us).  Here such a workgroup takes another role: the
@@ -957,6 +960,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3r(const u16* __restr
 #include "attn_fwd_v3_body.inc"
 #undef VBX_V3_ROLE_HOOK
 }
+#endif  // VBX_EXPERIMENTAL_V3R
 
 // ============================================================================ backward: delta
 // delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d]
@@ -1279,11 +1283,15 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
   if (v3 && !legacy && !abl && !abl2) {
+#ifdef VBX_EXPERIMENTAL_V3R
     static const bool ragged = getenv("VBX_ATTN_RAGGED") && atoi(getenv("VBX_ATTN_RAGGED")) == 1;  // EXPERIMENTAL, see v3r
-    if (ragged)
+    if (ragged) {
       hipLaunchKernelGGL(attn_fwd_kernel_v3r, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                          (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
-    else
+      VBX_LAUNCH_CHECK();
+      return 0;
+    }
+#endif
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
     VBX_LAUNCH_CHECK();
