@@ -84,6 +84,10 @@ typedef struct {
 } vbx_gemm_desc;
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
+/* Tuning knob (results are identical up to fp32 summation order): which tile serves vbx_gemm / the grouped launch.
+ * 0 automatic per shape (default; environment VBX_GEMM3=0/1/2 presets 1 / 0 / 2), 1 the 128-wide kernels only,
+ * 2 the 256 x 256 8-wave kernel wherever it can serve.  Not thread safe; call before launching work. */
+int vbx_gemm_select(int path);
 /* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch (same kernel body, same results as n vbx_gemm calls): the weight-gradient
  * GEMMs of a layer are 220-480 workgroups each -- separately they fill a third to two thirds of the chip.  EXPERIMENTAL: used by the
  * runtime only under VBX_GROUP_WGRAD=1 until it has been measured in situ. */

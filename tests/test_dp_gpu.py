@@ -175,3 +175,52 @@ def test_trainer_accumulation_and_reference_checkpoint_format(tmp_path, golden):
     for (k, a), (_, b) in zip(vb2.state_dict().items(), vb.state_dict().items()):
         assert torch.equal(a, b), k
     tr2.train_step()
+
+
+def _nccl_world1_worker(port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["VBX_FORCE_DIST"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))  # nccl == RCCL on ROCm
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+    from oracle import restate
+
+    cfg = restate.Cfg(dim=128, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=5)
+    res = {}
+    for forced in ("1", "0"):
+        os.environ["VBX_FORCE_DIST"] = forced
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(state, strict=False)
+        wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to("cuda:0"))
+        ts = TrainStep(wrapper, lr=1e-3, max_grad_norm=0.5, bucket_bytes=1 << 16)
+        d = _draws(100, 2, 72, 128)
+        launched = 0
+        for _ in range(3):
+            with rng_override(**{k: v for k, v in d.items() if k != "x1"}):
+                loss = ts.step(d["x1"].cuda())
+        torch.cuda.synchronize()
+        res[forced] = dict(loss=float(loss), flat=ts.fp.flat.detach().cpu().clone(), g=ts.gflat.detach().cpu().clone(),
+                           exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None)
+    dist.destroy_process_group()
+    torch.save(res, out)
+
+
+def test_rccl_path_executes_at_world_size_1(tmp_path):
+    """The RCCL code path of dp.TrainStep (init_process_group('nccl'), bucketed async all-reduce on the comm stream, work.wait(),
+    clip + Adam) on the ONE GPU of the test box: VBX_FORCE_DIST=1 issues the collectives at world size 1, where an all-reduce is
+    the identity -- three steps must give bit-identical parameters to the same steps without any collective."""
+    out = str(tmp_path / "nccl1.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    res = torch.load(out)
+    assert res["1"]["exchange"] and res["1"]["comm_stream"] and not res["0"]["exchange"]
+    assert res["1"]["loss"] == res["0"]["loss"]
+    assert torch.equal(res["1"]["g"], res["0"]["g"]) and torch.equal(res["1"]["flat"], res["0"]["flat"])

@@ -238,3 +238,15 @@ def test_duration_predictor_host_logic(golden):
     with pytest.raises(AssertionError):
         vbx.ConditionalFlowMatcherWrapper(voicebox=vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2,
                                                                 condition_on_text=False), duration_predictor=dp)
+
+
+def test_gemm3_lds_layout_emulation(tmp_path):
+    """csrc/gemm3_layout.hpp (LDS-DMA source permutation, fragment read addresses, transposed-accumulator column map of the
+    256 x 256 GEMM tile) replayed on the host against a plain GEMM, plus bank-conflict freedom of every fragment read."""
+    import subprocess
+
+    exe = str(tmp_path / "gemm3_layout_check")
+    src = os.path.join(ROOT, "tests", "native", "gemm3_layout_check.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:]

@@ -967,12 +967,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs j
 
 }  // namespace
 
+static int g_gemm_path = -1;
+int vbx_gemm_path() {
+  if (g_gemm_path < 0) {
+    const char* e = getenv("VBX_GEMM3");
+    g_gemm_path = e ? (atoi(e) == 0 ? 1 : (atoi(e) >= 2 ? 2 : 0)) : 0;
+  }
+  return g_gemm_path;
+}
+extern "C" int vbx_gemm_select(int path) {
+  VBX_REQUIRE(path >= 0 && path <= 2, "vbx_gemm_select: 0 automatic, 1 128-wide kernels only, 2 256-wide kernel wherever it serves");
+  g_gemm_path = path;
+  return 0;
+}
+// automatic choice: the 256 x 256 tile (one workgroup per CU) needs enough tiles to cover the chip; the N = dim GEMMs of the
+// model (M = 8320, N = 512: 66 tiles) stay on the 160 x 128 one-round kernels.
+static bool gemm3_wanted(const vbx_gemm_desc* d) {
+  const int path = vbx_gemm_path();
+  if (path == 1) return false;
+  if (path == 2) return true;
+  if (d->epilogue == VBX_EPI_SPLITK) return false;  // the caller picks split counts per tile shape (runtime.hip: grouped launch)
+  const long tiles = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
+  return tiles >= 120 && d->K >= 128;
+}
+
 extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   VBX_REQUIRE(d && d->A && d->B, "vbx_gemm: null operand");
   VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
   VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "vbx_gemm: leading dims must be multiples of 8 (16-byte rows)");
   VBX_REQUIRE(d->N % 8 == 0, "vbx_gemm: N must be a multiple of 8");
+  if (gemm3_wanted(d)) {
+    const int rc = vbx_gemm3(d, st);
+    if (rc != VBX_EUNSUPPORTED) return rc;
+  }
   GemmParams p;
   p.A = (const u16*)d->A; p.B = (const u16*)d->B;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
@@ -1031,6 +1059,10 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
 
 extern "C" int vbx_gemm_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, void* stream) {
   VBX_REQUIRE(descs && n >= 1 && n <= GG_MAX, "vbx_gemm_tn_splitk_grouped: 1..%d jobs", GG_MAX);
+  if (vbx_gemm_path() != 1) {
+    const int rc = vbx_gemm3_tn_splitk_grouped(descs, n, (hipStream_t)stream);
+    if (rc != VBX_EUNSUPPORTED) return rc;
+  }
   static const int abl = getenv("VBX_GEMM_ABL") ? atoi(getenv("VBX_GEMM_ABL")) : 0;
   GroupedGemm<EpiSplitK> g;
   g.n = n;

@@ -102,7 +102,7 @@ struct Acts {
   float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
-  u16* dxb2 = nullptr;  // VBX_GROUP_WGRAD=1 only: bf16 dx of the attention half, so that FeedForward-out's dx operand survives to the grouped launch
+  u16* dxb2 = nullptr;  // bf16 dx of the attention half, so that FeedForward-out's dx operand survives to the layer's grouped wgrad launch
   float* gl_ds;
   size_t slab_floats;
   size_t bytes;
@@ -113,16 +113,32 @@ struct Acts {
 // share the CU's L2->LDS stream -- a lone workgroup reaches ~60 % of the rate three reach together, two ~85 %; each k-step of 32
 // costs ~0.27 us per resident workgroup at full rate; the fp32 slabs cost a write + a read of s*I*J*4 bytes at ~4 TB/s.
 // VBX_WGRAD_TARGET=<workgroups> restores the plain "about that many workgroups" rule (A/B).
-// EXPERIMENTAL (off by default, not yet measured): the four weight-gradient GEMMs of a layer as ONE grouped launch at the end of
-// the layer's backward (vbx_gemm_tn_splitk_grouped) instead of four launches of 220-480 workgroups interleaved with the dgrads.
+// The four weight-gradient GEMMs of a layer run as ONE grouped launch at the end of the layer's backward
+// (vbx_gemm_tn_splitk_grouped; by default on the 256 x 256 tile of gemm3.hip) instead of four launches interleaved with the dgrads:
+// separately they are 8-24 tiles each.  VBX_GROUP_WGRAD=0 restores the separate launches (A/B); with VBX_GEMM3=0 the default is off.
 bool group_wgrad() {
-  static const bool on = getenv("VBX_GROUP_WGRAD") && atoi(getenv("VBX_GROUP_WGRAD")) == 1;
-  return on;
+  static const char* e = getenv("VBX_GROUP_WGRAD");
+  if (e) return atoi(e) == 1;
+  return vbx_gemm_path() != 1;
 }
 struct WgradGroup {
   vbx_gemm_desc d[4];
   int n = 0;
 };
+
+// K splits of the grouped launch on 256 x 256 tiles: every job gets the same count, chosen so that the layer's tiles x splits
+// fill the 256 CUs once (dim 512: 24 + 8 + 22 + 12 = 66 tiles -> 3 splits = 198 workgroups of ~44 k-tiles).
+int wgrad_splits3(const Dims& d) {
+  static const long fixed = getenv("VBX_WGRAD_SPLITS3") ? atol(getenv("VBX_WGRAD_SPLITS3")) : 0;
+  auto t = [](long I, long J) { return ((I + 255) / 256) * ((J + 255) / 256); };
+  const long tiles = t(3 * d.I, d.D) + t(d.D, d.I) + t(2 * d.Fp, d.D) + t(d.D, d.Fp);
+  long s = fixed > 0 ? fixed : 256 / tiles;
+  const long smax = (d.M + 1023) / 1024;  // at least 16 k-tiles per workgroup
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
 
 int wgrad_splits(long I, long J, long K) {
   const long tiles = ((I + 127) / 128) * ((J + 127) / 128);
@@ -222,8 +238,10 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.dk = c.take<float>(hs);
     a.delta = c.take<float>((size_t)d.B * d.H * d.Np);
     size_t sf = 0;
-    auto upd = [&](long I, long J, long K) {
-      const size_t n = (size_t)wgrad_splits(I, J, K) * I * J;
+    const int s3 = wgrad_splits3(d);
+    auto upd = [&](long I, long J, long K) {  // either split scheme may be selected at run time (vbx_gemm_select): size for both
+      const int s1 = wgrad_splits(I, J, K);
+      const size_t n = (size_t)(s1 > s3 ? s1 : s3) * I * J;
       if (n > sf) sf = n;
     };
     upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
@@ -254,7 +272,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.gl_ds = m->gateloop ? c.take<float>((size_t)d.M * d.D) : nullptr;
     a.gl_dp = m->gateloop ? c.take<u16>((size_t)d.M * 3 * d.D) : nullptr;
     a.demb = d.E ? c.take<u16>((size_t)d.M0 * d.E) : nullptr;
-    a.dxb2 = group_wgrad() ? c.take<u16>((size_t)d.M * d.D) : nullptr;
+    a.dxb2 = c.take<u16>((size_t)d.M * d.D);  // always carved: the arena layout must not depend on run-time tuning knobs
   }
   a.bytes = al256(c.off);
 }
@@ -357,12 +375,13 @@ int wgrad_join(hipStream_t st) {
 }
 // dW[I,J] = P[K,I]^T . Q[K,J]  -> grads (fp32, reference layout [dst_rows, dst_cols])
 int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, float* slabs, float* dst, int dst_rows,
-          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr, WgradGroup* grp = nullptr) {
+          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr, WgradGroup* grp = nullptr, int group_splits = 0) {
   vbx_gemm_desc g{};
-  const int splits = wgrad_splits(I, J, K);
+  const bool grouped = grp && defer && J % 4 == 0 && defer->n < VBX_SKR_MAX && grp->n < 4;
+  const int splits = (grouped && group_splits > 0) ? group_splits : wgrad_splits(I, J, K);
   g.mode = VBX_GEMM_TN; g.epilogue = VBX_EPI_SPLITK; g.M = I; g.N = J; g.K = (int)K; g.lda = ldp; g.ldb = ldq;
   g.A = P; g.B = Q; g.C = slabs; g.splits = splits;
-  if (grp && defer && J % 4 == 0 && defer->n < VBX_SKR_MAX && grp->n < 4) {  // GEMM and reduction both deferred to the layer's end
+  if (grouped) {  // GEMM and reduction both deferred to the layer's end
     grp->d[grp->n++] = g;
     vbx_skr_job& jb = defer->job[defer->n++];
     jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
@@ -610,11 +629,12 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   vbx_skr_jobs* wjp = batch_wg ? &wj : nullptr;
   WgradGroup wgg;
   WgradGroup* wgp = (batch_wg && group_wgrad() && a.dxb2) ? &wgg : nullptr;
+  const int gs = (wgp && vbx_gemm_path() != 1) ? wgrad_splits3(d) : 0;  // split count of the grouped 256-tile launch
   u16* dxb_attn = wgp ? a.dxb2 : a.dxb;  // bf16 dx entering the attention half (see Acts::dxb2)
   const size_t sfl = a.slab_floats;
   // ---- FeedForward
   CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
-  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp));
+  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp, gs));
   if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
     CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
   } else {
@@ -622,7 +642,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   }
   CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
-  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp));
+  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp, gs));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
@@ -639,7 +659,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   CK(gemm_nn_bf16(dxb_attn, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
-  CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp));
+  CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp, gs));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
@@ -663,7 +683,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   }
   CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
-  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp));
+  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp, gs));
   if (wgg.n) CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream));  // every operand is still live here (a.dxb: see dxb_attn)
   if (wj.n) CK(vbx_splitk_reduce_multi(&wj, stream));
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites

@@ -15,6 +15,10 @@ from . import _lib
 from .masks import mask_from_frac_lengths, take_draw
 
 
+def force_dist():
+    return os.environ.get("VBX_FORCE_DIST") == "1"
+
+
 class GradBucketReducer:
     """All-reduce(sum) of a flat gradient buffer in contiguous buckets as backward stages complete.
     Device-agnostic (gloo on CPU in tests, RCCL on GPUs).  xGMI is point-to-point (ring all-reduce is per-link
@@ -26,6 +30,9 @@ class GradBucketReducer:
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.staged = []
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # VBX_FORCE_DIST=1: issue the collectives even at world size 1 (exercises the RCCL path -- comm stream, async work,
+        # record_stream -- on a single GPU; an all-reduce over one rank is the identity)
+        self.active = self.world > 1 or (force_dist() and dist.is_available() and dist.is_initialized())
         self.comm_stream = comm_stream
         self.pending_lo = None
         self.pending_hi = None
@@ -36,7 +43,7 @@ class GradBucketReducer:
         if hi <= lo:
             return
         self.buckets_launched.append((lo, hi))
-        if self.world == 1:
+        if not self.active:
             return
         view = self.g[lo:hi]
         if self.comm_stream is not None:
@@ -135,13 +142,17 @@ class TrainStep:
         self.coef = torch.zeros(2, device=dev)
         self.scratch = torch.zeros(1024, device=dev)
         self.steps = 0
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        self.exchange = self.world > 1 or (force_dist() and self.distributed)
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and dev.type == "cuda") else None
         self.bucket_bytes = bucket_bytes
 
     def _dirty(self, keep=None):
-        for eng in self.vb._engines.values():
-            if eng is not keep:
-                eng.packed_version = None
+        """The flat parameter buffer was written behind PyTorch's version counters (native Adam, broadcast): bump the weights
+        epoch, which EVERY engine compares in bind_params -- including engines evicted from `vb._engines` that a cached
+        MidpointSampler still holds.  `keep` had its packed copies refreshed in the same pass."""
+        self.fp.bump()
+        if keep is not None:
+            keep.packed_version = self.fp.weights_key()
 
     # -- gradient accumulation with a deferred exchange (VoiceBoxTrainer.train_step, trainer.py:258-272: every micro-batch but
     #    the last runs under accelerator.no_sync, the loss is divided by grad_accum_every)
@@ -164,7 +175,7 @@ class TrainStep:
         self.gflat.copy_(self.gacc)
         self.gacc.zero_()
         self.acc_pending = False
-        if self.world > 1:
+        if self.exchange:
             red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
                                     comm_stream=self.comm_stream)
             for i, rng in enumerate(self.fp.stage_ranges):
@@ -178,6 +189,8 @@ class TrainStep:
         st = _lib.current_stream
         x1 = x1.to(dev, torch.float32).contiguous()
         B, N, _ = x1.shape
+        if mask is not None:
+            mask = mask.to(dev)  # a DataLoader hands over CPU masks; the kernels take device pointers only
         # --- ConditionalFlowMatcherWrapper.forward, same RNG draw order (voicebox_pytorch.py:1399,1403,1025,146)
         x0 = take_draw("x0")
         x0 = torch.randn_like(x1) if x0 is None else x0.to(dev, torch.float32)
@@ -190,7 +203,6 @@ class TrainStep:
         if frac is None:
             frac = torch.zeros((B,), device=dev).float().uniform_(*vb.frac_lengths_mask)
         cond_mask = mask_from_frac_lengths(N, frac.to(dev))
-        loss_mask = cond_mask if mask is None else (cond_mask & mask.to(dev))
         text = None
         if vb.condition_on_text:  # cond_drop_prob draw comes after the span-mask draws (voicebox_pytorch.py:1025,1040-1041)
             from .masks import prob_mask_like
@@ -200,7 +212,13 @@ class TrainStep:
             if w.cond_drop_prob > 0.:
                 drop = take_draw("cond_drop")
                 drop = prob_mask_like((B,), w.cond_drop_prob, dev) if drop is None else drop.to(dev)
-            text = (cond_token_ids.to(dev), vb.null_cond_id, drop, vb.null_cond)
+            ids = cond_token_ids.to(dev)
+            if mask is not None and ids.shape[-1] != N and mask.shape[-1] != N:
+                # voicebox_pytorch.py:1064-1066: the key-padding mask follows the token ids to frame resolution
+                m4 = mask.float()[:, None, :, None]
+                mask = torch.nn.functional.interpolate(m4, (N, 1), mode="bilinear")[:, 0, :, 0].to(torch.bool)
+            text = (ids, vb.null_cond_id, drop, vb.null_cond)
+        loss_mask = cond_mask if mask is None else (cond_mask & mask)  # reduce_masks_with_and (:1099)
         eng = vb.engine(B, N, training=True)
         loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
         eng.backward(self.gflat, gscale=None, on_stage=on_stage)
@@ -219,8 +237,7 @@ class TrainStep:
         # Adam + refresh of the training engine's fp16/bf16 operand copies in one pass (other engines repack lazily)
         if os.environ.get("VBX_FUSED_ADAM", "1") != "0":
             eng.adam_step_packed(self.gflat, self.m, self.v, float(lr if lr is not None else self.lr), self.betas[0], self.betas[1],
-                                 self.eps, self.steps, self.coef)
-            self._dirty(keep=eng)
+                                 self.eps, self.steps, self.coef)  # bumps the weights epoch; `eng` itself stays current
         else:  # A/B: plain Adam, the next forward repacks every weight
             self._dirty()
             _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
@@ -232,7 +249,7 @@ class TrainStep:
         # --- backward with overlapped gradient exchange
         red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
                                 comm_stream=self.comm_stream, comm_dtype=self.grad_comm_dtype)
-        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.world > 1 else None)
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None)
         red.finish()
         self._clip_adam(self._last_eng, lr)
         return loss

@@ -158,4 +158,4 @@ class DurationPredictor(nn.Module):
                       batch * n, D, st)  # :833
         if not return_aligned_phoneme_ids:
             return durations
-        return durations, self.align_phoneme_ids_with_durations(ids, durations)
+        return durations, self.align_phoneme_ids_with_durations(ids.clamp(min=0), durations)  # ids clamped as :811 does before :839

@@ -101,6 +101,11 @@ class FlatParams:
             off = (off + 63) // 64 * 64  # keep every slot 256-byte aligned (16-byte vector loads need 4)
         self.numel = off
         self.flat = None
+        # weights epoch: bumped by every writer that goes around PyTorch's version counters (the native Adam writes the flat
+        # buffer through a raw pointer) and by every re-flatten; flat_gen counts re-flattens only (a captured hipGraph has the
+        # old buffer's addresses baked in and must be dropped when it changes).
+        self.epoch = 0
+        self.flat_gen = 0
         # stage boundaries (in floats) for bucketed gradient exchange: [head][layer L-1]...[layer 0][embed]
         self.stage_ranges = []
         first_layer_slot = lambda l: next(s for s in self.order if s.startswith(f"L{l}."))
@@ -130,7 +135,22 @@ class FlatParams:
                 view.copy_(p.data.to(device=dev, dtype=torch.float32))
                 p.data = view
         self.flat = flat
+        self.epoch += 1
+        self.flat_gen += 1
         return flat
+
+    def bump(self):
+        """Call after writing parameter values behind PyTorch's back (raw-pointer kernels, collectives into `flat`)."""
+        self.epoch += 1
+
+    def weights_key(self):
+        """Changes whenever any parameter value may have changed.  The nn.Parameters are `p.data = view` tensors with their OWN
+        version counters: in-place updates through them (torch.optim.*.step, load_state_dict, p.copy_) bump p._version and never
+        flat._version, so the key sums the per-parameter counters; native writers bump `epoch`."""
+        ver = 0
+        for s in self.order:
+            ver += self.slots[s]._version
+        return (self.flat.data_ptr(), self.flat._version, self.epoch, ver)
 
     def offset_table(self):
         tab = (C.c_long * (NG + self.depth * NL))()
@@ -181,7 +201,7 @@ class Engine:
     def bind_params(self):
         flat = self.fp.flat
         self.m.params = flat.data_ptr()
-        key = (flat.data_ptr(), flat._version)
+        key = self.fp.weights_key()
         if key != self.packed_version:
             _check(_rt().vbx_model_pack_weights(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights")
             self.packed_version = key
@@ -206,7 +226,8 @@ class Engine:
                                       float(lr), float(beta1), float(beta2), float(eps), int(step),
                                       gscale.data_ptr() if gscale is not None else None, _lib.current_stream()),
                "vbx_adam_step_packed")
-        self.packed_version = (flat.data_ptr(), flat._version)  # this engine's operand copies were refreshed in the same pass
+        self.fp.bump()  # the flat buffer was written through a raw pointer: every other engine must repack
+        self.packed_version = self.fp.weights_key()  # this engine's operand copies were refreshed in the same pass
 
     # -- forward
     def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None, text=None):

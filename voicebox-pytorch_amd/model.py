@@ -573,6 +573,9 @@ class ConditionalFlowMatcherWrapper(nn.Module):
         B, N, _ = cond.shape
         T = cond_token_ids.shape[-1] if exists(cond_token_ids) else 0
         key = (B, N, steps, bool(use_graph), T, float(cond_scale) != 1.)
+        fp = self.voicebox.flat_params()
+        # a re-flatten (.to(), dtype change) frees the buffer whose addresses the cached hipGraphs captured: drop them
+        self._samplers = {k: s for k, s in self._samplers.items() if s.flat_gen == fp.flat_gen and s.eng.fp is fp}
         smp = self._samplers.get(key)
         if smp is None:
             if len(self._samplers) >= 2:

@@ -19,6 +19,7 @@ class MidpointSampler:
         assert steps >= 2, "need at least two time points"
         self.vb, self.B, self.N, self.steps = voicebox, B, N, steps
         self.eng = voicebox.engine(B, N, training=False)
+        self.flat_gen = self.eng.fp.flat_gen  # the captured graph bakes in addresses inside this flat parameter buffer
         dev = self.eng.device
         D = voicebox._cfg["D"]
         t = torch.linspace(0, 1, steps)  # host fp32, as the CPU oracle

@@ -27,10 +27,14 @@ def exists(v):
     return v is not None
 
 
-def cycle(dl):
+def cycle(dl, sampler=None):
+    epoch = 0
     while True:
+        if sampler is not None:  # DistributedSampler reshuffles only when told the epoch (accelerate's prepared loader does this)
+            sampler.set_epoch(epoch)
         for data in dl:
             yield data
+        epoch += 1
 
 
 def checkpoint_num_steps(checkpoint_path):  # trainer.py:44-57
@@ -102,7 +106,7 @@ class VoiceBoxTrainer(nn.Module):
             sampler = torch.utils.data.distributed.DistributedSampler(self.ds, num_replicas=self.world, rank=self.rank, shuffle=True)
         self.dl = get_dataloader(self.ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, drop_last=drop_last)
         self.valid_dl = get_dataloader(self.valid_ds, batch_size=batch_size, shuffle=True, drop_last=drop_last)
-        self.dl_iter, self.valid_dl_iter = cycle(self.dl), cycle(self.valid_dl)
+        self.dl_iter, self.valid_dl_iter = cycle(self.dl, sampler), cycle(self.valid_dl)
         self.log_every, self.save_model_every, self.save_results_every = log_every, save_model_every, save_results_every
         self.results_folder = Path(results_folder)
         if self.is_main and force_clear_prev_results is True and self.results_folder.exists():
