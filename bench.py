@@ -61,47 +61,126 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters * 1e-3  # seconds per launch
 
 
-def dominant_kernel_roofline(args, dev):
-    """Times the forward FeedForward-in GEMM (gemm_kernel<NT, EpiGEGLU, fp16>) at the benchmark shape: the largest
-    single MFMA kernel of the layer (23.3 GF of 105 GF at dim 512), launched exactly as the runtime does."""
+def stage_flops(args):
+    """Algorithmic FLOPs per launch of every MFMA stage the runtime labels (SURVEY 8(a) formulas at the benchmark shape;
+    attention backward = 2x forward: the S / dP recompute is NOT counted as useful work)."""
+    B, N, D, H, R = args.batch, args.frames, args.dim, args.heads, 16
+    Np, I, F = N + R, H * 64, int(D * 4 * 2 / 3)
+    M = B * Np
+    qkv, out, ffi, ffo = 2.0 * M * D * 3 * I, 2.0 * M * I * D, 2.0 * M * D * 2 * F, 2.0 * M * F * D
+    att = 2.0 * 2 * B * H * Np * Np * 64
+    return {"fwd to_qkv": qkv, "fwd attention": att, "fwd to_out": out, "fwd ff_in": ffi, "fwd ff_out": ffo,
+            "dgrad ff_out": ffo, "dgrad ff_in": ffi, "dgrad to_out": out, "dgrad to_qkv": qkv, "bwd attention": 2 * att,
+            "wgrad (4 GEMMs)": qkv + out + ffi + ffo}
+
+
+class ProfEntry(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("label", _C.c_char * 24), ("calls", _C.c_int), ("total_us", _C.c_float)]
+
+
+def in_situ_stage_table(args, step, n_steps):
+    """Per-stage launch times measured IN SITU: the runtime brackets every MFMA stage with HIP events on the launch stream
+    (vbx_prof_enable / vbx_prof_collect, include/vbx.h) during `n_steps` extra steps of the same workload."""
+    import ctypes as C
+
     from voicebox_pytorch_amd import _lib
 
-    B, N, D, R = args.batch, args.frames, args.dim, 16
-    M, F = B * (N + R), int(D * 4 * 2 / 3)
-    Fp = (F + 63) // 64 * 64
-    x = torch.randn(M, D, device=dev).half()
-    w = (torch.randn(2 * Fp, D, device=dev) * D ** -0.5).half()
-    bias = torch.zeros(2 * Fp, device=dev)
-    g = torch.empty(M, Fp, dtype=torch.float16, device=dev)
-    d = _lib.GemmDesc()
-    d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = _lib.VBX_GEMM_NT, _lib.VBX_EPI_GEGLU, M, 2 * Fp, D, D, D, Fp
-    d.A, d.B, d.C, d.bias, d.f16 = x.data_ptr(), w.data_ptr(), g.data_ptr(), bias.data_ptr(), 1
     lib = _lib.lib()
-    st = _lib.current_stream()
+    lib.vbx_prof_collect.argtypes = [C.POINTER(ProfEntry), C.c_int]
+    lib.vbx_prof_collect.restype = C.c_int
+    torch.cuda.synchronize()
+    lib.vbx_prof_enable(1)
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
+    tab = (ProfEntry * 32)()
+    n = lib.vbx_prof_collect(tab, 32)
+    fl = stage_flops(args)
+    rows = []
+    for e in tab[:max(n, 0)]:
+        label = e.label.decode()
+        us = e.total_us / max(e.calls, 1)
+        row = {"stage": label, "us_per_launch": round(us, 2), "launches_per_step": round(e.calls / n_steps, 2),
+               "us_per_step": round(e.total_us / n_steps, 1)}
+        if label in fl:
+            row["gflop_per_launch"] = round(fl[label] / 1e9, 2)
+            row["tflops"] = round(fl[label] / us / 1e6, 1)
+            row["frac"] = round(fl[label] / us / 1e6 / PEAK_MFMA_TFLOPS, 4)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["us_per_step"])
+    return rows
+
+
+def isolated_gemm_us(args, dev, which):
+    """HIP-event time of ONE GEMM stage launched back to back through the C ABI exactly as the runtime launches it."""
+    from voicebox_pytorch_amd import _lib
+
+    B, N, D, R, H = args.batch, args.frames, args.dim, 16, args.heads
+    M, F, I = B * (N + R), int(D * 4 * 2 / 3), H * 64
+    Fp = (F + 63) // 64 * 64
+    lib, st = _lib.lib(), _lib.current_stream()
+    d = _lib.GemmDesc()
+    keep = []
+    if which == "fwd ff_in":
+        x = torch.randn(M, D, device=dev).half()
+        w = (torch.randn(2 * Fp, D, device=dev) * D ** -0.5).half()
+        bias = torch.zeros(2 * Fp, device=dev)
+        g = torch.empty(M, Fp, dtype=torch.float16, device=dev)
+        d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = _lib.VBX_GEMM_NT, _lib.VBX_EPI_GEGLU, M, 2 * Fp, D, D, D, Fp
+        d.A, d.B, d.C, d.bias, d.f16 = x.data_ptr(), w.data_ptr(), g.data_ptr(), bias.data_ptr(), 1
+        keep = [x, w, bias, g]
+    elif which == "dgrad to_qkv":
+        x = torch.randn(M, 3 * I, device=dev).bfloat16()
+        w = (torch.randn(3 * I, D, device=dev) * D ** -0.5).bfloat16()
+        c = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = _lib.VBX_GEMM_NN, _lib.VBX_EPI_BF16, M, D, 3 * I, 3 * I, D, D
+        d.A, d.B, d.C = x.data_ptr(), w.data_ptr(), c.data_ptr()
+        keep = [x, w, c]
+    else:
+        return None
 
     def launch():
         rc = lib.vbx_gemm(d, st)
         assert rc == 0
 
-    sec = time_kernel(launch)
-    # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of this same command; tools/pmc_summary.py applies the gfx950 read-side correction)
-    traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_hbm.json")
-    if os.path.exists(pmc) and (B, N, D) == (8, 1024, 512):
-        for name, e in json.load(open(pmc)).items():
-            if "EpiGEGLU" in name and "hbm_bytes_per_launch" in e:
-                traffic = round(e["hbm_bytes_per_launch"])
-    flops = 2.0 * M * D * 2 * F  # algorithmic (unpadded F) FLOPs per launch
-    ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<NT,EpiGEGLU,f16> (FeedForward-in + GEGLU)", "achieved": round(ach, 1),
-            "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
-            "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 2)}
+    return round(time_kernel(launch) * 1e6, 2)
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed PMC passes of this command (tools/pmc_summary.py)."""
+    for name in ("r02_train_pmc.json", "r01_bench_pmc_hbm.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc):
+            continue
+        tab = json.load(open(pmc))
+        key = {"fwd ff_in": "GEGLU", "fwd to_qkv": "QKV", "wgrad (4 GEMMs)": "gemm3_grouped", "bwd attention": "attn_bwd",
+               "fwd attention": "attn_fwd"}.get(stage)
+        if key is None:
+            return None
+        tot = 0.0
+        for kname, e in tab.items():
+            if key in kname and "hbm_bytes_per_launch" in e:
+                tot += e["hbm_bytes_per_launch"]
+        if tot:
+            return round(tot)
+    return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's path, oracle/restate.py) on this box's host cores: one fwd+bwd CFM
-    step on a bounded sample (batch 2 instead of 8, same frames/dim/depth)."""
+    """The CPU oracle (a port of the reference's path, oracle/restate.py) on this box's host cores: fwd+bwd CFM steps on a
+    bounded sample -- batch 2 of the 8 (the CPU path's cost per sample does not depend on the batch: samples never interact),
+    same frames / dim / depth; 1 warm-up + 3 timed steps, best and median reported."""
     from oracle import restate
 
     # torch CPU matmuls scale poorly past a few dozen threads (256 threads: 300 s/step measured); cap and report it
@@ -110,22 +189,26 @@ def cpu_baseline(args):
     cfg = restate.Cfg(dim=args.dim, depth=args.depth, heads=args.heads, dim_head=64)
     state = restate.init_state_dict(cfg, seed=0)
     p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in state.items()}
-    Bs = 1
+    Bs = 2
     g = torch.Generator().manual_seed(0)
     x1, x0 = torch.randn(Bs, args.frames, args.dim, generator=g), torch.randn(Bs, args.frames, args.dim, generator=g)
     times, frac, rand = torch.rand(Bs, generator=g), 0.7 + 0.3 * torch.rand(Bs, generator=g), torch.rand(Bs, generator=g)
-    best = None
-    for _ in range(1):
+    ts = []
+    for it in range(4):
         t0 = time.perf_counter()
         loss = restate.cfm_loss(p, cfg, x1, x0, times, frac, rand)
         loss.backward()
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        if it > 0:
+            ts.append(dt)
         for v in p.values():
             v.grad = None
+    ts.sort()
+    best, med = ts[0], ts[len(ts) // 2]
     return {"value": round(Bs * args.frames / best, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "median_value": round(Bs * args.frames / med, 1), "cpu": cpu_model(), "host_cores_total": os.cpu_count(),
             "sample": f"oracle fwd+bwd (fp32, torch CPU, {cores} threads), batch {Bs} of {args.batch}, {args.frames} frames, "
-                      f"dim {args.dim}, depth {args.depth}; 1 step; {best:.2f} s/step"}
+                      f"dim {args.dim}, depth {args.depth}; 1 warm-up + 3 timed steps; best {best:.2f} s/step, median {med:.2f} s/step"}
 
 
 def main():
@@ -142,6 +225,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--intervals", type=int, default=64, help="sample mode: midpoint intervals (NFE = 2x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sample", action="store_true", help="train mode: skip the 64-interval sample leg")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
     args = ap.parse_args()
 
@@ -152,7 +236,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VBX_FORCE_DIST") == "1":  # VBX_FORCE_DIST=1: run the RCCL path at world size 1 too
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -214,7 +298,34 @@ def main():
         }
         if loss_val is not None:
             out["final_loss"] = round(loss_val, 5)
-        out["roofline"] = dominant_kernel_roofline(args, dev)
+        # ---- roofline: the DOMINANT MFMA stage of the timed workload, timed in situ with HIP events on the launch stream
+        rows = in_situ_stage_table(args, step, 3 if args.mode == "train" else 1)
+        mf = [r for r in rows if "frac" in r]
+        if mf:
+            top = mf[0]
+            out["roofline"] = {"bound": "mfma", "kernel": top["stage"], "achieved": top["tflops"], "peak": PEAK_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": top["frac"], "traffic": pmc_traffic(top["stage"]),
+                               "flops_per_launch": top["gflop_per_launch"] * 1e9, "us_per_launch": top["us_per_launch"],
+                               "measured": "HIP events around the stage's launch(es) on the launch stream, in situ (vbx_prof_*), "
+                                           "averaged over the layers of 3 extra steps",
+                               "isolated_us": {k: isolated_gemm_us(args, dev, k) for k in ("fwd ff_in", "dgrad to_qkv")},
+                               "mfma_us_per_step": round(sum(r["us_per_step"] for r in mf), 1),
+                               "kernels": rows}
+        if args.mode == "train" and world == 1 and not args.no_sample:
+            # the other half of BASELINE.json's metric in the same invocation: 64 midpoint intervals = 128 NFE under hipGraph
+            steps_pts = args.intervals + 1
+            wrapper.sample(cond=x, steps=steps_pts)  # capture + warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            wrapper.sample(cond=x, steps=steps_pts)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            nfe = 2 * args.intervals
+            fwd_flops = fwd_flops_per_frame(args.dim, args.depth, args.heads, args.frames, 16) * args.batch * args.frames
+            out["sample"] = {"ms": round(dt * 1e3, 2), "frames_per_s": round(args.batch * args.frames / dt, 1), "nfe": nfe,
+                             "ms_per_nfe": round(dt * 1e3 / nfe, 3), "fwd_frac": round(fwd_flops * nfe / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                             "what": f"ConditionalFlowMatcherWrapper.sample(cond=(8,{args.frames},{args.dim}), steps={steps_pts}) "
+                                     f"= {args.intervals} midpoint intervals under hipGraph, one timed run after the capture run"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -85,8 +85,9 @@ typedef struct {
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
 /* Tuning knob (results are identical up to fp32 summation order): which tile serves vbx_gemm / the grouped launch.
- * 0 automatic per shape (default; environment VBX_GEMM3=0/1/2 presets 1 / 0 / 2), 1 the 128-wide kernels only,
- * 2 the 256 x 256 8-wave kernel wherever it can serve.  Not thread safe; call before launching work. */
+ * 0 automatic per shape (default; environment VBX_GEMM_PATH=<n> presets it), 1 the 128-wide kernels only, 2 the 256 x 256
+ * 8-wave kernel (gemm3.hip) wherever it can serve, 3 the 128 x 256 two-workgroups-per-CU kernel (gemm4.hip) wherever it can.
+ * Not thread safe; call before launching work. */
 int vbx_gemm_select(int path);
 /* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch (same kernel body, same results as n vbx_gemm calls): the weight-gradient
  * GEMMs of a layer are 220-480 workgroups each -- separately they fill a third to two thirds of the chip.  EXPERIMENTAL: used by the
@@ -397,6 +398,20 @@ int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream)
 
 /* tests/debug only: device pointer of a named tensor inside the activation arena (NULL if unknown) */
 void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer);
+
+/* ------------------------------------------------------------------ in-situ stage timing (measurement only)
+ * While enabled, vbx_model_forward / vbx_model_backward_* bracket each MFMA stage of a layer (to_qkv, attention forward, to_out,
+ * ff_in, ff_out, the four dgrads, attention backward, the weight-gradient launch) with a pair of HIP events recorded on the
+ * caller's stream, i.e. the launches are timed where they run -- between their real neighbours -- not back to back in
+ * isolation.  vbx_prof_collect synchronises on the recorded events, aggregates by label and disables the recording.
+ * Not hipGraph-capture safe: do not enable around a capture.  bench.py's roofline.kernels come from here. */
+typedef struct {
+  char label[24];
+  int calls;
+  float total_us;
+} vbx_prof_entry;
+int vbx_prof_enable(int on);
+int vbx_prof_collect(vbx_prof_entry* out, int max_entries); /* returns the number of labels (<= max_entries) */
 
 /* ------------------------------------------------------------------ hardware probes (tests only) */
 int vbx_probe_tr16(const void* in_u16_4096, const int* lane_elem_off, void* out_u16_256, void* stream);

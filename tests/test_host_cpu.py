@@ -240,13 +240,15 @@ def test_duration_predictor_host_logic(golden):
                                                                 condition_on_text=False), duration_predictor=dp)
 
 
-def test_gemm3_lds_layout_emulation(tmp_path):
-    """csrc/gemm3_layout.hpp (LDS-DMA source permutation, fragment read addresses, transposed-accumulator column map of the
-    256 x 256 GEMM tile) replayed on the host against a plain GEMM, plus bank-conflict freedom of every fragment read."""
+@pytest.mark.parametrize("which", ["gemm3", "gemm4"])
+def test_gemm_tile_lds_layout_emulation(tmp_path, which):
+    """csrc/gemm3_layout.hpp / gemm4_layout.hpp (LDS-DMA source permutation, fragment read addresses, transposed-accumulator
+    column map of the 256 x 256 and 128 x 256 GEMM tiles) replayed on the host against a plain GEMM, plus bank-conflict
+    freedom of every fragment read and the DS-immediate identities the kernels rely on."""
     import subprocess
 
-    exe = str(tmp_path / "gemm3_layout_check")
-    src = os.path.join(ROOT, "tests", "native", "gemm3_layout_check.cpp")
+    exe = str(tmp_path / f"{which}_layout_check")
+    src = os.path.join(ROOT, "tests", "native", f"{which}_layout_check.cpp")
     subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:]

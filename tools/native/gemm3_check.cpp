@@ -62,7 +62,7 @@ static std::vector<double> refmm(const Mat& A, int at, const Mat& B, int bt, int
 }
 
 static void correctness(int path) {
-  printf("== correctness, path %d (%s)\n", path, path == 2 ? "256-wide gemm3" : "128-wide");
+  printf("== correctness, path %d (%s)\n", path, path == 2 ? "256x256 gemm3" : (path == 3 ? "128x256 gemm4" : "128-wide"));
   vbx_gemm_select(path);
   srand(7);
   {  // ---- NT, F32 (+bias +resid, bf16 copy), bf16 and fp16 operands; ragged M / N / K
@@ -293,7 +293,9 @@ static void model_shapes(bool do_time, bool do_race) {
       std::vector<std::vector<uint8_t>> first, oldp;
       vbx_gemm_select(1); run(b.d, b.name.c_str());
       for (auto& o : b.outs) oldp.push_back(host((const uint8_t*)o.first, o.second));
-      vbx_gemm_select(2);
+      for (int newpath = 2; newpath <= 3; newpath++) {
+      first.clear();
+      vbx_gemm_select(newpath);
       int diffs_run = 0;
       for (int it = 0; it < 6; it++) {
         for (auto& o : b.outs) HIPCHK(hipMemset(o.first, 0xff, o.second));
@@ -323,19 +325,20 @@ static void model_shapes(bool do_time, bool do_race) {
           if (e > worst || e != e) worst = e;
         }
       }
-      printf("  %-62s reruns differing: %d   |new-old| > 2e-2: %ld (worst %.3g)\n", b.name.c_str(), diffs_run, nd, worst);
+      printf("  %-62s path %d reruns differing: %d   |new-old| > 2e-2: %ld (worst %.3g)\n", b.name.c_str(), newpath, diffs_run, nd, worst);
       if (diffs_run || nd) bad++;
+      }
     }
   }
   if (do_time) {
     printf("== timing (us per launch, back to back, normal random data)\n");
     for (auto& b : bs) {
-      float t[2][2];
+      float t[3][2];
       for (int rep = 0; rep < 2; rep++)
-        for (int path = 1; path <= 2; path++) { vbx_gemm_select(path); t[path - 1][rep] = time_desc(b.d, 20); }
-      const float t1 = fminf(t[0][0], t[0][1]), t2 = fminf(t[1][0], t[1][1]);
-      printf("  %-62s 128-wide %7.1f us (%6.0f TF/s)   256-wide %7.1f us (%6.0f TF/s)   x%.2f\n", b.name.c_str(), t1, b.flops / t1 * 1e-6, t2,
-             b.flops / t2 * 1e-6, t1 / t2);
+        for (int path = 1; path <= 3; path++) { vbx_gemm_select(path); t[path - 1][rep] = time_desc(b.d, 20); }
+      const float t1 = fminf(t[0][0], t[0][1]), t2 = fminf(t[1][0], t[1][1]), t3 = fminf(t[2][0], t[2][1]);
+      printf("  %-62s 128-wide %6.1f us (%5.0f TF/s)  gemm3 %6.1f us (%5.0f)  gemm4 %6.1f us (%5.0f TF/s)\n", b.name.c_str(), t1, b.flops / t1 * 1e-6, t2,
+             b.flops / t2 * 1e-6, t3, b.flops / t3 * 1e-6);
     }
     // weight gradients of a layer: four launches (128-wide, their own split counts) vs one grouped launch
     {
@@ -367,7 +370,7 @@ static void model_shapes(bool do_time, bool do_race) {
     for (int n : {4096, 8192}) {
       auto X = dev(randn16((size_t)n * n, 1.0f, false)); auto Y = dev(randn16((size_t)n * n, 1.0f, false)); uint16_t* Z = devfill<uint16_t>((size_t)n * n, 0);
       vbx_gemm_desc d{}; d.mode = VBX_GEMM_NT; d.epilogue = VBX_EPI_BF16; d.M = d.N = d.K = n; d.lda = d.ldb = d.ldc = n; d.A = X; d.B = Y; d.C = Z;
-      for (int path = 1; path <= 2; path++) { vbx_gemm_select(path); const float t = time_desc(d, 10); printf("  %d^3 NT bf16 path %d: %8.1f us  %6.0f TF/s\n", n, path, t, 2.0 * n * n * n / t * 1e-6); }
+      for (int path = 1; path <= 3; path++) { vbx_gemm_select(path); const float t = time_desc(d, 10); printf("  %d^3 NT bf16 path %d: %8.1f us  %6.0f TF/s\n", n, path, t, 2.0 * n * n * n / t * 1e-6); }
       hipFree(X); hipFree(Y); hipFree(Z);
     }
   }
@@ -375,7 +378,7 @@ static void model_shapes(bool do_time, bool do_race) {
 
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
-  if (what == "correct" || what == "all") { correctness(1); correctness(2); }
+  if (what == "correct" || what == "all") { correctness(1); correctness(2); correctness(3); }
   if (what == "race" || what == "all") model_shapes(false, true);
   if (what == "time" || what == "all") model_shapes(true, false);
   printf(bad ? "GEMM3 CHECK FAILED: %d problems\n" : "GEMM3 CHECK OK\n", bad);

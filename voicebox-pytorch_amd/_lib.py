@@ -31,6 +31,7 @@ _PROTOS = {
     "vbx_check_device": [I],
     "vbx_gemm": [C.POINTER(GemmDesc), P],
     "vbx_gemm_select": [I],
+    "vbx_prof_enable": [I],
     "vbx_gemm_tn_splitk_grouped": [C.POINTER(GemmDesc), I, P],
     "vbx_splitk_reduce": [P, I, I, I, P, I, I, I, I, I, I, P],
     "vbx_rmsnorm_fwd": [P, P, P, L, P, P, I, I, I, I, I, P],

@@ -970,25 +970,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs j
 static int g_gemm_path = -1;
 int vbx_gemm_path() {
   if (g_gemm_path < 0) {
-    const char* e = getenv("VBX_GEMM3");
-    g_gemm_path = e ? (atoi(e) == 0 ? 1 : (atoi(e) >= 2 ? 2 : 0)) : 0;
+    const char* e = getenv("VBX_GEMM_PATH");
+    const char* e3 = getenv("VBX_GEMM3");
+    g_gemm_path = e ? atoi(e) : ((e3 && atoi(e3) == 0) ? 1 : 0);
+    if (g_gemm_path < 0 || g_gemm_path > 3) g_gemm_path = 0;
   }
   return g_gemm_path;
 }
 extern "C" int vbx_gemm_select(int path) {
-  VBX_REQUIRE(path >= 0 && path <= 2, "vbx_gemm_select: 0 automatic, 1 128-wide kernels only, 2 256-wide kernel wherever it serves");
+  VBX_REQUIRE(path >= 0 && path <= 3, "vbx_gemm_select: 0 automatic, 1 128-wide kernels only, 2 256x256 tile wherever it serves, 3 128x256 tile wherever it serves");
   g_gemm_path = path;
   return 0;
 }
-// automatic choice: the 256 x 256 tile (one workgroup per CU) needs enough tiles to cover the chip; the N = dim GEMMs of the
-// model (M = 8320, N = 512: 66 tiles) stay on the 160 x 128 one-round kernels.
-static bool gemm3_wanted(const vbx_gemm_desc* d) {
+// Which tile serves a descriptor.  Automatic choice (measured on the model's shapes, tools/native/gemm3_check time):
+//  * NT / NN with at least one 128 x 256 tile per workgroup slot (2 per CU): gemm4 -- its two co-resident workgroups overlap one
+//    tile's output stores with the other's MFMAs, which the short-K (K = dim), store-heavy GEMMs need;
+//  * everything else (the N = dim GEMMs: too few wide tiles to fill the chip) stays on the 160 x 128 / 128 x 128 kernels;
+//  * split-K weight gradients: the caller groups them into one gemm3 launch (runtime.hip).
+static int gemm_tile_for(const vbx_gemm_desc* d) {
   const int path = vbx_gemm_path();
-  if (path == 1) return false;
-  if (path == 2) return true;
-  if (d->epilogue == VBX_EPI_SPLITK) return false;  // the caller picks split counts per tile shape (runtime.hip: grouped launch)
-  const long tiles = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
-  return tiles >= 120 && d->K >= 128;
+  if (path == 1) return 1;
+  if (path == 2) return 3;
+  const bool ntnn = d->mode == VBX_GEMM_NT || d->mode == VBX_GEMM_NN;
+  if (path == 3) return ntnn ? 4 : 1;
+  if (!ntnn || d->epilogue == VBX_EPI_SPLITK) return 1;
+  const long tiles4 = (long)cdiv(d->M, 128) * cdiv(d->N, 256);
+  return (tiles4 >= 256 && d->K >= 64) ? 4 : 1;
 }
 
 extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
@@ -997,8 +1004,9 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
   VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "vbx_gemm: leading dims must be multiples of 8 (16-byte rows)");
   VBX_REQUIRE(d->N % 8 == 0, "vbx_gemm: N must be a multiple of 8");
-  if (gemm3_wanted(d)) {
-    const int rc = vbx_gemm3(d, st);
+  const int tile = gemm_tile_for(d);
+  if (tile == 3 || tile == 4) {
+    const int rc = tile == 3 ? vbx_gemm3(d, st) : vbx_gemm4(d, st);
     if (rc != VBX_EUNSUPPORTED) return rc;
   }
   GemmParams p;

@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <algorithm>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -277,6 +278,32 @@ void carve_acts(const vbx_model* m, Acts& a) {
   a.bytes = al256(c.off);
 }
 
+// ---- in-situ stage timing (vbx_prof_enable / vbx_prof_collect, include/vbx.h)
+struct ProfRec {
+  const char* label;
+  hipEvent_t e0, e1;
+};
+struct Prof {
+  bool on = false;
+  std::vector<ProfRec> recs;
+};
+Prof g_prof;
+struct ProfScope {
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(const char* label, hipStream_t st_) : st(st_) {
+    if (!g_prof.on) return;
+    ProfRec r{label, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    idx = (int)g_prof.recs.size();
+    g_prof.recs.push_back(r);
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof.recs[idx].e1, st);
+  }
+};
+
 #define CK(x)                 \
   do {                        \
     int rc__ = (x);           \
@@ -397,7 +424,7 @@ int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, fl
     }
     run = ss.s;
   }
-  CK(vbx_gemm(&g, run));
+  { ProfScope ps("wgrad (separate)", run); CK(vbx_gemm(&g, run)); }
   if (defer && J % 4 == 0 && defer->n < VBX_SKR_MAX) {  // reduced later, together with the layer's other weight gradients
     vbx_skr_job& jb = defer->job[defer->n++];
     jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
@@ -544,16 +571,20 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     g.k_gamma = m->qk_norm ? P + o[VBX_L_KG] : nullptr;
     g.rot_cos = m->rot_cos; g.rot_sin = m->rot_sin;
     g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.v16 = y.vh; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
-    CK(vbx_gemm(&g, stream));
-    CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
-    CK(gemm_nt(y.oh, d.I, w.layer[l].outh, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, nullptr, st));
+    { ProfScope ps("fwd to_qkv", st); CK(vbx_gemm(&g, stream)); }
+    { ProfScope ps("fwd attention", st);
+      CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream)); }
+    { ProfScope ps("fwd to_out", st);
+      CK(gemm_nt(y.oh, d.I, w.layer[l].outh, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, nullptr, st)); }
     // ff_prenorm -> FeedForward (GEGLU) + residual   (:471-472, :337-349)
     if (m->plain_norm) CK(vbx_rmsnorm_fwd(x_mid, P + o[VBX_L_N2G], nullptr, 0, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
     else CK(vbx_rmsnorm_fwd(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, y.hn2h, d.B, d.Np, 0, d.Np, d.D, stream));
-    CK(gemm_nt(y.hn2h, d.D, w.layer[l].w1h, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.gh, d.Fp, w.layer[l].b1, nullptr,
-               tr ? y.h1 : nullptr, y.g, st));
-    CK(gemm_nt(y.gh, d.Fp, w.layer[l].w2h, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
-               nullptr, st));
+    { ProfScope ps("fwd ff_in", st);
+      CK(gemm_nt(y.hn2h, d.D, w.layer[l].w1h, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.gh, d.Fp, w.layer[l].b1, nullptr,
+                 tr ? y.h1 : nullptr, y.g, st)); }
+    { ProfScope ps("fwd ff_out", st);
+      CK(gemm_nt(y.gh, d.Fp, w.layer[l].w2h, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
+                 nullptr, st)); }
   }
   if (m->stack_only)  // strip registers, final RMSNorm -> fp32 output   (:476-479)
     return vbx_rmsnorm_fwd_f32(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, io->pred, d.B, d.Np, d.R, d.N, d.D,
@@ -633,7 +664,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   u16* dxb_attn = wgp ? a.dxb2 : a.dxb;  // bf16 dx entering the attention half (see Acts::dxb2)
   const size_t sfl = a.slab_floats;
   // ---- FeedForward
-  CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st));
+  { ProfScope ps("dgrad ff_out", st); CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st)); }
   CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp, gs));
   if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
     CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
@@ -641,7 +672,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
     CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   }
-  CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st));
+  { ProfScope ps("dgrad ff_in", st); CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st)); }
   CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp, gs));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
@@ -658,10 +689,11 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   }
   if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
-  CK(gemm_nn_bf16(dxb_attn, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st));
+  { ProfScope ps("dgrad to_out", st); CK(gemm_nn_bf16(dxb_attn, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st)); }
   CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp, gs));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
+    ProfScope ps("bwd attention", st);
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
                           m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin,
                           m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, stream));
@@ -682,10 +714,10 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
       CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
     }
   }
-  CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st));
+  { ProfScope ps("dgrad to_qkv", st); CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st)); }
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp, gs));
-  if (wgg.n) CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream));  // every operand is still live here (a.dxb: see dxb_attn)
-  if (wj.n) CK(vbx_splitk_reduce_multi(&wj, stream));
+  if (wgg.n) { ProfScope ps("wgrad (4 GEMMs)", st); CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream)); }  // every operand is still live here (a.dxb: see dxb_attn)
+  if (wj.n) { ProfScope ps("wgrad slab reduce", st); CK(vbx_splitk_reduce_multi(&wj, stream)); }
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
     CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
@@ -854,6 +886,36 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
     for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
   }
   return (int)all.size();
+}
+
+extern "C" int vbx_prof_enable(int on) {
+  for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.recs.clear();
+  g_prof.on = on != 0;
+  return 0;
+}
+extern "C" int vbx_prof_collect(vbx_prof_entry* out, int max_entries) {
+  VBX_REQUIRE(out && max_entries > 0, "vbx_prof_collect: bad args");
+  g_prof.on = false;
+  int n = 0;
+  for (auto& r : g_prof.recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    int k = 0;
+    for (; k < n; k++)
+      if (!strncmp(out[k].label, r.label, sizeof(out[k].label) - 1)) break;
+    if (k == n) {
+      if (n == max_entries) continue;
+      memset(&out[n], 0, sizeof(out[n]));
+      strncpy(out[n].label, r.label, sizeof(out[n].label) - 1);
+      n++;
+    }
+    out[k].calls++;
+    out[k].total_us += ms * 1000.f;
+  }
+  for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.recs.clear();
+  return n;
 }
 
 // Debug/introspection (tests only): device pointer of a named arena tensor.
