@@ -282,6 +282,14 @@ def main():
         elapsed = float(t)
     loss_val = float(last.float().mean()) if args.mode == "train" else None
 
+    # ---- in-situ stage times (every rank runs the extra steps: they contain the collectives); sample mode replays a hipGraph,
+    # whose launches do not pass through the runtime again, so its table comes from an eager 2-interval sample
+    if args.mode == "train":
+        rows = in_situ_stage_table(args, step, 3)
+    else:
+        rows = in_situ_stage_table(args, lambda: wrapper.sample(cond=x, steps=3, use_graph=False), 1)
+    barrier()
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * units_per_step * args.steps / elapsed
@@ -299,7 +307,6 @@ def main():
         if loss_val is not None:
             out["final_loss"] = round(loss_val, 5)
         # ---- roofline: the DOMINANT MFMA stage of the timed workload, timed in situ with HIP events on the launch stream
-        rows = in_situ_stage_table(args, step, 3 if args.mode == "train" else 1)
         mf = [r for r in rows if "frac" in r]
         if mf:
             top = mf[0]

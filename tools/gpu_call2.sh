@@ -13,5 +13,4 @@ VBX_GEMM_PATH=2 timeout 300 python bench.py --no-cpu-baseline --no-sample > $O/b
 for i in 1 2; do
   echo "train path1 $(VBX_GEMM_PATH=1 tools/bv.sh)" | tee -a $O/summary.log
   echo "train auto  $(tools/bv.sh)" | tee -a $O/summary.log
-  echo "train path1+group $(VBX_GEMM_PATH=1 VBX_GROUP_WGRAD=1 tools/bv.sh)" | tee -a $O/summary.log
 done
