@@ -366,6 +366,19 @@ static void model_shapes(bool do_time, bool do_race) {
       float tot = 0; for (int j = 0; j < 4; j++) tot += time_desc(w[j], 20);
       printf("  layer wgrads, four 128-wide launches (splits 4/12/4/8): %7.1f us (%6.0f TF/s)\n", tot, fl / tot * 1e-6);
     }
+    // K sweep at the to_qkv output shape with a plain bf16 epilogue: slope = k-loop rate, intercept = prologue + epilogue + launch
+    {
+      const int N = 3072, Kmax = 4096;
+      auto X = dev(randn16((size_t)M * Kmax, 1.0f, false)); auto Y = dev(randn16((size_t)N * Kmax, 0.03f, false)); uint16_t* Z = devfill<uint16_t>((size_t)M * N, 0);
+      for (int K : {128, 256, 512, 1024, 2048, 4096}) {
+        vbx_gemm_desc d{}; d.mode = VBX_GEMM_NT; d.epilogue = VBX_EPI_BF16; d.M = M; d.N = N; d.K = K; d.lda = Kmax; d.ldb = Kmax; d.ldc = N; d.A = X; d.B = Y; d.C = Z;
+        float t[3];
+        for (int path = 1; path <= 3; path++) { vbx_gemm_select(path); t[path - 1] = fminf(time_desc(d, 20), time_desc(d, 20)); }
+        printf("  K sweep M=8320 N=3072 K=%4d (NT bf16 -> bf16): 128-wide %6.1f us  gemm3 %6.1f us  gemm4 %6.1f us   (%.0f / %.0f / %.0f TF/s)\n", K, t[0], t[1], t[2],
+               2.0 * M * N * K / t[0] * 1e-6, 2.0 * M * N * K / t[1] * 1e-6, 2.0 * M * N * K / t[2] * 1e-6);
+      }
+      hipFree(X); hipFree(Y); hipFree(Z);
+    }
     // square reference points (NT bf16 -> bf16)
     for (int n : {4096, 8192}) {
       auto X = dev(randn16((size_t)n * n, 1.0f, false)); auto Y = dev(randn16((size_t)n * n, 1.0f, false)); uint16_t* Z = devfill<uint16_t>((size_t)n * n, 0);

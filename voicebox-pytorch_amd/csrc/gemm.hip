@@ -982,20 +982,18 @@ extern "C" int vbx_gemm_select(int path) {
   g_gemm_path = path;
   return 0;
 }
-// Which tile serves a descriptor.  Automatic choice (measured on the model's shapes, tools/native/gemm3_check time):
-//  * NT / NN with at least one 128 x 256 tile per workgroup slot (2 per CU): gemm4 -- its two co-resident workgroups overlap one
-//    tile's output stores with the other's MFMAs, which the short-K (K = dim), store-heavy GEMMs need;
-//  * everything else (the N = dim GEMMs: too few wide tiles to fill the chip) stays on the 160 x 128 / 128 x 128 kernels;
-//  * split-K weight gradients: the caller groups them into one gemm3 launch (runtime.hip).
+// Which tile serves a descriptor.  Automatic choice (measured in situ on the model's shapes, bench.py's stage table):
+//  * the layer's four split-K weight gradients run as ONE grouped gemm3 launch (runtime.hip): 92 us against 4 x 38 us;
+//  * NT / NN GEMMs stay on the 128-wide kernels: at K = dim = 512 the wide GEMMs are bound by their output stores and by the
+//    L2 -> LDS fill rate, and neither the 256 x 256 tile (one workgroup per CU: k-loop and epilogue alternate) nor the
+//    128 x 256 tile (two per CU) beat the three-per-CU 128 x 128 kernel there; the N = dim GEMMs have too few wide tiles.
+//    Paths 2 / 3 force them for measurements (tools/native/gemm3_check).
 static int gemm_tile_for(const vbx_gemm_desc* d) {
   const int path = vbx_gemm_path();
-  if (path == 1) return 1;
   if (path == 2) return 3;
   const bool ntnn = d->mode == VBX_GEMM_NT || d->mode == VBX_GEMM_NN;
   if (path == 3) return ntnn ? 4 : 1;
-  if (!ntnn || d->epilogue == VBX_EPI_SPLITK) return 1;
-  const long tiles4 = (long)cdiv(d->M, 128) * cdiv(d->N, 256);
-  return (tiles4 >= 256 && d->K >= 64) ? 4 : 1;
+  return 1;
 }
 
 extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {

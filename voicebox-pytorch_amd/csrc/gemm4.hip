@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(G4Params p, Epi epi) {
   Frag4<MA, 4> fa;
   Frag4<MB, 8> fb;
   fa.init(smem, wr * 64, lane);
-  fb.init(smem + A_BYTES, wc * 128, lane);
+  fb.init(smem + A_BYTES, wc * 128, lane);  // B stage base inside slot 0: the reads below add only the slot offset SO
 
   Acc acc;
 #pragma unroll
@@ -160,10 +160,8 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(G4Params p, Epi epi) {
     if (t + 2 < nt) stage(t + 2);  // into the slot k-tile t-1 used
     RawFrag4 af[4], bf[8];
     fa.template read<SO, 0>(af[0]); fa.template read<SO, 1>(af[1]); fa.template read<SO, 2>(af[2]); fa.template read<SO, 3>(af[3]);
-    fb.template read<SO + A_BYTES, 0>(bf[0]); fb.template read<SO + A_BYTES, 1>(bf[1]);
-    fb.template read<SO + A_BYTES, 2>(bf[2]); fb.template read<SO + A_BYTES, 3>(bf[3]);
-    fb.template read<SO + A_BYTES, 4>(bf[4]); fb.template read<SO + A_BYTES, 5>(bf[5]);
-    fb.template read<SO + A_BYTES, 6>(bf[6]); fb.template read<SO + A_BYTES, 7>(bf[7]);
+    fb.template read<SO, 0>(bf[0]); fb.template read<SO, 1>(bf[1]); fb.template read<SO, 2>(bf[2]); fb.template read<SO, 3>(bf[3]);
+    fb.template read<SO, 4>(bf[4]); fb.template read<SO, 5>(bf[5]); fb.template read<SO, 6>(bf[6]); fb.template read<SO, 7>(bf[7]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
