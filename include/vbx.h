@@ -89,9 +89,9 @@ int vbx_gemm(const vbx_gemm_desc* d, void* stream);
  * 8-wave kernel (gemm3.hip) wherever it can serve, 3 the 128 x 256 two-workgroups-per-CU kernel (gemm4.hip) wherever it can.
  * Not thread safe; call before launching work. */
 int vbx_gemm_select(int path);
-/* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch (same kernel body, same results as n vbx_gemm calls): the weight-gradient
- * GEMMs of a layer are 220-480 workgroups each -- separately they fill a third to two thirds of the chip.  EXPERIMENTAL: used by the
- * runtime only under VBX_GROUP_WGRAD=1 until it has been measured in situ. */
+/* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch of the 256 x 256 tile (same slab layout and results as n vbx_gemm calls):
+ * the four weight-gradient GEMMs of a layer are 8-24 such tiles each; together, with 3 K-splits, they fill 198 CUs (92 us in
+ * situ against 4 x 38 us as separate 128-wide launches).  With vbx_gemm_select(1) it falls back to n separate launches. */
 int vbx_gemm_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, void* stream);
 /* Sum split-K slabs [splits][M][N] and scatter into dst (fp32): dst[rowmap(i)][j] (+)= sum_s slab.
  * rowmap: 0 identity; 1 GEGLU de-interleave with (F, Fp): packed row p -> ((p%128)<64 ?

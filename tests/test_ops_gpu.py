@@ -824,11 +824,9 @@ def test_geglu_bwd_colsum_and_multi_reduce(L):
     assert rel_err(out2[:, :64], x[:, :, :64].sum(1)) < 1e-6 and float(out2[:, 64:].abs().max()) == 0.0
 
 
-@pytest.mark.skipif(os.environ.get("VBX_TEST_EXPERIMENTAL") != "1",
-                    reason="vbx_gemm_tn_splitk_grouped is an unmeasured experiment (VBX_GROUP_WGRAD=1); run with VBX_TEST_EXPERIMENTAL=1")
 def test_grouped_splitk_gemm_equals_separate_launches(L):
-    """The four weight-gradient shapes of a dim-512 layer (and ragged ones) through ONE grouped launch: slabs bit-identical to
-    four vbx_gemm calls (same kernel body, same tile / split assignment)."""
+    """The four weight-gradient shapes of a dim-512 layer (and ragged ones) through ONE grouped launch of the 256 x 256 tile
+    (gemm3.hip): the same slabs as four vbx_gemm calls on the 128-wide kernels (same K ranges per split; fp32 accumulation)."""
     g = torch.Generator().manual_seed(0)
     for K, shapes in ((8320, ((3072, 512, 5), (512, 1024, 8), (2816, 512, 5), (512, 1408, 5))),
                       (1000, ((264, 136, 3), (72, 520, 1), (128, 128, 2)))):
@@ -850,4 +848,34 @@ def test_grouped_splitk_gemm_equals_separate_launches(L):
         assert rc == 0, L.lib().vbx_last_error()
         torch.cuda.synchronize()
         for a, b in zip(sep, grp):
-            assert torch.equal(a, b)
+            assert torch.isfinite(b).all() and rel_err(b, a.double()) < 1e-6
+
+
+def test_fp16_outputs_saturate(L):
+    """forward GEMM operands are stored as fp16 (max 65504).  Outlier activations must clamp, not
+    become inf (an inf would give inf * 0 = NaN in the next GEMM): the norm output with a huge gamma, and the v / GEGLU outputs of
+    a GEMM with huge weights."""
+    D, Bsz, Np = 512, 1, 24
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(Bsz, Np, D, generator=g)
+    gamma = torch.full((D,), 1.0e4)  # normed rows have |x_i| ~ 1 -> y ~ 1e4 .. 4e4 and beyond fp16 range for the tails
+    gamma[::7] = 1.0e5
+    y16 = torch.empty(Bsz * Np, D, dtype=torch.float16, device=dev)
+    L.call("vbx_rmsnorm_fwd", x.to(dev), gamma.to(dev), None, 0, None, y16, Bsz, Np, 0, Np, D, st())
+    assert torch.isfinite(y16.float()).all()
+    ref = (restate.l2norm_scale(x.double(), D) * gamma.double()).clamp(-65504, 65504).view(Bsz * Np, D)
+    assert rel_err(y16, ref) < 1e-3
+    assert (y16.float().abs() == 65504).any()  # the clamp was exercised
+    # GEGLU output of a GEMM with large weights
+    M, K, F = 64, 64, 128
+    a = (torch.randn(M, K, generator=g) * 30).half()
+    w = (torch.randn(2 * F, K, generator=g) * 30).half()
+    bias = torch.zeros(2 * F)
+    G = torch.empty(M, F, dtype=torch.float16, device=dev)
+    d = L.GemmDesc()
+    d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = L.VBX_GEMM_NT, L.VBX_EPI_GEGLU, M, 2 * F, K, K, K, F
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    d.A, d.B, d.C, d.bias, d.f16 = ad.data_ptr(), wd.data_ptr(), G.data_ptr(), bd.data_ptr(), 1
+    assert L.lib().vbx_gemm(d, st()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(G.float()).all() and (G.float().abs() == 65504).any()

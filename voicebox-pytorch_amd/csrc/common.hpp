@@ -46,7 +46,11 @@ VBX_DEV u16 f32_to_bf16(float f) {  // round-to-nearest-even (NaN preserved)
   return __builtin_bit_cast(u16, b);
 }
 VBX_DEV unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+// fp16 stores SATURATE at +-65504 (NaN stays NaN): forward GEMM operands are fp16 for their 11-bit mantissa, and an outlier
+// activation of a trained checkpoint (v, the GEGLU output, a normed row times a large gamma) must not turn into inf -- inf * 0 in
+// the next GEMM would poison the whole row.  A clamped outlier is a bounded error instead (tests/test_ops_gpu.py::test_fp16_outputs_saturate).
 VBX_DEV u16 f32_to_f16(float f) {
+  f = (f > 65504.0f) ? 65504.0f : ((f < -65504.0f) ? -65504.0f : f);
   _Float16 h = (_Float16)f;
   return __builtin_bit_cast(u16, h);
 }

@@ -298,44 +298,6 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
 #undef VBX_SPLIT_
 }
 
-// ---- several independent GEMMs of the same kind in ONE grid (first use: the four split-K weight-gradient GEMMs of a layer,
-// which as separate launches of 220-480 workgroups fill 0.29-0.63 of the chip's 768 slots each).  Job j owns the block ids
-// [block0[j], block0[j+1]); inside a job the ids run split-major with T8 = tiles rounded up to a multiple of 8 per split, so that
-// (block id % 8) -- the XCD the dispatcher picks -- equals (tile id % 8) as the XCD-aware tile order of the body assumes; the
-// up to 7 surplus workgroups per split exit at once.
-constexpr int GG_MAX = 4;
-template <class Epi>
-struct GroupedGemm {
-  int n;
-  int block0[GG_MAX + 1];
-  int T[GG_MAX];   // tiles of one split
-  int T8[GG_MAX];  // T rounded up to a multiple of 8
-  GemmParams p[GG_MAX];
-  Epi epi[GG_MAX];
-};
-template <int MA, int MB, class Epi, bool F16, int BM_>
-__global__ __launch_bounds__(256, 3) void gemm_kernel_v2_grouped(GroupedGemm<Epi> g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int j = 0;
-#pragma unroll
-  for (int i = 1; i < GG_MAX; i++)
-    if (i < g.n && (int)blockIdx.x >= g.block0[i]) j = i;
-  const GemmParams p = g.p[j];
-  const Epi epi = g.epi[j];
-  const int glocal = (int)blockIdx.x - g.block0[j];
-  const int gsplit = glocal / g.T8[j];
-  const int gbx = glocal - gsplit * g.T8[j];
-  const int gT = g.T[j];
-  if (gbx >= gT) return;  // padding workgroup (block-uniform)
-#define VBX_BX_ gbx
-#define VBX_T_ gT
-#define VBX_SPLIT_ gsplit
-#include "gemm_v2_body.inc"
-#undef VBX_BX_
-#undef VBX_T_
-#undef VBX_SPLIT_
-}
-
 // ---- 160 x 128 tile, 2x2 waves of 80 x 64, ONE workgroup per CU with a 5-slot ring.  For the N = dim GEMMs (to_out,
 // FeedForward-out, the dgrads into the residual width) at M = 8 x 1040 = 8320 rows: 128-row tiles give 65 x 4 = 260 workgroups,
 // i.e. 4 CUs get TWO tiles and the kernel lasts as long as those (FeedForward-out: 37 us for 11.6 GFLOP); 8320 = 52 x 160 gives
@@ -1064,45 +1026,16 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
 }
 
 extern "C" int vbx_gemm_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, void* stream) {
-  VBX_REQUIRE(descs && n >= 1 && n <= GG_MAX, "vbx_gemm_tn_splitk_grouped: 1..%d jobs", GG_MAX);
-  if (vbx_gemm_path() != 1) {
+  VBX_REQUIRE(descs && n >= 1 && n <= 4, "vbx_gemm_tn_splitk_grouped: 1..4 jobs");
+  if (vbx_gemm_path() != 1) {  // one launch of the 256 x 256 tile over all jobs (gemm3.hip)
     const int rc = vbx_gemm3_tn_splitk_grouped(descs, n, (hipStream_t)stream);
     if (rc != VBX_EUNSUPPORTED) return rc;
   }
-  static const int abl = getenv("VBX_GEMM_ABL") ? atoi(getenv("VBX_GEMM_ABL")) : 0;
-  GroupedGemm<EpiSplitK> g;
-  g.n = n;
-  int blocks = 0;
-  for (int i = 0; i < GG_MAX; i++) {
-    const vbx_gemm_desc* d = descs + (i < n ? i : 0);  // unused slots repeat job 0 (never selected)
-    if (i < n) {
-      VBX_REQUIRE(d->mode == VBX_GEMM_TN && d->epilogue == VBX_EPI_SPLITK, "vbx_gemm_tn_splitk_grouped: job %d is not TN / SPLITK", i);
-      VBX_REQUIRE(d->A && d->B && d->C && d->splits >= 1, "vbx_gemm_tn_splitk_grouped: job %d has a null pointer / no splits", i);
-      VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm_tn_splitk_grouped: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
-      VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->N % 8 == 0 && d->M % 8 == 0,
-                  "vbx_gemm_tn_splitk_grouped: lda, ldb, M, N must be multiples of 8");
-    }
-    GemmParams& p = g.p[i];
-    p.A = (const u16*)d->A; p.B = (const u16*)d->B;
-    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
-    p.kchunk = cdiv(cdiv(d->K, d->splits), BK) * BK;  // as vbx_gemm's VBX_EPI_SPLITK case
-    p.tiles_m = cdiv(d->M, BM);
-    p.abl = abl;
-    g.epi[i] = EpiSplitK{(float*)d->C};
-    g.T[i] = p.tiles_m * cdiv(d->N, BN);
-    g.T8[i] = (g.T[i] + 7) & ~7;
-    g.block0[i] = blocks;
-    if (i < n) blocks += g.T8[i] * d->splits;
+  for (int i = 0; i < n; i++) {  // 128-wide kernels: one launch per job
+    VBX_REQUIRE(descs[i].mode == VBX_GEMM_TN && descs[i].epilogue == VBX_EPI_SPLITK, "vbx_gemm_tn_splitk_grouped: job %d is not TN / SPLITK", i);
+    const int rc = vbx_gemm(&descs[i], stream);
+    if (rc) return rc;
   }
-  g.block0[GG_MAX] = blocks;
-  auto kern = gemm_kernel_v2_grouped<1, 1, EpiSplitK, false, 128>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), GEMM2_LDS, (hipStream_t)stream, g);
-  VBX_LAUNCH_CHECK();
   return 0;
 }
 

@@ -15,8 +15,8 @@
 //
 // Hazards of the k-loop (phase numbers global, 4 per k-tile; group G0 = waves 0-3, G1 = waves 4-7, G1 one barrier behind):
 //   G0 runs load(p) in barrier interval 2p and mfma(p) in 2p+1; G1 load(p) in 2p+1 and mfma(p) in 2p+2.
-//   RAW: the region(s) read in phase p+1 are awaited by each wave's counted vmcnt in ITS load(p) (interval 2p for G0, 2p+1 for
-//        G1); every wave has passed that wait before barrier 2p+2, and the reads are issued in load(p+1) = interval 2p+2 / 2p+3.
+//   RAW: a wave's vmcnt wait sits in ITS load(4t+3); every wave has passed it before barrier 8t+8, and the first reads of
+//        k-tile t+1 are issued in load(4t+4) = interval 8t+8 (G0) / 8t+9 (G1).
 //   WAR: fragment reads of phase p are complete (lgkmcnt(0) precedes the MFMAs) before barrier 2p+2 (G0) / 2p+3 (G1); the region
 //        read in phase p is re-staged in phase p+2 or later, i.e. from interval 2p+4 (G0) / 2p+5 (G1) on.
 //   Region read phases within k-tile t: A-lo, B-lo 4t; A-hi 4t+1; B-hi 4t+2.  Re-stage phases: A-hi(t+1) 4t, B-hi(t+1) 4t+1,
@@ -200,8 +200,8 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
   // ---- prologue: k-tile 0 whole, A-lo / B-lo of k-tile 1
   stage(0, 0); stage(0, 2); stage(0, 1); stage(0, 3);
   stage(1, 0); stage(1, 2);
-  // A-lo / B-lo of k-tile 0 must have landed; the four regions issued after them may stay in flight (see G3_DMA_WAIT)
-  if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // k-tile 0 must have landed; A-lo / B-lo of k-tile 1 stay in flight
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -223,16 +223,10 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
     __builtin_amdgcn_sched_barrier(0);                       \
     __builtin_amdgcn_s_setprio(1);                           \
   } while (0)
-// DMA wait of a phase, placed after the phase's own stage(): the region(s) the NEXT phase reads were issued four region-issues
-// earlier (one region = 2 DMA instructions per thread per phase), so 8 younger instructions may stay in flight -- 64 KiB per
-// workgroup at every wait.  (A single wait per k-tile, as first written, left only 32 KiB in flight and gave B-hi two phases of
-// lead; the k-loop then ran at the L2 -> LDS latency, 1293 TFLOP/s at 8192^3.)  In the last two k-tiles fewer regions are
-// issued behind the awaited one: drain.
-#define G3_DMA_WAIT(t)                                                   \
-  do {                                                                   \
-    if ((t) + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                \
-  } while (0)
+// ONE DMA wait per k-tile (phase 3): k-tile t+1 complete, A-lo / B-lo of t+2 (4 instructions) stay in flight.  Tried: a counted
+// wait in every phase with four regions (64 KiB instead of 32 KiB) in flight -- 8192^3 1293 -> 1240 TFLOP/s, grouped wgrads 89 ->
+// 94 us: the k-loop is not bound by load latency but by the L2 -> LDS fill rate (~10 TB/s aggregate: 655 / 870 / 1300 TFLOP/s for
+// the 128^2, 128 x 256 and 256^2 tiles are all 10.2 TB/s times their FLOP per staged byte).
 #define G3_MFMA_END()                     \
   do {                                    \
     __builtin_amdgcn_s_setprio(0);        \
@@ -250,7 +244,6 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
     read_frag<MA, true, Bf, OFF_ALO, 0, 0>(alo[0][0], fa); read_frag<MA, true, Bf, OFF_ALO, 0, 1>(alo[0][1], fa);
     read_frag<MA, true, Bf, OFF_ALO, 1, 0>(alo[1][0], fa); read_frag<MA, true, Bf, OFF_ALO, 1, 1>(alo[1][1], fa);
     stage(t + 1, 1);
-    G3_DMA_WAIT(t);  // A-hi of this k-tile (read in phase 1)
     G3_MFMA_BEGIN();
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
@@ -264,7 +257,6 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
     read_frag<MA, true, Bf, OFF_AHI, 0, 0>(ahi[0][0], fa); read_frag<MA, true, Bf, OFF_AHI, 0, 1>(ahi[0][1], fa);
     read_frag<MA, true, Bf, OFF_AHI, 1, 0>(ahi[1][0], fa); read_frag<MA, true, Bf, OFF_AHI, 1, 1>(ahi[1][1], fa);
     stage(t + 1, 3);
-    G3_DMA_WAIT(t);  // B-hi of this k-tile (read in phase 2)
     G3_MFMA_BEGIN();
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
@@ -289,9 +281,10 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
         for (int j = 0; j < 4; j++)
           acc[2 + i][4 + j] = mfma16<F16>(frag_value<MB>(bq[j][kk]), frag_value<MA>(ahi[i][kk]), acc[2 + i][4 + j]);
     G3_MFMA_END();
-    // ---- phase 3: no reads -> acc[0..1][4..7]; wait for A-lo / B-lo of k-tile t+1 (read in its phase 0)
+    // ---- phase 3: no reads -> acc[0..1][4..7]; wait for k-tile t+1 (A-lo / B-lo of t+2 may stay in flight)
     stage(t + 2, 2);
-    G3_DMA_WAIT(t);
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G3_MFMA_BEGIN();
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
