@@ -7,7 +7,7 @@ on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced re
 ("fetch_bytes_corrected"); WRITE_SIZE is taken as reported.
 MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over all SIMDs (32 per
 v_mfma_f32_32x32x16, 16 per 16x16x32); GRBM_GUI_ACTIVE is the elapsed GPU clock per counter instance.  mfma_util =
-MFMA_BUSY / (1024 SIMDs x mean GRBM_GUI_ACTIVE per instance).  Profiled runs clock lower than un-profiled ones.
+MFMA_BUSY / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD; the CSV row holds the sum over the 8 XCDs).  Profiled runs clock lower than un-profiled ones.
 """
 import collections, csv, glob, json, os, re, sys
 
@@ -37,10 +37,10 @@ def main():
                 a = agg[k][c]
                 a[0] += 1
                 a[1] += v
-                if c == "GRBM_GUI_ACTIVE":
+                if c == "GRBM_GUI_ACTIVE":  # rocprofv3 reports ONE row per dispatch: the sum over the 8 XCDs (19.7 "GHz" otherwise)
                     b = agg[k]["GRBM_GUI_ACTIVE_per_instance"]
                     b[0] += 1
-                    b[1] += v / inst[(d_, k, c)]
+                    b[1] += v / (inst[(d_, k, c)] if inst[(d_, k, c)] > 1 else 8)
             for (d_, k), us in dur.items():
                 a = agg[k]["profiled_us"]
                 a[0] += 1

@@ -41,8 +41,6 @@ def build(force=False, verbose=True):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(src)] + [os.path.getmtime(f) for f in shared]):
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src, "-o", obj]
-        if os.environ.get("VBX_BUILD_EXPERIMENTAL") == "1":  # unmeasured kernels kept out of the default library (attn.hip: v3r)
-            cmd.insert(1, "-DVBX_EXPERIMENTAL_V3R")
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -724,243 +724,13 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
                                                              u16* __restrict__ out, u16* __restrict__ outb,
                                                              float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
-#define VBX_V3_ROLE_HOOK
 #include "attn_fwd_v3_body.inc"
-#undef VBX_V3_ROLE_HOOK
 }
 
-#ifdef VBX_EXPERIMENTAL_V3R
-// ============================================================================ forward, v3r: v3 + a role for the ragged tile
-// EXPERIMENTAL: compiled only with -DVBX_EXPERIMENTAL_V3R (VBX_BUILD_EXPERIMENTAL=1 python build.py) and used only under
-// VBX_ATTN_RAGGED=1; written after the round's GPU time was used up -- not yet run.  (Kept out of the default library because the
-// role is a real function call, the only one in the code object.)  With Np = 1040 every head
-// has a ninth query tile holding only the 16 register tokens.  In v3 that workgroup walks all 17 key tiles behind the shared
-// ring with one active wave: its lifetime is the 17-step DMA -> barrier -> compute chain, and because the 128 such workgroups do
-// not fit the 1024 slots they run as a second round (~15 of the kernel's 64 us).  Here such a workgroup takes another role: the
-// four waves all work on the same 32 query rows but on different key tiles (wave w: tiles w, w+4, ...), each with a PRIVATE
-// single-buffered V tile in its quarter of the 32 KiB ring (K row fragments come straight from global memory), no workgroup
-// barrier inside the loop -- 5 steps instead of 17 -- and the four partial softmax states (m, l, O) are merged through LDS.
-__device__ __noinline__ void attn_fwd_ragged_role(char* smem, const u16* __restrict__ q16, const u16* __restrict__ k16, const u16* __restrict__ vv,
-                                  const uint8_t* __restrict__ mask, u16* __restrict__ out, u16* __restrict__ outb,
-                                  float* __restrict__ lse, int H, int Np, float scale2, int b, int h, int tile) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const long bh = (long)b * H + h;
-  const u16* kbase = k16 + bh * Np * 64;
-  const u16* vbase = vv + bh * Np * 64;
-  const int q0 = tile * 128;  // the same 32 rows for every wave
-  const int ql = lane & 31;
-  const int q = q0 + ql;
-  const int qc = min(q, Np - 1);
-  const int ntiles = (Np + 63) / 64;
-  char* vt = smem + wave * TILE16;  // this wave's V tile, same lane-linear DMA image as dma_tile builds (swz_off2)
-
-  f16x8 qf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
-#pragma unroll
-  for (int t = 0; t < 4; t++) asm volatile("" ::"v"(qf[t]));
-
-  unsigned va[2], va8[2];
-  {
-    const int G = lane >> 4, a16 = lane & 15;
-    const int vrow = 4 * (G >> 1) + (a16 >> 2);
-#pragma unroll
-    for (int db = 0; db < 2; db++) {
-      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
-      va[db] = lds_addr32(vt + swz_off2(vrow, d >> 3) + (d & 7) * 2);
-      va8[db] = lds_addr32(vt + swz_off2(vrow + 8, d >> 3) + (d & 7) * 2);
-    }
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = NEG_INF, l_run = 0.f;
-
-  for (int kt = wave; kt < ntiles; kt += 4) {
-    const int k0 = kt * 64;
-    // V tile kt -> private LDS (8 x 1 KiB per wave); rows past the end re-read the last row (their keys are masked below)
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int sl = i * 64 + lane;
-      const int row = sl >> 3, c = (sl & 7) ^ attn_swz(row);
-      const int gr = min(k0 + row, Np - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (long)gr * 64 + c * 8),
-                                       (__attribute__((address_space(3))) void*)(vt + i * 1024), 16, 0, 0);
-    }
-    // K row fragments of the two 32-key blocks straight from global memory (A operand: key row = lane & 31)
-    f16x8 kf[4], kg[4];
-    {
-      const u16* kr0 = kbase + (long)min(k0 + ql, Np - 1) * 64 + 8 * hi;
-      const u16* kr1 = kbase + (long)min(k0 + 32 + ql, Np - 1) * 64 + 8 * hi;
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        kf[t] = *reinterpret_cast<const f16x8*>(kr0 + 16 * t);
-        kg[t] = *reinterpret_cast<const f16x8*>(kr1 + 16 * t);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K fragments in registers, V tile in LDS (this wave's own DMAs)
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      asm volatile("" ::"v"(kf[t]));
-      asm volatile("" ::"v"(kg[t]));
-    }
-    f32x16 s[2];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { s[0][i] = 0.f; s[1][i] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < 4; t++) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t], qf[t], s[0], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; t++) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kg[t], qf[t], s[1], 0, 0, 0);
-    // V^T fragments of the first 32-key block
-    s16x4 vl[4], vh[4];
-    asm_read_tr<0>(vl[0], vh[0], va[0], va8[0]);
-    asm_read_tr<0>(vl[1], vh[1], va[1], va8[1]);
-    asm_read_tr<2048>(vl[2], vh[2], va[0], va8[0]);
-    asm_read_tr<2048>(vl[3], vh[3], va[1], va8[1]);
-    const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
-    if (need_mask) {
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int kgi = k0 + kb * 32 + acc_row(r, hi);
-          bool ok = kgi < Np;
-          if (ok && mask) ok = mask[(long)b * Np + kgi] != 0;
-          if (!ok) s[kb][r] = NEG_INF;
-        }
-    }
-    float mx = NEG_INF;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale2);
-    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-    const float alpha = fast_exp2(m_run - m_use);
-    float ps = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float pv = fast_exp2(fmaf(s[kb][r], scale2, -m_use));
-        s[kb][r] = pv;
-        ps += pv;
-      }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
-#define VBX_PVR(KB)                                                                                             \
-    {                                                                                                           \
-      const f16x8 p0 = pack_frag_f16_fast(s[KB], 0), p1 = pack_frag_f16_fast(s[KB], 1);                         \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-      f16x8 vf[4];                                                                                              \
-      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                           \
-        const s16x8 tt = {vl[j][0], vl[j][1], vl[j][2], vl[j][3], vh[j][0], vh[j][1], vh[j][2], vh[j][3]};      \
-        vf[j] = __builtin_bit_cast(f16x8, tt);                                                                  \
-      }                                                                                                         \
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], p0, o[0], 0, 0, 0);                                  \
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], p0, o[1], 0, 0, 0);                                  \
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2], p1, o[0], 0, 0, 0);                                  \
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[3], p1, o[1], 0, 0, 0);                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-    }
-    VBX_PVR(0)
-    asm_read_tr<4096>(vl[0], vh[0], va[0], va8[0]);
-    asm_read_tr<4096>(vl[1], vh[1], va[1], va8[1]);
-    asm_read_tr<4096 + 2048>(vl[2], vh[2], va[0], va8[0]);
-    asm_read_tr<4096 + 2048>(vl[3], vh[3], va[1], va8[1]);
-    VBX_PVR(1)
-#undef VBX_PVR
-    // (VBX_PVR waited lgkmcnt(0): every LDS read of this tile has returned before the next DMA overwrites it)
-  }
-
-  // ---- merge the four partial states (wave w: m_w, l_w, O_w over its own keys)
-  const float l_own = l_run + __shfl_xor(l_run, 32, 64);
-  __syncthreads();  // every wave has left its loop: the V tiles (and wave 0's quarter) are free
-  float* stat = reinterpret_cast<float*>(smem);  // [4 waves][m: 32 | l: 32], inside wave 0's quarter
-  if (hi == 0) {
-    stat[wave * 64 + ql] = m_run;
-    stat[wave * 64 + 32 + ql] = l_own;
-  }
-  __syncthreads();
-  float mg = NEG_INF;
-#pragma unroll
-  for (int w = 0; w < 4; w++) mg = fmaxf(mg, stat[w * 64 + ql]);
-  float l_tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const float mw = stat[w * 64 + ql];
-    l_tot += stat[w * 64 + 32 + ql] * ((mw == NEG_INF) ? 0.f : fast_exp2(mw - mg));
-  }
-  const float f_own = (m_run == NEG_INF) ? 0.f : fast_exp2(m_run - mg);
-#pragma unroll
-  for (int i = 0; i < 16; i++) { o[0][i] *= f_own; o[1][i] *= f_own; }
-  if (wave != 0) {  // O_w^T [64 d][32 q] fp32 = 8 KiB into the wave's own quarter (not wave 0's: the stats live there)
-    float* osh = reinterpret_cast<float*>(smem + wave * TILE16);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) osh[(db * 32 + acc_row(r, hi)) * 32 + ql] = o[db][r];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int w = 1; w < 4; w++) {
-    const float* osh = reinterpret_cast<const float*>(smem + w * TILE16);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[db][r] += osh[(db * 32 + acc_row(r, hi)) * 32 + ql];
-  }
-  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-  if (hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (mg + log2f(l_tot)) : 1e30f;
-  // epilogue as in v3 (wave 0's quarter is the staging space; its stats were consumed before the last barrier)
-  char* ost = smem;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int db = 0; db < 2; db++)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      const int d = db * 32 + 8 * g4 + 4 * hi;
-      const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
-                  v3 = o[db][4 * g4 + 3] * inv;
-      const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
-      *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
-      if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-    }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int it = 0; it < 4; it++) {
-    const int row = it * 8 + (lane >> 3), ch = lane & 7;
-    const int qq = q0 + row;
-    if (qq < Np) {
-      const int off = row * 128 + ((ch ^ (row & 7)) << 4);
-      const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
-      *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
-      if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3r(const u16* __restrict__ q16, const u16* __restrict__ k16,
-                                                              const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
-                                                              u16* __restrict__ out, u16* __restrict__ outb,
-                                                              float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
-#define VBX_V3_ROLE_HOOK                                                                                                  \
-  if (co.tile == ((Np + 127) >> 7) - 1 && Np - co.tile * 128 <= 32) { /* block-uniform */                                  \
-    attn_fwd_ragged_role(smem, q16, k16, vv, mask, out, outb, lse, H, Np, scale2, b, h, co.tile);                         \
-    return;                                                                                                               \
-  }
-#include "attn_fwd_v3_body.inc"
-#undef VBX_V3_ROLE_HOOK
-}
-#endif  // VBX_EXPERIMENTAL_V3R
+// (Round 1 wrote a "ragged tile" role for this kernel -- the 128 workgroups per launch whose query tile holds only the 16
+//  register-token rows split their KEYS over the four waves with private tiles straight from global memory.  Round 2 ran it:
+//  correct (tests/test_ops_gpu.py -k attn_fwd), but the 128-forward sample got SLOWER, 349.8 -> 357.1 ms in the same run, so it
+//  was removed.)
 
 // ============================================================================ backward: delta
 // delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d]
@@ -1283,15 +1053,6 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
   if (v3 && !legacy && !abl && !abl2) {
-#ifdef VBX_EXPERIMENTAL_V3R
-    static const bool ragged = getenv("VBX_ATTN_RAGGED") && atoi(getenv("VBX_ATTN_RAGGED")) == 1;  // EXPERIMENTAL, see v3r
-    if (ragged) {
-      hipLaunchKernelGGL(attn_fwd_kernel_v3r, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                         (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
-      VBX_LAUNCH_CHECK();
-      return 0;
-    }
-#endif
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
     VBX_LAUNCH_CHECK();
