@@ -1037,6 +1037,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
   }
 }
 
+// ---- Round-2 experiment, removed after measurement: "v2" backward kernels with 8 waves = two groups of four that work on
+// alternate 32-row blocks of the streamed operand, one barrier interval apart (phase A: softmax VALU + the LDS fragment reads of
+// the next phase; phase B: 16 / 12 MFMAs), tiles by LDS-DMA into a 4-slot ring, zero-page rows instead of masks -- the structure
+// that took the GEMM k-loop (gemm3.hip) from 700 to 1290 TFLOP/s.  Both kernels were correct on the unmasked tests and SLOWER in
+// the train step (same run): dk/dv 117 -> ~163 us, dq 93 -> ~124 us.  Why: (1) 100 KiB of ring means ONE workgroup per CU, so
+// the per-workgroup prologue (per-lane K / V fragments from global, first tiles) and epilogue (merge of the two groups through
+// LDS, fused qk-norm / rotary backward, stores) of 4.5 workgroups per CU run back to back with nothing to overlap them, where v1's
+// two independent workgroups per CU hide each other's; (2) the loop itself cannot be shortened much: every 64-row tile step
+// stages 24 KiB per workgroup, 1152 x 17 x 24 KiB = 480 MB of L2 -> LDS traffic per launch, i.e. ~48 us at the ~10 TB/s fill
+// rate all of this library's LDS-DMA loops top out at (gemm3.hip) -- v1 is within 2-2.4x of that floor, not of the MFMA peak.
+// What would move it: 256 owned rows per workgroup (halves the staged bytes per MFMA; Np = 1040 then wastes 19 % of the slots).
 }  // namespace
 
 static const float LOG2E = 1.4426950408889634f;
