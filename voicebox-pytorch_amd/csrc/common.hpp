@@ -46,16 +46,23 @@ VBX_DEV u16 f32_to_bf16(float f) {  // round-to-nearest-even (NaN preserved)
   return __builtin_bit_cast(u16, b);
 }
 VBX_DEV unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
-// fp16 stores SATURATE at +-65504 (NaN stays NaN): forward GEMM operands are fp16 for their 11-bit mantissa, and an outlier
-// activation of a trained checkpoint (v, the GEGLU output, a normed row times a large gamma) must not turn into inf -- inf * 0 in
-// the next GEMM would poison the whole row.  A clamped outlier is a bounded error instead (tests/test_ops_gpu.py::test_fp16_outputs_saturate).
 VBX_DEV u16 f32_to_f16(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(u16, h);
+}
+// SATURATING fp16 store (+-65504, NaN stays NaN) for the UNBOUNDED forward operands: v, the GEGLU output, the normed rows (a row
+// times a large gamma) and the packed model inputs.  An outlier activation of a trained checkpoint must not turn into inf -- inf * 0
+// in the next GEMM would poison the whole row; a clamped outlier is a bounded error (tests/test_ops_gpu.py::test_fp16_outputs_saturate).
+// q-hat / k-hat (|x| <= 8 gamma by construction) and the attention output (a convex combination of saturated v rows) use the plain
+// conversion: the clamp is four VALU operations per element and measurably slowed the to_qkv epilogue when applied everywhere.
+VBX_DEV u16 f32_to_f16_sat(float f) {
   f = (f > 65504.0f) ? 65504.0f : ((f < -65504.0f) ? -65504.0f : f);
   _Float16 h = (_Float16)f;
   return __builtin_bit_cast(u16, h);
 }
 VBX_DEV float f16_to_f32(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
 VBX_DEV unsigned pack_f16x2(float lo, float hi) { return (unsigned)f32_to_f16(lo) | ((unsigned)f32_to_f16(hi) << 16); }
+VBX_DEV unsigned pack_f16x2_sat(float lo, float hi) { return (unsigned)f32_to_f16_sat(lo) | ((unsigned)f32_to_f16_sat(hi) << 16); }
 
 // ---- wave64 reductions ----------------------------------------------------------------------
 VBX_DEV float wave_sum(float v) {

@@ -20,6 +20,7 @@ typedef f32x4 Acc[4][8];
 
 VBX_DEV uint2 pack4_bf16(const f32x4& v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 VBX_DEV uint2 pack4_f16(const f32x4& v) { return make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])); }
+VBX_DEV uint2 pack4_f16_sat(const f32x4& v) { return make_uint2(pack_f16x2_sat(v[0], v[1]), pack_f16x2_sat(v[2], v[3])); }
 VBX_DEV f32x4 ld4(const float* p) {
   const float4 t = *reinterpret_cast<const float4*>(p);
   return (f32x4){t.x, t.y, t.z, t.w};
@@ -121,7 +122,7 @@ struct Epi3GEGLU {
 #pragma unroll
         for (int r = 0; r < 4; r++) o[r] = gelu_erf(gt[r]) * x[r];
         const long go = (long)gr * ldg + (col0 >> 1) + j * 16 + 4 * g;
-        *reinterpret_cast<uint2*>(G + go) = g_f16 ? pack4_f16(o) : pack4_bf16(o);
+        *reinterpret_cast<uint2*>(G + go) = g_f16 ? pack4_f16_sat(o) : pack4_bf16(o);
         if (Gb) *reinterpret_cast<uint2*>(Gb + go) = pack4_bf16(o);
       }
       if (H1) {
@@ -159,7 +160,7 @@ struct Epi3QKV {
         for (int j = 0; j < 8; j++) {
           const long o = (((long)b * H + hbase + (j >> 2)) * Np + n) * 64 + (j & 3) * 16 + 4 * g;
           if (v) *reinterpret_cast<uint2*>(v + o) = pack4_bf16(acc[i][j]);
-          if (v16) *reinterpret_cast<uint2*>(v16 + o) = pack4_f16(acc[i][j]);
+          if (v16) *reinterpret_cast<uint2*>(v16 + o) = pack4_f16_sat(acc[i][j]);
         }
         continue;
       }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
           const float4 o = make_float4(v[i].x * r * g[i].x + bt[i].x, v[i].y * r * g[i].y + bt[i].y, v[i].z * r * g[i].z + bt[i].z,
                                        v[i].w * r * g[i].w + bt[i].w);
           if (yr) yr[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
-          if (yr16) yr16[c] = make_uint2(pack_f16x2(o.x, o.y), pack_f16x2(o.z, o.w));
+          if (yr16) yr16[c] = make_uint2(pack_f16x2_sat(o.x, o.y), pack_f16x2_sat(o.z, o.w));
           if (y32) reinterpret_cast<float4*>(y32 + ri * D)[c] = o;
         }
       }

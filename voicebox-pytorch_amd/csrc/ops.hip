@@ -22,8 +22,8 @@ VBX_DEV void unpack8_f16(const uint4 p, float v[8]) {
     v[2 * i + 1] = f16_to_f32((u16)(w[i] >> 16));
   }
 }
-VBX_DEV uint4 pack8_h(const float v[8]) {
-  return make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+VBX_DEV uint4 pack8_h(const float v[8]) {  // model inputs / activations: saturating (common.hpp)
+  return make_uint4(pack_f16x2_sat(v[0], v[1]), pack_f16x2_sat(v[2], v[3]), pack_f16x2_sat(v[4], v[5]), pack_f16x2_sat(v[6], v[7]));
 }
 VBX_DEV uint4 pack8(const float v[8]) {
   return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));

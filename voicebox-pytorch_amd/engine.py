@@ -60,6 +60,14 @@ def _rt():
     return l
 
 
+def _u8(mask):
+    """bool mask -> uint8 storage for the kernels: a zero-copy view when possible (the .to(uint8) conversion is a kernel launch
+    per mask per forward)."""
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
 def _check(rc, what):
     if rc != 0:
         raise _lib.VbxError(f"{what} failed (rc={rc}): {_lib.lib().vbx_last_error().decode()}")
@@ -237,10 +245,10 @@ class Engine:
         self.bind_params()
         B, N, D = self.B, self.N, self.cfg["D"]
         x, cond = x.contiguous(), cond.contiguous()
-        cm = cond_mask.to(torch.uint8).contiguous()
+        cm = _u8(cond_mask)
         am = amp = lm = None
         if attn_mask is not None:
-            am = attn_mask.to(torch.uint8).contiguous()
+            am = _u8(attn_mask)
             R = self.cfg["R"]
             amp = torch.cat((torch.ones(B, R, dtype=torch.uint8, device=am.device), am), dim=1).contiguous() if R else am
         io = self.io
@@ -250,7 +258,7 @@ class Engine:
         io.times = times.data_ptr()
         if target is not None:
             target = target.contiguous()
-            lm = loss_mask.to(torch.uint8).contiguous()
+            lm = _u8(loss_mask)
             io.target, io.loss_mask, io.loss = target.data_ptr(), lm.data_ptr(), self.loss.data_ptr()
             pred = None
             io.pred = None
@@ -261,7 +269,7 @@ class Engine:
         if self.cfg.get("E", 0):
             ids, null_id, drop, null_cond = text
             ids = ids.to(torch.int64).contiguous()
-            drop8 = drop.to(torch.uint8).contiguous() if drop is not None else None
+            drop8 = _u8(drop) if drop is not None else None
             null_cond = null_cond.detach().to(torch.float32).contiguous()
             io.cond_ids, io.T, io.null_id = ids.data_ptr(), int(ids.shape[1]), int(null_id)
             io.drop_mask = drop8.data_ptr() if drop8 is not None else None
@@ -281,7 +289,7 @@ class Engine:
         cond = cond.contiguous() if cond is not None else None
         am = amp = None
         if attn_mask is not None:
-            am = attn_mask.to(torch.uint8).contiguous()
+            am = _u8(attn_mask)
             amp = torch.cat((torch.ones(B, R, dtype=torch.uint8, device=am.device), am), dim=1).contiguous() if R else am
         out = torch.empty(B, N, D, dtype=torch.float32, device=self.device)
         io = self.io
