@@ -734,6 +734,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
 
 // ============================================================================ backward: delta
 // delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d]
+// (Round 2 tried folding this pass into the dq kernel's prologue -- the lane already holds half of its query's dO row, the
+//  matching half of O is four more 16-byte loads and one lane^32 exchange.  Correct, and the train step got 0.15 ms SLOWER in the
+//  same run (10.61 -> 10.77 ms): the extra per-lane loads lengthen every dq workgroup's serial prologue by more than the 9 us
+//  launch they replace.  Kept as a separate streaming pass at 4 TB/s.)
 template <bool O_F16>
 __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
                                   int Np, long total_chunks) {
