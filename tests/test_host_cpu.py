@@ -252,3 +252,33 @@ def test_gemm_tile_lds_layout_emulation(tmp_path, which):
     subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:]
+
+
+def test_weights_key_sees_every_kind_of_parameter_write():
+    """ADVICE r1 (high / medium): the packed-operand cache key must change when parameters change through PyTorch (the views have
+    their own version counters) and when native code bumps the epoch; a re-flatten must change flat_gen (cached hipGraphs)."""
+    import voicebox_pytorch_amd as vbx
+
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    fp = vb.flat_params()
+    k0, gen0 = fp.weights_key(), fp.flat_gen
+    opt = torch.optim.SGD(vb.parameters(), lr=0.1)
+    for p in vb.parameters():
+        if p.requires_grad:
+            p.grad = torch.ones_like(p)
+    opt.step()
+    k1 = fp.weights_key()
+    assert k1 != k0
+    vb.load_state_dict(vb.state_dict())
+    k2 = fp.weights_key()
+    assert k2 != k1
+    with torch.no_grad():
+        vb.to_pred.weight.mul_(0.5)
+    k3 = fp.weights_key()
+    assert k3 != k2
+    fp.bump()  # what the native Adam / a broadcast into the flat buffer do
+    assert fp.weights_key() != k3 and fp.flat_gen == gen0
+    assert vb.flat_params() is fp and fp.is_current()
+    vb.double()  # dtype change: the parameters leave the flat buffer -> re-flatten, new generation
+    fp2 = vb.flat_params()
+    assert fp2.flat_gen == gen0 + 1 and fp2.is_current()

@@ -121,11 +121,11 @@ def test_small_golden_eval_and_sample(golden):
             # (a) against the same midpoint solver with the product path's operand precision emulated: tight
             # (chaotic flow: even the rounding mode of the softmax weights -- RTZ on the GPU, RNE in the emulation --
             #  moves a 4-interval sample by ~2.5 %)
-            assert rel(s, emu) < 0.1, (key, use_graph, rel(s, emu))
+            assert rel(s, emu) < 0.07, (key, use_graph, rel(s, emu))  # measured 0.028 (2 intervals) / 0.047 (4 intervals)
             # (b) against the fp32 reference: this random-init, qk-normed net has logits of std ~80 and its flow
             # field is ill-conditioned in its input -- 2 big midpoint steps turn a 2% per-evaluation error
             # (fp16 operands) into ~9% (the emulated CPU oracle shows the same 9.3%); 4 steps: ~4%.
-            assert rel(s, g[key]) < 0.15, (key, use_graph, rel(s, g[key]))
+            assert rel(s, g[key]) < 0.12, (key, use_graph, rel(s, g[key]))  # measured 0.092 / 0.053; benign network: 5e-4 (below)
             print("sample", key, "graph" if use_graph else "eager", "vs emulated", rel(s, emu), "vs reference", rel(s, g[key]))
     # the captured graph must replay identically
     with rng_override(y0=g["y0"]):
@@ -640,20 +640,20 @@ def test_well_conditioned_sampler_is_tight(golden):
     errs = {k: rel(named[k].grad, ref) for k, ref in g["grads"].items()}
     worst = sorted(errs.items(), key=lambda kv: -kv[1])
     print("well-conditioned: cosine", cos, "worst grad rel errors vs REFERENCE", [(k, round(v, 4)) for k, v in worst[:6]])
-    assert cos > 0.999, cos
-    assert worst[0][1] < 5e-2, worst[:6]
+    assert cos > 0.9997, cos          # measured 0.99993
+    assert worst[0][1] < 3e-2, worst[:6]  # measured 1.6 % (register tokens), every tensor against the TRUE reference gradient
     vb.eval()
     with torch.no_grad():
         pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev), cond_drop_prob=0.0)
     print("well-conditioned: pred rel", rel(pred, g["pred"]))
-    assert rel(pred, g["pred"]) < 5e-3
+    assert rel(pred, g["pred"]) < 3e-3   # measured 1.2e-3
     for steps in (3, 5, 9, 17):
         for use_graph in (False, True):
             with rng_override(y0=g["y0"]):
                 s = wrapper.sample(cond=g["cond"].to(dev), steps=steps, use_graph=use_graph)
             e = rel(s, g[f"sample{steps}"])
             print("well-conditioned sample", steps, "graph" if use_graph else "eager", e)
-            assert e < 1e-2, (steps, use_graph, e)
+            assert e < 2e-3, (steps, use_graph, e)  # measured 3.1e-4 .. 5.5e-4 for 2 .. 16 intervals
 
 
 def test_packed_weights_follow_torch_optimizer_and_load_state_dict(golden):
