@@ -1,15 +1,18 @@
-# Round-end check on the GPU box (one gpurun call): full GPU suite, smoke, benches, kernel-trace profile of the train step.
-# Every step is bounded by its own timeout; logs land in gpurun_out/.
-set -x
-R=$GRAFT_REPO_ROOT
-cd $R
-mkdir -p gpurun_out
-timeout 150 python -m pytest tests -m gpu -x -q > gpurun_out/final_pytest.log 2>&1; tail -3 gpurun_out/final_pytest.log
-timeout 60 python __graft_entry__.py --smoke > gpurun_out/final_smoke.log 2>&1; tail -2 gpurun_out/final_smoke.log
-timeout 150 python bench.py > gpurun_out/bench_train_full.log 2>&1; tail -1 gpurun_out/bench_train_full.log > gpurun_out/bench_train.json
-timeout 60 python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_sample.json
-export TMPDIR=/tmp
-cd /tmp
-timeout 90 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof11 -o run -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof11.log 2>&1
-cd $R
-cat gpurun_out/bench_train.json gpurun_out/bench_sample.json
+#!/bin/bash
+# Round-end verification bundle (GPU box): full GPU test suite, smoke, the default bench line (train + sample leg + CPU baseline),
+# the sample-mode and dim-1024 bench lines.   usage: gpurun --timeout 1800 -- 'bash tools/final_check.sh'
+cd $GRAFT_REPO_ROOT; O=gpurun_out/final; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 600 python bench.py > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > $O/r02_bench_train.json; tail -c 600 $O/r02_bench_train.json
+timeout 300 python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_sample.json
+timeout 300 python bench.py --dim 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-sample 2>/dev/null | tail -1 > $O/r02_bench_train_dim1024.json
+python - <<'PY'
+import json
+for n in ("r02_bench_train","r02_bench_sample","r02_bench_train_dim1024"):
+    try:
+        d=json.loads(open(f"gpurun_out/final/{n}.json").read())
+        print(n, d["value"], d["ms_per_step"], d.get("roofline",{}).get("kernel"), d.get("roofline",{}).get("frac"), d.get("sample",{}).get("ms"), (d.get("cpu_baseline") or {}).get("value"))
+    except Exception as e:
+        print(n, "ERR", e)
+PY
