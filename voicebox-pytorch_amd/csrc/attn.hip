@@ -272,24 +272,63 @@ VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratc
 // and run back to back there.  With the plain (tile, h, b) grid the 9 tiles of a head sat on 9 different XCDs and every
 // panel was fetched 8-9x from HBM/MALL (rocprofv3 FETCH_SIZE: 290 MB per forward launch against 51 MB of q|k|v).
 struct AttnCoord { int tile, h, b; bool ok; };
-VBX_DEV AttnCoord attn_coord(int H, int Np, int BH, int xmap) {
-  const int nq = (Np + 127) >> 7;
-  const int id = blockIdx.x;
+// blockIdx -> (128-row tile, head, batch).  The ragged tail tile of every (b, h) (Np % 128 rows: ONE row at the benchmark's
+// Np = 1025) is a workgroup with one active wave that still walks the whole key loop: it lives about as long as a full workgroup
+// (it is bound by the tile round trip, not by throughput) while using a fraction of a CU.  Tails therefore go FIRST, where they
+// overlap with full workgroups; dispatched last they were a 30 us drain phase with the chip empty (tools/attn_timeline.py).
+// xmap bit 0: consecutive ids rotate over the 8 XCDs, all tiles of a (b, h) on one XCD sharing its L2 copy of K / V;
+// bit 1 (A/B): tails last.
+VBX_DEV int attn_tail_ids(int Np, int BH, int xmap) { return (Np & 127) ? ((xmap & 1) ? ((BH + 7) >> 3) * 8 : BH) : 0; }
+VBX_DEV AttnCoord attn_coord_id(int id, int H, int Np, int BH, int xmap) {
+  const int nfull = Np >> 7;
+  const int per_tile = (xmap & 1) ? ((BH + 7) >> 3) * 8 : BH;
+  const int ntail = (Np & 127) ? per_tile : 0;
   AttnCoord c;
   int bh;
-  if (xmap) {
-    const int slot = id >> 3;
-    bh = (slot / nq) * 8 + (id & 7);
-    c.tile = slot % nq;
+  bool tail;
+  if (xmap & 2) {
+    tail = id >= per_tile * nfull;
+    id -= tail ? per_tile * nfull : 0;
   } else {
-    bh = id / nq;
-    c.tile = id - bh * nq;
+    tail = id < ntail;
+    id -= tail ? 0 : ntail;
+  }
+  if (tail) {
+    bh = id;  // == (id >> 3) * 8 + (id & 7)
+    c.tile = nfull;
+  } else if (xmap & 1) {
+    const int slot = id >> 3;
+    bh = (slot / nfull) * 8 + (id & 7);
+    c.tile = slot % nfull;
+  } else {
+    bh = id / nfull;
+    c.tile = id - bh * nfull;
   }
   c.ok = bh < BH;
   c.b = bh / H;
   c.h = bh - c.b * H;
   return c;
 }
+VBX_DEV AttnCoord attn_coord(int H, int Np, int BH, int xmap) { return attn_coord_id(blockIdx.x, H, Np, BH, xmap); }
+
+
+// Diagnostic build only (-DVBX_ATTN_TRACE, tools/build_trace_lib.sh): every workgroup records when it started, when its main loop
+// ended and when it finished (100 MHz s_memrealtime ticks) plus where it ran, for tools/attn_timeline.py.
+#ifdef VBX_ATTN_TRACE
+__device__ unsigned long long* g_attn_trace = nullptr;
+#define ATTN_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long trace_t1 = 0
+#define ATTN_TRACE_LOOP_END() trace_t1 = __builtin_amdgcn_s_memrealtime()
+#define ATTN_TRACE_END(TAG)                                                                                         \
+  if (g_attn_trace && threadIdx.x == 0) {                                                                           \
+    unsigned long long* r = g_attn_trace + ((size_t)((TAG) ? 8192 : 0) + blockIdx.x) * 4; /* [fwd 8192 | bwd 8192] */ \
+    r[0] = trace_t0; r[1] = trace_t1; r[2] = __builtin_amdgcn_s_memrealtime();                                      \
+    r[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)(TAG) << 48); \
+  }
+#else
+#define ATTN_TRACE_BEGIN()
+#define ATTN_TRACE_LOOP_END()
+#define ATTN_TRACE_END(TAG)
+#endif
 
 // ============================================================================ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
@@ -1052,7 +1091,459 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __rest
 // stages 24 KiB per workgroup, 1152 x 17 x 24 KiB = 480 MB of L2 -> LDS traffic per launch, i.e. ~48 us at the ~10 TB/s fill
 // rate all of this library's LDS-DMA loops top out at (gemm3.hip) -- v1 is within 2-2.4x of that floor, not of the MFMA peak.
 // What would move it: 256 owned rows per workgroup (halves the staged bytes per MFMA; Np = 1040 then wastes 19 % of the slots).
+// ============================================================================ backward: dk, dv with an LDS-DMA ring
+// v1's decomposition and serial per-wave order (4 waves x 32 keys, 64-row query tiles, both 32-row blocks of a tile per wave), but
+// the Q16 | Qb | dO tiles and the L / delta rows arrive by LDS-DMA into a 2-slot ring instead of through 48 staging registers:
+// <= 168 VGPRs and 49 KiB of LDS -> THREE workgroups per CU instead of two (1152 workgroups = 1.5 rounds instead of 2.25).
+// An invalid / masked key only affects its own dK / dV row, which is zeroed once after the loop: the loop carries no masks.  All LDS reads
+// are inline asm (a compiler-visible ds_read would make hipcc drain the DMA queue with vmcnt(0) at every read).
+constexpr int D3_SLOT = 3 * TILE16 + 512;  // Q16 | Qb | dO | L[64] | delta[64]
+constexpr int D3_LDS = 2 * D3_SLOT;        // 50176 B
+__device__ const float attn_big_page[4] = {1e30f, 1e30f, 1e30f, 1e30f};  // L of a row past Np
+
+#define D3_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+#define D3_READTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+
+__device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, const u16* __restrict__ q16,
+                                                       const u16* __restrict__ qb16, const u16* __restrict__ k16,
+                                                       const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                       const u16* __restrict__ dout, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, float* __restrict__ dk,
+                                                       u16* __restrict__ dv, int dv_ld, int H, int Np, float scale2, float scale,
+                                                       int BH, int xmap, const QKBwd& fk) {
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const AttnCoord co = attn_coord_id(wg_id, H, Np, BH, xmap);
+  if (!co.ok) return;
+  ATTN_TRACE_BEGIN();
+  const int h = co.h, b = co.b;
+  const long bh = (long)b * H + h;
+  const u16* qbase = q16 + bh * Np * 64;
+  const u16* qbbase = qb16 + bh * Np * 64;
+  const u16* dobase = dout + (long)b * Np * (H * 64) + h * 64;
+  const int key0 = co.tile * 128 + wave * 32;
+  const bool active = key0 < Np;
+  const int key = key0 + (lane & 31);
+  const int keyc = min(key, Np - 1);
+  bool kvalid = key < Np;
+  if (kvalid && mask) kvalid = mask[(long)b * Np + key] != 0;
+  const int ntiles = (Np + 63) / 64;
+
+  f16x8 kf[4];
+  bf16x8 vf[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    kf[t] = *reinterpret_cast<const f16x8*>(k16 + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
+    vf[t] = *reinterpret_cast<const bf16x8*>(vv + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {  // retire the per-lane fragment loads before any LDS-DMA is in flight
+    asm volatile("" ::"v"(kf[t]));
+    asm volatile("" ::"v"(vf[t]));
+  }
+  asm volatile("" ::"v"(kvalid));
+
+  // Rows past Np are clamped to the last row (finite data) and get L = 1e30 from a constant page, so P = exp2(S - 1e30) = 0 and
+  // every contribution of such a row vanishes.  Addresses are uniform base + 32-bit per-thread offset: nothing 64-bit stays live.
+  auto issue = [&](int qt) {  // 2 pieces per thread per tile + the statistics rows (waves 0 / 1)
+    char* slot = smem + (qt & 1) * D3_SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int sidx = i * 256 + tid;
+      const int row = sidx >> 3, c = (sidx & 7) ^ attn_swz(row);
+      const int gr = min(qt * 64 + row, Np - 1);
+      const unsigned oq = (unsigned)(gr * 64 + c * 8) * 2u, od = (unsigned)(gr * (H * 64) + c * 8) * 2u;
+      const char* s0 = reinterpret_cast<const char*>(qbase) + oq;
+      const char* s1 = reinterpret_cast<const char*>(qbbase) + oq;
+      const char* s2 = reinterpret_cast<const char*>(dobase) + od;
+      char* wdst = slot + (i * 256 + wave * 64) * 16;  // wave-uniform; the DMA adds lane * 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)wdst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(wdst + TILE16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2, (__attribute__((address_space(3))) void*)(wdst + 2 * TILE16), 16, 0, 0);
+    }
+    if (wave < 2) {  // wave 0: L, wave 1: delta -- 64 floats, lane-linear
+      const int n = qt * 64 + lane;
+      const float* src = (wave == 0 ? lse : delta) + bh * Np + min(n, Np - 1);
+      if (wave == 0 && n >= Np) src = attn_big_page;
+      char* sdst = slot + 3 * TILE16 + wave * 256;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)sdst, 4, 0, 0);
+    }
+  };
+
+  // per-lane LDS addresses inside slot 0 / block 0 (slot, tile, block, t2, row-group offsets are DS immediates)
+  unsigned ra[4], ta[2], ta8[2], sa;
+  {
+    const int row = lane & 31;
+    const int G = lane >> 4, a16 = lane & 15;
+    const int trow = 4 * (G >> 1) + (a16 >> 2);
+#pragma unroll
+    for (int t = 0; t < 4; t++) ra[t] = lds_addr32(smem + swz_off2(row, 2 * t + hi));
+#pragma unroll
+    for (int db = 0; db < 2; db++) {
+      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
+      ta[db] = lds_addr32(smem + swz_off2(trow, d >> 3) + (d & 7) * 2);
+      ta8[db] = lds_addr32(smem + swz_off2(trow + 8, d >> 3) + (d & 7) * 2);
+    }
+    sa = lds_addr32(smem + 3 * TILE16 + 4 * hi * 4);
+  }
+
+  f32x16 adk[2], adv[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { adk[0][i] = 0.f; adk[1][i] = 0.f; adv[0][i] = 0.f; adv[1][i] = 0.f; }
+
+  issue(0);
+  // one 32-row block QB of the tile in slot SO (both compile time)
+  auto block = [&](auto so_c, auto qb_c) {
+    constexpr int SO = decltype(so_c)::value, QB = decltype(qb_c)::value;
+    constexpr int O = SO + QB * 4096;
+    f32x16 s, dp;
+    {
+      f16x8 qfr[4];
+      D3_READ128(qfr[0], ra[0], O); D3_READ128(qfr[1], ra[1], O); D3_READ128(qfr[2], ra[2], O); D3_READ128(qfr[3], ra[3], O);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 4; t++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr[t], kf[t], s, 0, 0, 0);  // S[q][key] = Q . K^T
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      bf16x8 dofr[4];
+      D3_READ128(dofr[0], ra[0], O + 2 * TILE16); D3_READ128(dofr[1], ra[1], O + 2 * TILE16);
+      D3_READ128(dofr[2], ra[2], O + 2 * TILE16); D3_READ128(dofr[3], ra[3], O + 2 * TILE16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 16; e++) dp[e] = 0.f;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 4; t++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr[t], vf[t], dp, 0, 0, 0);  // dP = dO . V^T
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      f32x4 l4[4];
+      D3_READ128(l4[0], sa, SO + QB * 128); D3_READ128(l4[1], sa, SO + QB * 128 + 32);
+      D3_READ128(l4[2], sa, SO + QB * 128 + 64); D3_READ128(l4[3], sa, SO + QB * 128 + 96);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], scale2, -l4[g4][j]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      f32x4 d4[4];
+      D3_READ128(d4[0], sa, SO + QB * 128 + 256); D3_READ128(d4[1], sa, SO + QB * 128 + 288);
+      D3_READ128(d4[2], sa, SO + QB * 128 + 320); D3_READ128(d4[3], sa, SO + QB * 128 + 352);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) dp[4 * g4 + j] = s[4 * g4 + j] * (dp[4 * g4 + j] - d4[g4][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 pf[2], dsf[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++) {
+      pf[t2] = pack_frag(s, t2);
+      dsf[t2] = pack_frag(dp, t2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    s16x4 tl[4], th[4];  // transposed dO / Qb fragments of rows +0..15 (t2 = 0)
+    D3_READTR(tl[0], ta[0], O + 2 * TILE16); D3_READTR(th[0], ta8[0], O + 2 * TILE16);
+    D3_READTR(tl[1], ta[1], O + 2 * TILE16); D3_READTR(th[1], ta8[1], O + 2 * TILE16);
+    D3_READTR(tl[2], ta[0], O + TILE16); D3_READTR(th[2], ta8[0], O + TILE16);
+    D3_READTR(tl[3], ta[1], O + TILE16); D3_READTR(th[3], ta8[1], O + TILE16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const s16x8 v8 = {tl[j][0], tl[j][1], tl[j][2], tl[j][3], th[j][0], th[j][1], th[j][2], th[j][3]};
+      fr[j] = __builtin_bit_cast(bf16x8, v8);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    adv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], pf[0], adv[0], 0, 0, 0);
+    adk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2], dsf[0], adk[0], 0, 0, 0);
+    adv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1], pf[0], adv[1], 0, 0, 0);
+    adk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[3], dsf[0], adk[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // rows +16..31 (t2 = 1): 2048 bytes further, same swizzle phase
+    D3_READTR(tl[0], ta[0], O + 2 * TILE16 + 2048); D3_READTR(th[0], ta8[0], O + 2 * TILE16 + 2048);
+    D3_READTR(tl[1], ta[1], O + 2 * TILE16 + 2048); D3_READTR(th[1], ta8[1], O + 2 * TILE16 + 2048);
+    D3_READTR(tl[2], ta[0], O + TILE16 + 2048); D3_READTR(th[2], ta8[0], O + TILE16 + 2048);
+    D3_READTR(tl[3], ta[1], O + TILE16 + 2048); D3_READTR(th[3], ta8[1], O + TILE16 + 2048);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const s16x8 v8 = {tl[j][0], tl[j][1], tl[j][2], tl[j][3], th[j][0], th[j][1], th[j][2], th[j][3]};
+      fr[j] = __builtin_bit_cast(bf16x8, v8);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    adv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], pf[1], adv[0], 0, 0, 0);
+    adk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2], dsf[1], adk[0], 0, 0, 0);
+    adv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1], pf[1], adv[1], 0, 0, 0);
+    adk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[3], dsf[1], adk[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto step = [&](auto so_c, int qt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of tile qt have landed
+    __builtin_amdgcn_s_barrier();                     // tile qt visible to all; everyone is done with tile qt-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (qt + 1 < ntiles) issue(qt + 1);
+    if (!active) return;
+    block(so_c, std::integral_constant<int, 0>{});
+    if (qt * 64 + 32 < Np) block(so_c, std::integral_constant<int, 1>{});
+  };
+  for (int qt = 0; qt < ntiles; qt += 2) {
+    step(std::integral_constant<int, 0>{}, qt);
+    if (qt + 1 < ntiles) step(std::integral_constant<int, D3_SLOT>{}, qt + 1);
+  }
+  __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
+  ATTN_TRACE_LOOP_END();
+
+  if (active && !kvalid) {  // out-of-range or masked key: its softmax weight is 0 for every query
+#pragma unroll
+    for (int e = 0; e < 16; e++) { adk[0][e] = 0.f; adk[1][e] = 0.f; adv[0][e] = 0.f; adv[1][e] = 0.f; }
+  }
+  if (fk.dqkv)  // fused rotary + qk-norm backward of dk (all waves: it ends with workgroup barriers)
+    store_rows_qknorm(smem + wave * 12288, reinterpret_cast<float*>(smem + 4 * 12288), adk, scale, fk, active, b, h, H, co.tile,
+                      (Np + 127) >> 7, key0, Np, lane, wave);
+  if (active) {
+    char* wst = smem + wave * 12288;  // 8 KiB fp32 dk block | 4 KiB bf16 dv block
+    if (!fk.dqkv) store_rows_f32(wst, adk, scale, dk + bh * Np * 64, key0, Np, lane);
+    char* vst = wst + 8192;
+    const int kl = lane & 31;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int d = db * 32 + 8 * g4 + 4 * hi;
+        *reinterpret_cast<uint2*>(vst + kl * 128 + (((d >> 3) ^ (kl & 7)) << 4) + (d & 7) * 2) =
+            make_uint2(pack_bf16x2(adv[db][4 * g4 + 0], adv[db][4 * g4 + 1]), pack_bf16x2(adv[db][4 * g4 + 2], adv[db][4 * g4 + 3]));
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      if (key0 + row < Np)
+        *reinterpret_cast<uint4*>(dv + ((long)b * Np + key0 + row) * dv_ld + h * 64 + ch * 8) =
+            *reinterpret_cast<const uint4*>(vst + row * 128 + ((ch ^ (row & 7)) << 4));
+    }
+  }
+  ATTN_TRACE_END(2);
+}
+
+// ---------------------------------------------------------------------------- backward: dq with the same ring
+// v1's decomposition (4 waves x 32 queries, 64-key tiles of K16 | Kb | V) with LDS-DMA staging and asm fragment reads: no staging
+// registers -> three workgroups per CU.  Key masks (user mask / keys past Np) are applied per element only in tiles that need them,
+// exactly as the forward does.
+constexpr int Q3_SLOT = 3 * TILE16;
+__device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, int wg_id, const u16* __restrict__ q16,
+                                                     const u16* __restrict__ k16, const u16* __restrict__ kb16,
+                                                     const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                     const u16* __restrict__ dout, const float* __restrict__ lse,
+                                                     const float* __restrict__ delta, float* __restrict__ dq, int H, int Np,
+                                                     float scale2, float scale, int BH, int xmap, const QKBwd& fq) {
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const AttnCoord co = attn_coord_id(wg_id, H, Np, BH, xmap);
+  if (!co.ok) return;
+  ATTN_TRACE_BEGIN();
+  const int h = co.h, b = co.b;
+  const long bh = (long)b * H + h;
+  const u16* kbase = k16 + bh * Np * 64;
+  const u16* kbbase = kb16 + bh * Np * 64;
+  const u16* vbase = vv + bh * Np * 64;
+  const int q0 = co.tile * 128 + wave * 32;
+  const bool active = q0 < Np;
+  const int q = q0 + (lane & 31);
+  const int qc = min(q, Np - 1);
+  const int ntiles = (Np + 63) / 64;
+
+  f16x8 qf[4];
+  bf16x8 dof[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
+    dof[t] = *reinterpret_cast<const bf16x8*>(dout + ((long)b * Np + qc) * (H * 64) + h * 64 + 16 * t + 8 * hi);
+  }
+  const float L2 = lse[bh * Np + qc];
+  const float dlt = delta[bh * Np + qc];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {  // retire the per-lane loads before any LDS-DMA is in flight
+    asm volatile("" ::"v"(qf[t]));
+    asm volatile("" ::"v"(dof[t]));
+  }
+  asm volatile("" ::"v"(L2), "v"(dlt));
+
+  auto issue = [&](int kt) {
+    char* slot = smem + (kt & 1) * Q3_SLOT;
+    dma_tile(slot, kbase, kt * 64, Np, tid);
+    dma_tile(slot + TILE16, kbbase, kt * 64, Np, tid);
+    dma_tile(slot + 2 * TILE16, vbase, kt * 64, Np, tid);
+  };
+  issue(0);
+
+  unsigned ra[4], ta[2], ta8[2];
+  {
+    const int row = lane & 31;
+    const int G = lane >> 4, a16 = lane & 15;
+    const int trow = 4 * (G >> 1) + (a16 >> 2);
+#pragma unroll
+    for (int t = 0; t < 4; t++) ra[t] = lds_addr32(smem + swz_off2(row, 2 * t + hi));
+#pragma unroll
+    for (int db = 0; db < 2; db++) {
+      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
+      ta[db] = lds_addr32(smem + TILE16 + swz_off2(trow, d >> 3) + (d & 7) * 2);
+      ta8[db] = lds_addr32(smem + TILE16 + swz_off2(trow + 8, d >> 3) + (d & 7) * 2);
+    }
+  }
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  auto block = [&](auto so_c, auto kb_c, int k0, bool need_mask) {
+    constexpr int SO = decltype(so_c)::value, KB = decltype(kb_c)::value;
+    constexpr int O = SO + KB * 4096;
+    f32x16 s, dp;
+    f16x8 kfr[4];
+    bf16x8 vfr[4];
+    D3_READ128(kfr[0], ra[0], O); D3_READ128(kfr[1], ra[1], O); D3_READ128(kfr[2], ra[2], O); D3_READ128(kfr[3], ra[3], O);
+    D3_READ128(vfr[0], ra[0], O + 2 * TILE16); D3_READ128(vfr[1], ra[1], O + 2 * TILE16);
+    D3_READ128(vfr[2], ra[2], O + 2 * TILE16); D3_READ128(vfr[3], ra[3], O + 2 * TILE16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) { s[e] = 0.f; dp[e] = 0.f; }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // S[key][q] = K . Q^T ; dP[key][q] = V . dO^T   (two independent chains)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[t], qf[t], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[t], dof[t], dp, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // Kb^T fragments of keys +0..15: requested now, they land while the VALU block runs
+    s16x4 tl[4], th[4];
+    D3_READTR(tl[0], ta[0], O); D3_READTR(th[0], ta8[0], O);
+    D3_READTR(tl[1], ta[1], O); D3_READTR(th[1], ta8[1], O);
+    D3_READTR(tl[2], ta[0], O + 2048); D3_READTR(th[2], ta8[0], O + 2048);
+    D3_READTR(tl[3], ta[1], O + 2048); D3_READTR(th[3], ta8[1], O + 2048);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float pv = fast_exp2(fmaf(s[r], scale2, -L2));
+      if (need_mask) {
+        const int kg = k0 + KB * 32 + acc_row(r, hi);
+        bool ok = kg < Np;
+        if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
+        if (!ok) pv = 0.f;
+      }
+      s[r] = pv * (dp[r] - dlt);
+    }
+    const bf16x8 ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const s16x8 v8 = {tl[j][0], tl[j][1], tl[j][2], tl[j][3], th[j][0], th[j][1], th[j][2], th[j][3]};
+      fr[j] = __builtin_bit_cast(bf16x8, v8);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], ds0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1], ds0, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2], ds1, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[3], ds1, acc[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto step = [&](auto so_c, int kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                     // tile kt visible to all; everyone is done with tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < ntiles) issue(kt + 1);
+    if (!active) return;
+    const int k0 = kt * 64;
+    const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
+    block(so_c, std::integral_constant<int, 0>{}, k0, need_mask);
+    if (k0 + 32 < Np) block(so_c, std::integral_constant<int, 1>{}, k0, need_mask);
+  };
+  for (int kt = 0; kt < ntiles; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < ntiles) step(std::integral_constant<int, Q3_SLOT>{}, kt + 1);
+  }
+  __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
+  ATTN_TRACE_LOOP_END();
+
+  if (fq.dqkv) {  // fused rotary + qk-norm backward -> bf16 d(qkv); the red scratch sits behind the four 8 KiB wave blocks
+    store_rows_qknorm(smem + wave * 8192, reinterpret_cast<float*>(smem + 4 * 8192), acc, scale, fq, active, b, h, H, co.tile,
+                      (Np + 127) >> 7, q0, Np, lane, wave);
+    ATTN_TRACE_END(1);
+    return;
+  }
+  if (active) store_rows_f32(smem + wave * 8192, acc, scale, dq + bh * Np * 64, q0, Np, lane);
+  ATTN_TRACE_END(1);
+}
+
+// dq and dk/dv depend on the same inputs and not on each other: ONE launch carries both grids, so the chip goes through one
+// drain phase (the last, partly filled round of workgroups) instead of two.  role: 0 both, 1 dq only, 2 dk/dv only (A/B, tests).
+struct AttnBwdArgs {
+  const u16 *q16, *k16, *qb16, *kb16, *vv, *dout;
+  const uint8_t* mask;
+  const float *lse, *delta;
+  float *dq, *dk;
+  u16* dv;
+  int dv_ld, H, Np, BH, xmap, grid_one, role;
+  float scale2, scale;
+  QKBwd fq, fk;
+};
+constexpr int BWD_DMA_LDS = D3_LDS > 2 * Q3_SLOT ? D3_LDS : 2 * Q3_SLOT;
+__global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int id = blockIdx.x, role;
+  if (a.role) {
+    role = a.role == 1;
+  } else {  // launch order: tails of both roles, dk/dv full tiles (the longer ones), dq full tiles
+    const int T = attn_tail_ids(a.Np, a.BH, a.xmap), F = a.grid_one - T;
+    if (a.xmap & 2) {  // A/B: tails last
+      if (id < 2 * F) { role = id >= F; id -= role * F; }
+      else { id -= 2 * F; role = id >= T; id += F - role * T; }
+    } else if (id < 2 * T) {
+      role = id >= T;
+      id -= role * T;
+    } else {
+      id -= 2 * T;
+      role = id >= F;
+      id += T - role * F;
+    }
+  }
+  if (role)
+    attn_bwd_dq_dma_body(smem, id, a.q16, a.k16, a.kb16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dq, a.H, a.Np, a.scale2, a.scale,
+                         a.BH, a.xmap, a.fq);
+  else
+    attn_bwd_dkdv_dma_body(smem, id, a.q16, a.qb16, a.k16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dk, a.dv, a.dv_ld, a.H, a.Np,
+                           a.scale2, a.scale, a.BH, a.xmap, a.fk);
+}
+
 }  // namespace
+
+#ifdef VBX_ATTN_TRACE
+extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf = [2][8192][4] u64 (forward | backward launches, by blockIdx), null to stop
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static const float LOG2E = 1.4426950408889634f;
 
@@ -1062,7 +1553,7 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
   static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;  // 0: A/B against the plain tile order
   const int BH = B * H;
-  dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
+  dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
   static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
@@ -1106,6 +1597,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     attr = true;
   }
   const long chunks = (long)B * Np * H * 8;
@@ -1118,13 +1610,36 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   VBX_LAUNCH_CHECK();
   static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;
   const int BH = B * H;
-  dim3 grid(cdiv(Np, 128) * (xmap ? cdiv(BH, 8) * 8 : BH));
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
-                     (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap, fq);
+  dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
+  // VBX_ATTN_BWD_DMA: 0 = round-1 kernels (register-staged tiles, two launches); 1 / 2 = only dq / only dk,dv on the LDS-DMA ring
+  // (separate launches); 3 = both on the ring, separate launches; 4 = both in ONE launch.
+  static const int bwd_dma = getenv("VBX_ATTN_BWD_DMA") ? atoi(getenv("VBX_ATTN_BWD_DMA")) : 4;
+  AttnBwdArgs a;
+  a.q16 = (const u16*)q16; a.k16 = (const u16*)k16; a.qb16 = (const u16*)qb; a.kb16 = (const u16*)kb; a.vv = (const u16*)v;
+  a.dout = (const u16*)dout; a.mask = mask; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = (u16*)dv; a.dv_ld = dv_ld;
+  a.H = H; a.Np = Np; a.BH = BH; a.xmap = xmap; a.grid_one = (int)grid.x; a.scale2 = scale * LOG2E; a.scale = scale; a.fq = fq; a.fk = fk;
+  if (bwd_dma == 4) {
+    a.role = 0;
+    hipLaunchKernelGGL(attn_bwd_kernel_dma, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (bwd_dma & 1) {
+    a.role = 1;
+    hipLaunchKernelGGL(attn_bwd_kernel_dma, grid, dim3(256), BWD_DMA_LDS, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
+                       (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap, fq);
+  }
   VBX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
-                     (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
-                     scale * LOG2E, scale, BH, xmap, fk);
+  if (bwd_dma & 2) {
+    a.role = 2;
+    hipLaunchKernelGGL(attn_bwd_kernel_dma, grid, dim3(256), BWD_DMA_LDS, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
+                       (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
+                       scale * LOG2E, scale, BH, xmap, fk);
+  }
   VBX_LAUNCH_CHECK();
   return 0;
 }
