@@ -64,6 +64,18 @@ VBX_DEV float f16_to_f32(u16 v) { return (float)__builtin_bit_cast(_Float16, v);
 VBX_DEV unsigned pack_f16x2(float lo, float hi) { return (unsigned)f32_to_f16(lo) | ((unsigned)f32_to_f16(hi) << 16); }
 VBX_DEV unsigned pack_f16x2_sat(float lo, float hi) { return (unsigned)f32_to_f16_sat(lo) | ((unsigned)f32_to_f16_sat(hi) << 16); }
 
+// Start-phase stagger (experiment, VBX_GEMM_STAGGER=<us>): workgroups that become co-resident on a CU at launch run their
+// k-loops and their epilogues in lockstep -- the matrix pipes idle while every CU stores and the memory system idles while every
+// CU multiplies (tools/native/gemm_trace.cpp).  Delaying the workgroups of launch slot s (blockIdx / #CUs) by s * ticks (100 MHz
+// s_memrealtime units) puts the co-residents out of phase; later workgroups inherit the phase of the slot they take over.
+VBX_DEV void stagger_wait(int slot, int ticks) {
+  if (slot > 0 && ticks > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long d = (unsigned long long)slot * (unsigned)ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 // ---- wave64 reductions ----------------------------------------------------------------------
 VBX_DEV float wave_sum(float v) {
 #pragma unroll

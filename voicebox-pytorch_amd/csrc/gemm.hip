@@ -91,6 +91,7 @@ struct GemmParams {
   int tiles_m;
   int abl;     // timing ablations (tools only; results are wrong when != 0): 1 no DMA, 2 no LDS reads, 4 no barrier,
                // 8/16 linear A/B sources, 32 no epilogue functor, 64 no epilogue at all
+  int stagger; // start-phase stagger of co-resident workgroups in 10 ns ticks (common.hpp::stagger_wait); 0 = off
 };
 
 // 16x16x32 MFMA on raw 16-bit fragments: bf16 (default) or fp16 (the q/k projection: 11-bit mantissa)
@@ -289,6 +290,7 @@ struct FragPlan {
 template <int MA, int MB, class Epi, bool F16, int BM_>
 __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.stagger && gridDim.y == 1 && blockIdx.x < 768) stagger_wait(blockIdx.x >> 8, p.stagger);  // 3 workgroups per CU
 #define VBX_BX_ blockIdx.x
 #define VBX_T_ gridDim.x
 #define VBX_SPLIT_ blockIdx.y
@@ -949,9 +951,11 @@ extern "C" int vbx_gemm_select(int path) {
 }
 // Which tile serves a descriptor.  Automatic choice (measured in situ on the model's shapes, bench.py's stage table):
 //  * the layer's four split-K weight gradients run as ONE grouped gemm3 launch (runtime.hip): 92 us against 4 x 38 us;
-//  * NT / NN GEMMs stay on the 128-wide kernels: at K = dim = 512 the wide GEMMs are bound by their output stores and by the
-//    L2 -> LDS fill rate, and neither the 256 x 256 tile (one workgroup per CU: k-loop and epilogue alternate) nor the
-//    128 x 256 tile (two per CU) beat the three-per-CU 128 x 128 kernel there; the N = dim GEMMs have too few wide tiles.
+//  * the other NT / NN GEMMs stay on the 128-wide kernels except the two cases below: at K = dim = 512 a tile's k-loop
+//    (12-14 us for 256 x 256) is followed by a VALU-bound epilogue of the same order (qk-norm + rotary 10-13 us, GEGLU 5.5 us:
+//    tools/native/gemm_trace.cpp) during which the matrix pipes idle; three independent 128 x 128 workgroups per CU overlap the
+//    two phases better than one 256 x 256 or two lock-stepped 128 x 256 workgroups (a start-phase stagger of the co-resident
+//    workgroups, VBX_GEMM_STAGGER, did not help either); the N = dim GEMMs have too few wide tiles.
 //    Paths 2 / 3 force them for measurements (tools/native/gemm3_check).
 static int gemm_tile_for(const vbx_gemm_desc* d) {
   const int path = vbx_gemm_path();
@@ -962,6 +966,14 @@ static int gemm_tile_for(const vbx_gemm_desc* d) {
   // one wide GEMM where the 128 x 256 two-per-CU tile wins: 34.1 us against 40.7 us back to back.  VBX_GEMM4_FFIN=0: A/B.
   static const bool ffin4 = !(getenv("VBX_GEMM4_FFIN") && atoi(getenv("VBX_GEMM4_FFIN")) == 0);
   if (ffin4 && d->epilogue == VBX_EPI_GEGLU && d->mode == VBX_GEMM_NT && !d->C2 && !d->C3 &&
+      (long)cdiv(d->M, 128) * cdiv(d->N, 256) >= 256)
+    return 4;
+  // The K = dim dgrads into wide outputs (NN, plain bf16 epilogue: the to_out and FeedForward-out dgrads, N = 1024 / 1408) run on
+  // the 128 x 256 tile since its epilogue stores whole rows through LDS (gemm_epi3.hpp): in the train step 24.8 -> 21.9 us and
+  // 26.9 -> 25.6 us per launch, step 10.60 -> 10.48 ms in the same run.  VBX_GEMM4_DGRAD=0: A/B.  (The training FeedForward-in
+  // on the same tile: 55.5 vs 55.7 us -- no change, it stays on the 128-wide kernel.)
+  static const bool dgrad4 = !(getenv("VBX_GEMM4_DGRAD") && atoi(getenv("VBX_GEMM4_DGRAD")) == 0);
+  if (dgrad4 && d->epilogue == VBX_EPI_BF16 && d->mode == VBX_GEMM_NN && d->K <= 512 &&
       (long)cdiv(d->M, 128) * cdiv(d->N, 256) >= 256)
     return 4;
   // (Tried: gemm3 for K >= 1024 with >= 256 tiles -- the dim-1024 model's to_qkv / FeedForward-in / FeedForward dgrad.  Back to
@@ -986,6 +998,8 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   p.kchunk = d->K; p.tiles_m = cdiv(d->M, BM);
   static const int abl = getenv("VBX_GEMM_ABL") ? atoi(getenv("VBX_GEMM_ABL")) : 0;
   p.abl = abl;
+  static const int stagger = getenv("VBX_GEMM_STAGGER") ? (int)(atof(getenv("VBX_GEMM_STAGGER")) * 100.0) : 0;
+  p.stagger = stagger;
   if (d->mode == VBX_GEMM_NT) VBX_REQUIRE(d->K % 8 == 0, "vbx_gemm NT: K must be a multiple of 8");
   if (d->mode == VBX_GEMM_TN) VBX_REQUIRE(d->M % 8 == 0, "vbx_gemm TN: M must be a multiple of 8");
 

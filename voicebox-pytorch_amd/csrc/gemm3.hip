@@ -42,6 +42,13 @@ struct G3Params {
 };
 
 __device__ uint4 g3_zero_page[4];  // source of out-of-range DMA lanes
+}  // namespace
+#ifdef VBX_GEMM_TRACE
+extern "C" int vbx_debug_gemm3_trace(void* buf) {  // diagnostic build only: buf = [workgroups][5] u64, null to stop
+  return hipMemcpyToSymbol(HIP_SYMBOL(gepi::g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+namespace {
 
 // ---------------------------------------------------------------------------------------------------------------- staging
 // One operand's LDS-DMA sources.  All four pieces a thread issues per k-tile and region pair (q = 0,1 x lo,hi) derive from ONE
@@ -155,6 +162,7 @@ VBX_DEV int xcd_chunk_order(int bid, int T) {
 // one 256 x 256 output tile: `lin` = tile index (n fastest) of this GEMM, `split` = its K split
 template <int MA, int MB, class Epi, bool F16>
 VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int split) {
+  GEMM_TRACE_DECL();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -204,6 +212,7 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
   if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  GEMM_TRACE_MARK(gtr1);
   __builtin_amdgcn_sched_barrier(0);
   if (g1) __builtin_amdgcn_s_barrier();  // stagger: G1's phases start one barrier interval after G0's
   __builtin_amdgcn_sched_barrier(0);
@@ -304,7 +313,9 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
   if (!g1) __builtin_amdgcn_s_barrier();  // pairs with G1's extra barrier: every wave has executed the same number
   __builtin_amdgcn_sched_barrier(0);
 
-  epi(acc, m0 + wr * 32, n0 + wc * 128, lane, split, p.M, p.N, 128);
+  GEMM_TRACE_MARK(gtr2);
+  epi(acc, m0 + wr * 32, n0 + wc * 128, lane, split, p.M, p.N, 128, lds_u32(smem + wave * EPI_STAGE_BYTES));
+  GEMM_TRACE_END();
 }
 
 template <int MA, int MB, class Epi, bool F16>

@@ -26,9 +26,17 @@ struct G4Params {
   const u16* B;
   int M, N, K;
   long lda, ldb;
+  int stagger;  // start-phase stagger of the second workgroup per CU in 10 ns ticks (common.hpp::stagger_wait); 0 = off
 };
 
 __device__ uint4 g4_zero_page[4];
+}  // namespace
+#ifdef VBX_GEMM_TRACE
+extern "C" int vbx_debug_gemm4_trace(void* buf) {  // diagnostic build only: buf = [workgroups][5] u64, null to stop
+  return hipMemcpyToSymbol(HIP_SYMBOL(gepi::g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+namespace {
 
 // LDS-DMA sources of one operand.  K-contiguous: piece q covers rows +64q of the stage (A: q < 2, B: q < 4).
 // K-strided: per 128-wide image two pieces (k rows +16); B has two images (columns +128).
@@ -107,6 +115,8 @@ struct Frag4 {
 template <int MA, int MB, class Epi, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm4_kernel(G4Params p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GEMM_TRACE_DECL();
+  if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512) stagger_wait(1, p.stagger);  // 2 workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -177,7 +187,12 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(G4Params p, Epi epi) {
     if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
     if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
   }
-  epi(acc, m0 + wr * 64, n0 + wc * 128, lane, 0, p.M, p.N, 32);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the epilogues' row-staging space
+  __builtin_amdgcn_sched_barrier(0);
+  GEMM_TRACE_MARK(gtr2);
+  epi(acc, m0 + wr * 64, n0 + wc * 128, lane, 0, p.M, p.N, 32, lds_u32(smem + wave * EPI_STAGE_BYTES));
+  GEMM_TRACE_END();
 }
 
 template <int MA, int MB, bool F16 = false, class Epi>
@@ -204,7 +219,8 @@ int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return VBX_EUNSUPPORTED;
   if (d->lda % 8 || d->ldb % 8 || d->N % 8 || d->K % 8) return VBX_EUNSUPPORTED;
   if (d->mode != VBX_GEMM_NT && d->mode != VBX_GEMM_NN) return VBX_EUNSUPPORTED;
-  G4Params p{(const u16*)d->A, (const u16*)d->B, d->M, d->N, d->K, d->lda, d->ldb};
+  static const int stagger = getenv("VBX_GEMM_STAGGER") ? (int)(atof(getenv("VBX_GEMM_STAGGER")) * 100.0) : 0;
+  G4Params p{(const u16*)d->A, (const u16*)d->B, d->M, d->N, d->K, d->lda, d->ldb, stagger};
   switch (d->epilogue) {
     case VBX_EPI_BF16: {
       if (!d->C || d->ldc % 8) return VBX_EUNSUPPORTED;

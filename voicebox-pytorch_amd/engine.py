@@ -177,8 +177,11 @@ class Engine:
     """One (batch, frames, training) configuration of a VoiceBox on one GPU: owns the packed-weight and
     activation arenas and issues the native stage calls on the current HIP stream."""
 
-    def __init__(self, cfg, flat: FlatParams, B, N, training, device):
+    def __init__(self, cfg, flat: FlatParams, B, N, training, device, wpack_from=None):
+        """wpack_from: another Engine of the same model whose packed-weight arena this one shares (the arena depends on the
+        architecture only): the concurrent half-batch engines of the sampler keep ONE copy of the operand weights."""
         self.cfg, self.fp, self.B, self.N, self.training, self.device = cfg, flat, B, N, bool(training), device
+        self.wpack_owner = wpack_from
         _lib.call("vbx_check_device", device.index if device.index is not None else torch.cuda.current_device())
         l = _rt()
         m = VbxModel()
@@ -196,7 +199,11 @@ class Engine:
         self.rot_cos, self.rot_sin = rotary_tables(N, cfg["R"], 64, cfg["theta"], device)
         m.rot_cos, m.rot_sin = self.rot_cos.data_ptr(), self.rot_sin.data_ptr()
         self.m = m
-        self.wpack = torch.empty(l.vbx_model_wpack_bytes(C.byref(m)), dtype=torch.uint8, device=device)
+        if wpack_from is not None:
+            assert wpack_from.wpack.numel() == l.vbx_model_wpack_bytes(C.byref(m)) and wpack_from.fp is flat
+            self.wpack = wpack_from.wpack
+        else:
+            self.wpack = torch.empty(l.vbx_model_wpack_bytes(C.byref(m)), dtype=torch.uint8, device=device)
         self.act = torch.empty(l.vbx_model_act_bytes(C.byref(m)), dtype=torch.uint8, device=device)
         m.wpack, m.act = self.wpack.data_ptr(), self.act.data_ptr()
         self.packed_version = None
@@ -209,6 +216,9 @@ class Engine:
     def bind_params(self):
         flat = self.fp.flat
         self.m.params = flat.data_ptr()
+        if self.wpack_owner is not None:  # shared arena: its owner packs
+            self.wpack_owner.bind_params()
+            return
         key = self.fp.weights_key()
         if key != self.packed_version:
             _check(_rt().vbx_model_pack_weights(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights")

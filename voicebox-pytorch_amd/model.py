@@ -398,18 +398,22 @@ class VoiceBox(nn.Module):
             self._engines.clear()
         return self._flat
 
-    def engine(self, B, N, training):
+    def engine(self, B, N, training, slot=0, wpack_from=None):
+        """slot > 0: a further engine (own activation arena) for the same shape -- the sampler integrates the halves of a
+        batch concurrently on two streams."""
         fp = self.flat_params()
         dev = fp.flat.device
         if dev.type != "cuda":
             raise _lib.VbxError("VoiceBox compute runs only on an MI355X (gfx950) through libvbx_hip.so; "
                                 f"parameters are on '{dev}' and there is no CPU fallback")
-        key = (B, N, bool(training))
+        key = (B, N, bool(training)) if slot == 0 else (B, N, bool(training), slot)
         eng = self._engines.get(key)
+        if eng is not None and eng.wpack_owner is not wpack_from:
+            eng = None
         if eng is None:
-            if len(self._engines) >= 4:  # arenas are large: keep a few shapes only
-                self._engines.pop(next(iter(self._engines)))
-            eng = Engine(self._cfg, fp, B, N, training, dev)
+            if len(self._engines) >= 4 and key not in self._engines:  # arenas are large: keep a few shapes only
+                self._engines.pop(next(k for k in self._engines if self._engines[k] is not wpack_from))
+            eng = Engine(self._cfg, fp, B, N, training, dev, wpack_from=wpack_from)
             self._engines[key] = eng
         return eng
 
