@@ -430,6 +430,12 @@ __global__ __launch_bounds__(256, NST_ == 5 ? 1 : 2) void gemm_kernel_bm160(Gemm
 
 // ---- 160 x 128 tile with EIGHT waves of 80 x 32 (512 threads), one workgroup per CU, 5-slot ring: two waves per SIMD, so one
 // wave's MFMAs run while the other waits for its LDS fragments (with four waves that round trip is exposed on every k-step).
+// Tried (round 2, session 3): fragment prefetch -- the reads of k-step t+1 issued before the MFMAs of k-step t (two register
+// sets; ring = stage t+1 being read, t+2 / t+3 in flight, t+4 issued into the slot of stage t).  Correct, and worth nothing:
+// dgrad to_qkv 44.9 -> 43.9 us back to back, train step 9.96 -> 9.97 ms in the same run.  The k-step (~1000 cycles for 18 KiB of
+// operands and 320 MFMA cycles per SIMD) is not waiting for the LDS round trip; like every LDS-DMA loop here it runs at ~18 bytes
+// per clock per CU of fill, a third of what the same instruction streams from an L2-resident buffer without barriers
+// (tools/probes/l2_fill_rate.hip: 48-57 B/clk).
 template <int MB, class Epi, bool F16>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160x8(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

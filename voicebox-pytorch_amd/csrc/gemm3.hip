@@ -236,6 +236,11 @@ VBX_DEV void g3_tile(const G3Params& p, const Epi& epi, char* smem, int lin, int
 // wait in every phase with four regions (64 KiB instead of 32 KiB) in flight -- 8192^3 1293 -> 1240 TFLOP/s, grouped wgrads 89 ->
 // 94 us: the k-loop is not bound by load latency but by the L2 -> LDS fill rate (~10 TB/s aggregate: 655 / 870 / 1300 TFLOP/s for
 // the 128^2, 128 x 256 and 256^2 tiles are all 10.2 TB/s times their FLOP per staged byte).
+// Tried (round 2, session 3): issuing a phase's two LDS-DMAs INSIDE its MFMA cluster (after the 4th and 10th MFMA; k-tile wait
+// vmcnt(2)) instead of behind the fragment reads of the load part, on the theory that the load group's 12 ds_read + 2 DMA issue
+// (~440 cycles per barrier interval against 256 cycles of MFMAs) bounds the interval: correct, and SLOWER -- 8192^3 1315 -> 1018
+// TFLOP/s, K = 512 at the to_qkv shape 36.8 -> 46.2 us; one piece in each part: 1183 TFLOP/s, 42.5 us.  A DMA issued by the wave
+// that holds the matrix pipe stalls that pipe; the load part is the right place.
 #define G3_MFMA_END()                     \
   do {                                    \
     __builtin_amdgcn_s_setprio(0);        \
