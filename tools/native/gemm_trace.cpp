@@ -133,6 +133,55 @@ int main(int argc, char** argv) {
   vbx_gemm_desc ff = base(VBX_GEMM_NT, VBX_EPI_GEGLU, 2 * Fp, D, A512h, D, W1h, D);
   ff.f16 = 1; ff.C = G; ff.ldc = Fp; ff.bias = bias;
   vbx_gemm_desc fft = ff; fft.C2 = H1; fft.C3 = Gb;
+  if (argc > 1 && !strcmp(argv[1], "alias")) {
+    // Is the k-loop of the one-round N = dim tile waiting for L2 MISSES of its activation panel?  Same GEMM with the rows of A
+    // aliased onto a few KB (lda = 8: every A piece is an L1 / L2 hit) against the real layout.
+    const int K = 3072;
+    auto Abig = dev(randn16((size_t)M * K, 1.0f, false));
+    auto Wb = dev(randn16((size_t)K * D, 0.03f, false));
+    uint16_t* Co = devfill<uint16_t>((size_t)M * D, 0);
+    for (int lda : {K, 8, K, 8}) {
+      vbx_gemm_desc d = base(VBX_GEMM_NN, VBX_EPI_BF16, D, K, Abig, lda, Wb, D); d.C = Co; d.ldc = D;
+      vbx_gemm_select(1);
+      for (int i = 0; i < 3; i++) if (vbx_gemm(&d, nullptr)) { printf("vbx_gemm: %s\n", vbx_last_error()); return 2; }
+      hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < 20; i++) vbx_gemm(&d, nullptr);
+      HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      printf("dgrad to_qkv shape (NN, M=8320 N=512 K=3072), lda = %4d: %6.1f us\n", lda, ms * 50.f);
+    }
+    // the same for the 256 x 256 tile at a K-loop-dominated shape (N = 3072, K = 4096: A = 68 MB)
+    {
+      const int N2 = 3072, K2 = 4096;
+      auto X = dev(randn16((size_t)M * K2, 1.0f, false)); auto Y = dev(randn16((size_t)N2 * K2, 0.03f, false)); uint16_t* Z = devfill<uint16_t>((size_t)M * N2, 0);
+      for (int path = 1; path <= 2; path++)
+        for (int lda : {K2, 8}) {
+          vbx_gemm_desc d = base(VBX_GEMM_NT, VBX_EPI_BF16, N2, K2, X, lda, Y, K2); d.C = Z; d.ldc = N2;
+          vbx_gemm_select(path);
+          for (int i = 0; i < 3; i++) vbx_gemm(&d, nullptr);
+          hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+          HIPCHK(hipEventRecord(e0, nullptr));
+          for (int i = 0; i < 10; i++) vbx_gemm(&d, nullptr);
+          HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+          float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+          printf("NT M=8320 N=3072 K=4096 path %d, lda = %4d: %6.1f us\n", path, lda, ms * 100.f);
+        }
+      // both operands aliased
+      for (int path = 1; path <= 2; path++) {
+        vbx_gemm_desc d = base(VBX_GEMM_NT, VBX_EPI_BF16, N2, K2, X, 8, Y, 8); d.C = Z; d.ldc = N2;
+        vbx_gemm_select(path);
+        for (int i = 0; i < 3; i++) vbx_gemm(&d, nullptr);
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 10; i++) vbx_gemm(&d, nullptr);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+        float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        printf("NT M=8320 N=3072 K=4096 path %d, lda = ldb = 8: %6.1f us\n", path, ms * 100.f);
+      }
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "time")) {  // back-to-back launch times of all three tiles (VBX_GEMM_STAGGER A/B: one process per value)
     struct { const char* n; vbx_gemm_desc* d; } L[5] = {{"plain bf16 N=3072", &plain}, {"to_qkv eval", &qkv}, {"to_qkv train", &qkvt}, {"ff_in eval", &ff}, {"ff_in train", &fft}};
     printf("stagger %s us:", getenv("VBX_GEMM_STAGGER") ? getenv("VBX_GEMM_STAGGER") : "0");

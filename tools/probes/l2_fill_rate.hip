@@ -12,15 +12,27 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int V, int DEPTH>
+// SW: lane -> source map inside a piece (the LDS image stays lane-linear, as LDS-DMA requires)
+//   0  8 rows x 128 B, chunks in lane order            1  same rows, chunk index XOR (row & 7)  (the GEMMs' bank swizzle, BK = 64)
+//   2  16 rows x 64 B, chunks in lane order (BK = 32)  3  16 rows x 64 B with gemm.hip's pair swizzle ((s & 7) ^ (p & 7))
+//   4  8 rows x 128 B, chunk index rotated by the row
+template <int V, int DEPTH, int SW = 0>
 __global__ void fill(const char* __restrict__ src, size_t bytes_mask, long rowstride, int iters, uint4* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   // lane offset inside a piece: rowstride == 0 -> 1 KiB contiguous; else 8 rows x 128 B
-  const long lane_off = rowstride ? (long)(lane >> 3) * rowstride + (lane & 7) * 16 : (long)lane * 16;
-  const long piece = rowstride ? 8 * rowstride : 1024;  // address step between consecutive pieces of one wave
+  long lane_off = rowstride ? (long)(lane >> 3) * rowstride + (lane & 7) * 16 : (long)lane * 16;
+  long piece = rowstride ? 8 * rowstride : 1024;  // address step between consecutive pieces of one wave
+  if (SW == 1) lane_off = (long)(lane >> 3) * rowstride + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+  if (SW == 4) lane_off = (long)(lane >> 3) * rowstride + ((((lane & 7) + (lane >> 3)) & 7) * 16);
+  if (SW == 2) { lane_off = (long)(lane >> 2) * rowstride + (lane & 3) * 16; piece = 16 * rowstride; }
+  if (SW == 3) {  // gemm.hip DmaPlan MODE 0: slot s -> pair p = s >> 3, x = (s & 7) ^ (p & 7), row = 2 p + (x >> 2), chunk = x & 3
+    const int pr = lane >> 3, x = (lane & 7) ^ (pr & 7);
+    lane_off = (long)(2 * pr + (x >> 2)) * rowstride + (x & 3) * 16;
+    piece = 16 * rowstride;
+  }
   // start positions differ per workgroup and wave (CUs of a GEMM read different panels at the same time)
   size_t pos = ((size_t)blockIdx.x * 7919 * 4096 + (size_t)wave * piece * 17) & bytes_mask;
   char* my = smem + (size_t)wave * DEPTH * 1024;
@@ -67,12 +79,12 @@ __global__ void fill(const char* __restrict__ src, size_t bytes_mask, long rowst
   if (acc.x == 0x12345678u) sink[blockIdx.x * blockDim.x + tid] = acc;  // never true in practice: keeps the loads alive
 }
 
-template <int V, int DEPTH>
+template <int V, int DEPTH, int SW = 0>
 void run(const char* name, const char* src, size_t bytes, long rowstride, int waves, int wgs_per_cu, uint4* sink) {
   const int iters = 1024;
   const int grid = 256 * wgs_per_cu;
   const size_t lds = (size_t)waves * DEPTH * 1024;
-  auto kern = fill<V, DEPTH>;
+  auto kern = fill<V, DEPTH, SW>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -91,13 +103,27 @@ void run(const char* name, const char* src, size_t bytes, long rowstride, int wa
          name, DEPTH, waves, wgs_per_cu, bytes >> 10, rowstride, ms * 1e3, tbs, tbs * 1e3 / 256, tbs * 1e12 / 256 / 2.4e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
   const size_t big = (size_t)1 << 30;
   char* src;
   uint4* sink;
   CHECK(hipMalloc(&src, big));
   CHECK(hipMemset(src, 1, big));
   CHECK(hipMalloc(&sink, 64 << 20));
+  if (argc > 1) {  // lane -> source maps of the GEMM staging (L2-resident 2 MiB buffer, 8 waves, depth 4)
+    const size_t b = (size_t)2 << 20;
+    for (long stride : {1024L, 6144L}) {
+      run<0, 4, 0>("LDS-DMA 8 rows x 128 B, lane order", src, b, stride, 8, 1, sink);
+      run<0, 4, 1>("LDS-DMA 8 rows x 128 B, XOR swizzle", src, b, stride, 8, 1, sink);
+      run<0, 4, 4>("LDS-DMA 8 rows x 128 B, rotation", src, b, stride, 8, 1, sink);
+      run<0, 4, 2>("LDS-DMA 16 rows x 64 B, lane order", src, b, stride, 8, 1, sink);
+      run<0, 4, 3>("LDS-DMA 16 rows x 64 B, pair swizzle", src, b, stride, 8, 1, sink);
+      run<2, 4, 0>("load x4 -> VGPR 8 rows x 128 B", src, b, stride, 8, 1, sink);
+      run<2, 4, 1>("load x4 -> VGPR, XOR swizzle", src, b, stride, 8, 1, sink);
+      run<2, 4, 3>("load x4 -> VGPR 16 x 64 B pair swizzle", src, b, stride, 8, 1, sink);
+    }
+    return 0;
+  }
   const size_t sizes[3] = {(size_t)2 << 20, (size_t)64 << 20, big};
   for (int s = 0; s < 3; s++) {
     const size_t b = sizes[s];

@@ -547,6 +547,183 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160x8(GemmParams p, Epi 
   }
 }
 
+// ---- 160 x 128 x 64: the one-round tile with 128-BYTE operand rows.  An LDS-DMA instruction costs the texture path one slot
+// per cache line it touches: 8 rows x 128 B stream at 52 B/clk per CU from L2, the 16 rows x 64 B pieces of a 32-deep k-tile at
+// 27 B/clk (tools/probes/l2_fill_rate.hip swz) -- and every k-loop of this file ran at ~18.  So the K-contiguous operands are staged
+// 64 deep: LDS row = one row's 64 k values, 16-byte chunk c at c ^ (row & 7) (the layout of gemm3.hip), a stage = A [192][64]
+// (24 KiB: 3 DMA instructions x 512 threads, rows >= 160 from the zero page) + B [128][64] or two K-strided [32][128] images
+// (16 KiB), 3 stages = 120 KiB, one barrier per 64 k (half as many as before).  Back to back (tools/native/gemm3_check time): to_out
+// 21.9 -> 18.9 us, FeedForward-out 26.3 -> 22.4, dgrad to_qkv 45.0 -> 36.4 (720 TFLOP/s), dgrad FeedForward-in 42.4 -> 34.0.
+constexpr int V9_A_BYTES = 192 * 128;
+constexpr int V9_B_BYTES = 16384;
+constexpr int V9_STAGE = V9_A_BYTES + V9_B_BYTES;  // 40 KiB
+constexpr int GEMM_V9_LDS = 3 * V9_STAGE;          // 120 KiB
+static_assert(GEMM_V9_LDS >= 64 * CS_LD * 4, "C chunk must fit");
+
+template <int ROWS>
+struct DmaPlan64 {
+  static constexpr int N = ROWS * 8 / 512;
+  const u16* base[N];
+  int kq[N];
+  bool ok[N];
+  VBX_DEV void init(const u16* __restrict__ X, long ld, int o0, int olim, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int s = i * 512 + tid, row = s >> 3;
+      kq[i] = (((s & 7) ^ (row & 7))) * 8;
+      ok[i] = (o0 + row) < olim;
+      base[i] = X + (long)(o0 + row) * ld + kq[i];
+    }
+  }
+  VBX_DEV void issue(char* dst, int k0, int kend, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const bool in = ok[i] && (k0 + kq[i] < kend);
+      const u16* src = in ? base[i] + k0 : reinterpret_cast<const u16*>(g_zero_page);
+      char* wave_dst = dst + (i * 512 + (tid & ~63)) * 16;  // the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
+    }
+  }
+};
+struct FragPlan64 {  // 16 rows [woff + 16 S, +16) x k half KK of a [rows][64] operand stage; woff a multiple of 8
+  unsigned a[2];
+  VBX_DEV void init(const char* op_base, int woff, int lane) {
+    const int row = woff + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) a[kk] = lds_addr(op_base + row * 128 + ((((kk * 4 + (lane >> 4)) ^ (row & 7))) << 4));
+  }
+  template <int S, int KK>
+  VBX_DEV void read(bf16x8& out) const {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(a[KK]), "i"(S * 2048) : "memory");
+  }
+};
+
+template <int MB, class Epi, bool F16>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_bm160k64(GemmParams p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
+  const int q = T >> 3, r = T & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
+  const int tiles_n = T / p.tiles_m;
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * 160, n0 = tn * BN;
+  const int kend = p.K;
+  const int nt = (kend + 63) / 64;
+
+  DmaPlan64<192> da;
+  DmaPlan64<128> db0;            // MB == 0
+  DmaPlan<1, 128, 512> db1;      // MB == 1: one 32-deep K-strided image per instruction
+  da.init(p.A, p.lda, m0, min(p.M, m0 + 160), tid);
+  if (MB == 0) db0.init(p.B, p.ldb, n0, p.N, tid);
+  else db1.init(p.B, p.ldb, n0, p.N, tid);
+  FragPlan64 fa[3], fb0[3];
+  FragPlan<1> fb1[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    fa[s].init(smem + s * V9_STAGE, wm * 80, lane);
+    if (MB == 0) fb0[s].init(smem + s * V9_STAGE + V9_A_BYTES, wn * 32, lane);
+    else fb1[s].init(smem + s * V9_STAGE + V9_A_BYTES, wn * 32, lane);
+  }
+
+  f32x4 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int slot, int t) {  // k-tile t -> ring slot (5 DMA instructions per thread)
+    char* dst = smem + slot * V9_STAGE;
+    da.issue(dst, t * 64, kend, tid);
+    if (MB == 0) {
+      db0.issue(dst + V9_A_BYTES, t * 64, kend, tid);
+    } else {
+      db1.issue(dst + V9_A_BYTES, t * 64, kend, tid);
+      db1.issue(dst + V9_A_BYTES + OP_BYTES, t * 64 + 32, kend, tid);
+    }
+  };
+  struct Frags9 { bf16x8 af[2][5], bfr[2][2]; s16x4 blo[2][2], bhi[2][2]; };
+  auto read_frags = [&](auto stg_c, Frags9& f) {
+    constexpr int STG = decltype(stg_c)::value;
+    fa[STG].template read<0, 0>(f.af[0][0]); fa[STG].template read<1, 0>(f.af[0][1]); fa[STG].template read<2, 0>(f.af[0][2]);
+    fa[STG].template read<3, 0>(f.af[0][3]); fa[STG].template read<4, 0>(f.af[0][4]);
+    if (MB == 0) {
+      fb0[STG].template read<0, 0>(f.bfr[0][0]); fb0[STG].template read<1, 0>(f.bfr[0][1]);
+    } else {
+      fb1[STG].template read<0, 0>(f.bfr[0][0], f.blo[0][0], f.bhi[0][0]); fb1[STG].template read<0, 1>(f.bfr[0][1], f.blo[0][1], f.bhi[0][1]);
+    }
+    fa[STG].template read<0, 1>(f.af[1][0]); fa[STG].template read<1, 1>(f.af[1][1]); fa[STG].template read<2, 1>(f.af[1][2]);
+    fa[STG].template read<3, 1>(f.af[1][3]); fa[STG].template read<4, 1>(f.af[1][4]);
+    if (MB == 0) {
+      fb0[STG].template read<0, 1>(f.bfr[1][0]); fb0[STG].template read<1, 1>(f.bfr[1][1]);
+    } else {
+      fb1[STG].template read<OP_BYTES, 0>(f.bfr[1][0], f.blo[1][0], f.bhi[1][0]); fb1[STG].template read<OP_BYTES, 1>(f.bfr[1][1], f.blo[1][1], f.bhi[1][1]);
+    }
+  };
+  auto mfmas = [&](Frags9& f) {
+    if (MB == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          s16x8 v = {f.blo[kk][s2][0], f.blo[kk][s2][1], f.blo[kk][s2][2], f.blo[kk][s2][3],
+                     f.bhi[kk][s2][0], f.bhi[kk][s2][1], f.bhi[kk][s2][2], f.bhi[kk][s2][3]};
+          f.bfr[kk][s2] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma16<F16>(f.af[kk][i], f.bfr[kk][j], acc[i][j]);
+  };
+  if (nt > 0) stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  auto step = [&](auto stg_c, int t) {
+    constexpr int STG = decltype(stg_c)::value;
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // k-tile t has landed, t+1 may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // k-tile t visible to all; every wave is done reading k-tile t-1
+    Frags9 f;
+    read_frags(stg_c, f);
+    // the DMAs of k-tile t+2 are issued BEHIND the fragment reads: the LDS round trip runs under their issue time (dgrad to_qkv
+    // 39.1 -> 36.4 us back to back against issuing them first).  Prefetching the fragments of k-tile t+1 before the MFMAs of
+    // k-tile t (two register sets) measured 1 us SLOWER than this order.
+    if (t + 2 < nt) stage((STG + 2) % 3, t + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f);
+  };
+  for (int t = 0; t < nt; t += 3) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
+  }
+  // ---- epilogue: as gemm_kernel_bm160x8
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int half = tid >> 8, tq = tid & 255;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int trow = wm * 80 + i * 16;
+      if ((trow >> 6) == c) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            Cs[(trow - 64 * c + (lane >> 4) * 4 + rr) * CS_LD + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][rr];
+      }
+    }
+    __syncthreads();
+    if (c < 2 || half == 0) epi(Cs + half * 32 * CS_LD, m0 + c * 64 + half * 32, n0, tq, 0, p.M, p.N, 32);
+  }
+}
+
 VBX_DEV void load8(const float* Cs, int row, int cc, float v[8]) {
   const float4 a = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8);
   const float4 b = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * 8 + 4);
@@ -835,6 +1012,21 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
     if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
       static bool attr8 = false;
+      // 64-deep stages (128-byte operand rows) are the default: in the train step to_out 27.2 -> 23.8 us, FeedForward-out 33.6 ->
+      // 28.0, dgrad to_qkv 50.4 -> 43.9, dgrad FeedForward-in 52.0 -> 41.8, step 10.24 -> 9.99 ms (same run).  VBX_BM160_K64=0: A/B.
+      static const bool k64 = !(getenv("VBX_BM160_K64") && atoi(getenv("VBX_BM160_K64")) == 0);
+      if (k64) {
+        static bool attr9 = false;
+        auto k9 = gemm_kernel_bm160k64<MB, Epi, F16>;
+        if (!attr9) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V9_LDS);
+          attr9 = true;
+        }
+        p.tiles_m = cdiv(p.M, 160);
+        hipLaunchKernelGGL(k9, dim3(p.tiles_m * tiles_n), dim3(512), GEMM_V9_LDS, st, p, epi);
+        VBX_LAUNCH_CHECK();
+        return 0;
+      }
       auto k8 = gemm_kernel_bm160x8<MB, Epi, F16>;
       if (!attr8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V8_LDS);

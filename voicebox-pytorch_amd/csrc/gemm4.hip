@@ -27,6 +27,7 @@ struct G4Params {
   int M, N, K;
   long lda, ldb;
   int stagger;  // start-phase stagger of the second workgroup per CU in 10 ns ticks (common.hpp::stagger_wait); 0 = off
+  int late_dma; // a k-tile's DMAs issued behind the fragment reads (default; VBX_GEMM_LATE_DMA=0: in front of them, A/B)
 };
 
 __device__ uint4 g4_zero_page[4];
@@ -167,11 +168,12 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(G4Params p, Epi epi) {
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // k-tile t visible to all waves; everyone is done reading k-tile t-1
-    if (t + 2 < nt) stage(t + 2);  // into the slot k-tile t-1 used
+    if (!p.late_dma && t + 2 < nt) stage(t + 2);  // into the slot k-tile t-1 used
     RawFrag4 af[4], bf[8];
     fa.template read<SO, 0>(af[0]); fa.template read<SO, 1>(af[1]); fa.template read<SO, 2>(af[2]); fa.template read<SO, 3>(af[3]);
     fb.template read<SO, 0>(bf[0]); fb.template read<SO, 1>(bf[1]); fb.template read<SO, 2>(bf[2]); fb.template read<SO, 3>(bf[3]);
     fb.template read<SO, 4>(bf[4]); fb.template read<SO, 5>(bf[5]); fb.template read<SO, 6>(bf[6]); fb.template read<SO, 7>(bf[7]);
+    if (p.late_dma && t + 2 < nt) stage(t + 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -220,7 +222,8 @@ int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st) {
   if (d->lda % 8 || d->ldb % 8 || d->N % 8 || d->K % 8) return VBX_EUNSUPPORTED;
   if (d->mode != VBX_GEMM_NT && d->mode != VBX_GEMM_NN) return VBX_EUNSUPPORTED;
   static const int stagger = getenv("VBX_GEMM_STAGGER") ? (int)(atof(getenv("VBX_GEMM_STAGGER")) * 100.0) : 0;
-  G4Params p{(const u16*)d->A, (const u16*)d->B, d->M, d->N, d->K, d->lda, d->ldb, stagger};
+  static const int late = getenv("VBX_GEMM_LATE_DMA") ? atoi(getenv("VBX_GEMM_LATE_DMA")) : 1;
+  G4Params p{(const u16*)d->A, (const u16*)d->B, d->M, d->N, d->K, d->lda, d->ldb, stagger, late};
   switch (d->epilogue) {
     case VBX_EPI_BF16: {
       if (!d->C || d->ldc % 8) return VBX_EUNSUPPORTED;
