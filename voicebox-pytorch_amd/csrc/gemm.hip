@@ -560,16 +560,16 @@ constexpr int V9_STAGE = V9_A_BYTES + V9_B_BYTES;  // 40 KiB
 constexpr int GEMM_V9_LDS = 3 * V9_STAGE;          // 120 KiB
 static_assert(GEMM_V9_LDS >= 64 * CS_LD * 4, "C chunk must fit");
 
-template <int ROWS>
+template <int ROWS, int NTHR = 512>
 struct DmaPlan64 {
-  static constexpr int N = ROWS * 8 / 512;
+  static constexpr int N = ROWS * 8 / NTHR;
   const u16* base[N];
   int kq[N];
   bool ok[N];
   VBX_DEV void init(const u16* __restrict__ X, long ld, int o0, int olim, int tid) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      const int s = i * 512 + tid, row = s >> 3;
+      const int s = i * NTHR + tid, row = s >> 3;
       kq[i] = (((s & 7) ^ (row & 7))) * 8;
       ok[i] = (o0 + row) < olim;
       base[i] = X + (long)(o0 + row) * ld + kq[i];
@@ -580,7 +580,7 @@ struct DmaPlan64 {
     for (int i = 0; i < N; i++) {
       const bool in = ok[i] && (k0 + kq[i] < kend);
       const u16* src = in ? base[i] + k0 : reinterpret_cast<const u16*>(g_zero_page);
-      char* wave_dst = dst + (i * 512 + (tid & ~63)) * 16;  // the DMA adds lane*16
+      char* wave_dst = dst + (i * NTHR + (tid & ~63)) * 16;  // the DMA adds lane*16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
     }
@@ -915,12 +915,20 @@ struct EpiQKV {
     const int I = H * 64;
     const int which = n0 / I;
     const int hbase = (n0 % I) >> 6;
+    // (batch, token) of a row: one division per call (m0 is uniform), rows of the chunk by a conditional subtract
+    const int mb = min(m0, M - 1);
+    const int b0 = mb / Np, n00 = mb - b0 * Np;
+    auto split_row = [&](int gr, int& b, int& n) {
+      if (rows <= Np) { b = b0; n = n00 + (gr - mb); if (n >= Np) { n -= Np; b++; } }
+      else { b = gr / Np; n = gr - b * Np; }
+    };
     if (which == 2) {  // v: plain head split
       for (int it = 0; it < rows / 16; it++) {
         const int row = it * 16 + (tid >> 4), cc = tid & 15;
         const int gr = m0 + row;
         if (gr >= M) continue;
-        const int b = gr / Np, n = gr - b * Np;
+        int b, n;
+        split_row(gr, b, n);
         float t[8];
         load8(Cs, row, cc, t);
         const long o = (((long)b * H + hbase + (cc >> 3)) * Np + n) * 64 + (cc & 7) * 8;
@@ -936,8 +944,8 @@ struct EpiQKV {
       const int row = it * 32 + (tid >> 3), hj = tid & 7;
       const int gr = m0 + row;
       const bool valid = gr < M;
-      const int grc = valid ? gr : (M - 1);
-      const int b = grc / Np, n = grc - b * Np;
+      int b, n;
+      split_row(valid ? gr : mb, b, n);
       const int hl = hj >> 2, j = hj & 3;  // head inside the 128-column tile, chunk pair
       const int head = hbase + hl;
       const int d0 = j * 8;
@@ -949,6 +957,10 @@ struct EpiQKV {
       for (int i = 0; i < 8; i++) ss += lo[i] * lo[i] + hi[i] * hi[i];
       ss += __shfl_xor(ss, 1, 64);
       ss += __shfl_xor(ss, 2, 64);
+      // 1 / max(|x|, 1e-12) (F.normalize, voicebox_pytorch.py:286).  (min(v_rsq_f32(ss), 1e12) would save ~20 VALU instructions of
+      // this VALU-bound epilogue and is 1 ulp away -- but at random initialisation the depth-12 network is chaotic enough that this
+      // single ulp moved the config-4 loss from 1.0e-3 to 3.9e-3 off the reference (tests/test_model_gpu.py::test_cfg4_depth12_parity),
+      // so the IEEE sequence stays.)
       const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
       if (qk_scale > 0.f) {
         const float* gam = (which == 0 ? qg : kg) + head * 64 + d0;
@@ -1071,6 +1083,10 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
         hipLaunchKernelGGL(kern64, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM2_LDS, st, p, epi);
       }
     }
+    // Tried (round 2, session 3): a 64-deep / two-stage / two-workgroups-per-CU form of this kernel for the NT GEMMs (128-byte
+    // operand rows, the recipe that took the one-round tile from 45 to 36 us): to_qkv 52.4 -> 50.4 us back to back, but the train
+    // step 9.93 -> 10.05 ms and the 16-interval sample 83.2 -> 87.9 ms in the same run -- the third co-resident workgroup (its
+    // epilogue under the others' k-loops) is worth more than the cheaper staging.  Removed.
     if (!small) hipLaunchKernelGGL(kern128, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM2_LDS, st, p, epi);
   }
   VBX_LAUNCH_CHECK();
