@@ -957,10 +957,10 @@ struct EpiQKV {
       for (int i = 0; i < 8; i++) ss += lo[i] * lo[i] + hi[i] * hi[i];
       ss += __shfl_xor(ss, 1, 64);
       ss += __shfl_xor(ss, 2, 64);
-      // 1 / max(|x|, 1e-12) (F.normalize, voicebox_pytorch.py:286).  (min(v_rsq_f32(ss), 1e12) would save ~20 VALU instructions of
-      // this VALU-bound epilogue and is 1 ulp away -- but at random initialisation the depth-12 network is chaotic enough that this
-      // single ulp moved the config-4 loss from 1.0e-3 to 3.9e-3 off the reference (tests/test_model_gpu.py::test_cfg4_depth12_parity),
-      // so the IEEE sequence stays.)
+      // 1 / max(|x|, 1e-12) (F.normalize, voicebox_pytorch.py:286).  Tried: min(v_rsq_f32(ss), 1e12) (~20 VALU instructions fewer) --
+      // the raw v_rsq moved the chaotic random-init depth-12 loss from 1.0e-3 to 3.9e-3 off the reference
+      // (tests/test_model_gpu.py::test_cfg4_depth12_parity); with one Newton step the test passes again, and neither variant is
+      // measurably faster (16-interval sample 80.6 vs 80.6 ms in the same run).  The IEEE sequence stays.
       const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
       if (qk_scale > 0.f) {
         const float* gam = (which == 0 ? qg : kg) + head * 64 + d0;
