@@ -149,7 +149,7 @@ def isolated_gemm_us(args, dev, which):
 
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the committed PMC passes of this command (tools/pmc_summary.py)."""
-    for name in ("r02_train_pmc.json", "r01_bench_pmc_hbm.json"):
+    for name in ("r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue
@@ -332,7 +332,8 @@ def main():
             out["sample"] = {"ms": round(dt * 1e3, 2), "frames_per_s": round(args.batch * args.frames / dt, 1), "nfe": nfe,
                              "ms_per_nfe": round(dt * 1e3 / nfe, 3), "fwd_frac": round(fwd_flops * nfe / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
                              "what": f"ConditionalFlowMatcherWrapper.sample(cond=(8,{args.frames},{args.dim}), steps={steps_pts}) "
-                                     f"= {args.intervals} midpoint intervals under hipGraph, one timed run after the capture run"}
+                                     f"= {args.intervals} midpoint intervals under hipGraph (the two halves of the batch integrated concurrently as "
+                                     f"two branches of the graph, solver.py), one timed run after the capture run"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
