@@ -1019,7 +1019,12 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     static const char* b160 = getenv("VBX_GEMM_BM160");
     const long t128 = (long)p.tiles_m * tiles_n, t160 = (long)cdiv(p.M, 160) * tiles_n;
     static const bool all160 = getenv("VBX_GEMM_BM160ALL") != nullptr;  // experiment: also the multi-round GEMMs
-    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 && t128 > 256 && (t160 <= 256 || all160);
+    // Also for half a batch (the sampler integrates the two halves concurrently, solver.py): 104 such workgroups, one per CU --
+    // two of these launches from the two streams then share the chip (16-interval sample 82.7 -> 79.1 ms in the same run against
+    // the 64- / 128-row tiles of gemm_kernel_v2).  VBX_BM160_MIN=<tiles>: smallest one-round grid served (257 = full batches only).
+    static const long min160 = getenv("VBX_BM160_MIN") ? atol(getenv("VBX_BM160_MIN")) : 96;
+    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 &&
+                        ((t128 > 256 && (t160 <= 256 || all160)) || (t160 <= 256 && t160 >= min160));
     // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
     static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
     if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
