@@ -240,6 +240,10 @@ int vbx_ode_set_time(float* times, int B, const float* table, const int* counter
 int vbx_axpy_ctr(const float* y, const float* f, const float* table, const int* counter, int slot, float* out, long n,
                  void* stream);
 int vbx_counter_add(int* counter, int inc, void* stream);
+/* Occupies `stream` with one idle wave for `us` microseconds (0 .. 10000).  The sampler integrates the two halves of a batch as two
+ * graphs on two streams and starts the second one ~60 us late, so that different kernels of the two forwards overlap (attention
+ * beside GEMMs) instead of the same ones: 16 intervals 81.7 -> 80.1 ms (tools/sample_offset.py). */
+int vbx_stream_delay(float us, void* stream);
 /* fp32 -> bf16 and/or fp16 weight packing with optional row map / K padding:
  * dst[p][c] = (src row of p valid && c < src_cols) ? src[row][c] : 0 ; dst is [dst_rows, dst_cols] */
 int vbx_pack_weight(const float* src, int src_rows, int src_cols, void* dst_bf16 /* or NULL */, void* dst_f16 /* or NULL */,

@@ -1037,6 +1037,11 @@ __global__ void axpy_ctr_kernel(const float* __restrict__ y, const float* __rest
 __global__ void counter_add_kernel(int* counter, int inc) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += inc;
 }
+// one idle wave for `ticks` x 10 ns: start-phase offset between the sampler's two half-batch streams (solver.py)
+__global__ void stream_delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 // ---------------------------------------------------------------- weight packing
 __global__ void pack_weight_kernel(const float* __restrict__ src, int src_rows, int src_cols, u16* __restrict__ dst,
@@ -1555,6 +1560,15 @@ extern "C" int vbx_counter_add(int* counter, int inc, void* stream) {
   VBX_REQUIRE(counter, "vbx_counter_add: null");
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, ST, counter, inc);
   VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_stream_delay(float us, void* stream) {
+  VBX_REQUIRE(us >= 0.f && us <= 1e4f, "vbx_stream_delay: 0 .. 10000 us");
+  if (us > 0.f) {
+    hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long)(us * 100.0f));
+    VBX_LAUNCH_CHECK();
+  }
   return 0;
 }
 

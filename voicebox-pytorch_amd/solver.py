@@ -12,9 +12,12 @@ state is kept (the reference stacks the whole trajectory, voicebox_pytorch.py:12
 Concurrent halves.  Every kernel of a forward has a ramp, a drain and -- the GEMMs -- a VALU-bound epilogue during which the
 matrix pipes idle (tools/native/gemm_trace.cpp); batch elements are independent in every kernel of the path.  So a batch of
 B >= 4 (even) is integrated as TWO half-batches on two streams, each with its own engine (activation arena; the packed weights
-are shared), captured as two parallel branches of the SAME graph: one kernel stream fills the other's holes.  Measured on the
-benchmark shape (tools/sample_concurrent.py): 88.0 -> 82.9 ms for 16 intervals, results bit-identical to the single-stream run.
-VBX_SAMPLE_SPLIT=1 restores the single stream (A/B).
+are shared) and its own captured interval graph: one kernel stream fills the other's holes.  The two integrations never meet
+before the end, and the second stream starts SPLIT_OFFSET_US late, so that different kernels of the two forwards overlap
+(attention beside GEMMs) rather than the same ones.  Measured on the benchmark shape, 16 intervals: one stream 85.7 ms, two
+joined branches of one graph 82.5, two free-running graphs 81.7, with the offset 80.1 (tools/sample_concurrent.py,
+tools/sample_offset.py); results bit-identical to the single-stream run.  VBX_SAMPLE_SPLIT=1 restores the single stream (A/B).
+Without a graph (use_graph=False) the halves run as fork / join branches per interval.
 """
 import os
 
@@ -22,6 +25,9 @@ import os
 import torch
 
 from . import _lib
+
+
+SPLIT_OFFSET_US = 60.0  # start delay of the second (third, ...) half-batch stream; 30 .. 250 us measured equal
 
 
 class _Part:
@@ -82,7 +88,8 @@ class MidpointSampler:
                 p.f_null, p.f_diff = self.f_null[sl], self.f_diff[sl]
             self.parts.append(p)
         self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(split - 1)]
-        self.graph = None
+        self.part_streams = [torch.cuda.Stream(device=dev) for _ in range(split)] if split > 1 else []
+        self.graph = None       # split == 1: one interval; split > 1: a list, one interval graph per part
         self.use_graph = use_graph
         self.nfe = 2 * (steps - 1) * (2 if self.guided else 1)
 
@@ -132,10 +139,33 @@ class MidpointSampler:
             self._interval()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._interval()
-        self.graph = g
+        if self.split == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._interval()
+            self.graph = g
+        else:
+            self.graph = []
+            for p in self.parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._interval_part(p)
+                self.graph.append(g)
+
+    def _replay_parts(self):
+        """steps-1 intervals of every part: each part's graph on its own stream, the streams never meet before the end."""
+        cur = torch.cuda.current_stream()
+        for s in self.part_streams:
+            s.wait_stream(cur)
+        for i, s in enumerate(self.part_streams[1:], 1):
+            with torch.cuda.stream(s):
+                _lib.call("vbx_stream_delay", SPLIT_OFFSET_US * i, _lib.current_stream())
+        for _ in range(self.steps - 1):
+            for g, s in zip(self.graph, self.part_streams):
+                with torch.cuda.stream(s):
+                    g.replay()
+        for s in self.part_streams:
+            cur.wait_stream(s)
 
     def run(self, y0, cond=None, cond_mask=None, cond_token_ids=None, cond_scale=1.0):
         # eval semantics of the reference: cond_mask None -> everything masked -> cond is zeroed (:1028-1035)
@@ -155,9 +185,12 @@ class MidpointSampler:
             self._capture()
         self.y.copy_(y0)
         self.counters.zero_()
-        for _ in range(self.steps - 1):
-            if self.use_graph:
-                self.graph.replay()
-            else:
-                self._interval()
+        if self.use_graph and self.split > 1:
+            self._replay_parts()
+        else:
+            for _ in range(self.steps - 1):
+                if self.use_graph:
+                    self.graph.replay()
+                else:
+                    self._interval()
         return self.y.clone()
