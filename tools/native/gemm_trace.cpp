@@ -13,6 +13,7 @@
 #include <vector>
 #include "../../include/vbx.h"
 
+extern "C" int vbx_debug_gemm2_trace(void*);
 extern "C" int vbx_debug_gemm3_trace(void*);
 extern "C" int vbx_debug_gemm4_trace(void*);
 
@@ -52,17 +53,18 @@ static void trace_one(const char* name, const vbx_gemm_desc& d, int path, int wg
   for (int i = 0; i < 20; i++) vbx_gemm(&d, nullptr);
   HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
   float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (path == 2 ? vbx_debug_gemm3_trace : vbx_debug_gemm4_trace)(buf);
+  auto setter = path == 1 ? vbx_debug_gemm2_trace : (path == 2 ? vbx_debug_gemm3_trace : vbx_debug_gemm4_trace);
+  setter(buf);
   vbx_gemm(&d, nullptr);
   HIPCHK(hipDeviceSynchronize());
-  (path == 2 ? vbx_debug_gemm3_trace : vbx_debug_gemm4_trace)(nullptr);
+  setter(nullptr);
   std::vector<unsigned long long> h((size_t)8192 * 5);
   HIPCHK(hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost));
   hipFree(buf);
   unsigned long long t0 = ~0ull;
   int n = 0;
   for (int i = 0; i < 8192; i++) if (h[i * 5]) { t0 = std::min(t0, h[i * 5]); n++; }
-  printf("== %s, path %d (%s): %.1f us per launch back to back; %d workgroups traced (expected %d)\n", name, path, path == 2 ? "gemm3 256x256" : "gemm4 128x256",
+  printf("== %s, path %d (%s): %.1f us per launch back to back; %d workgroups traced (expected %d)\n", name, path, path == 1 ? "128x128, 3 per CU" : (path == 2 ? "gemm3 256x256" : "gemm4 128x256"),
          ms * 50.f, n, wgs);
   // classify by start time: first wave of workgroups (started within 3 us of the first) vs later ones
   std::vector<double> st[2], pro[2], loop[2], epi[2], life[2], endt[2];
@@ -206,9 +208,9 @@ int main(int argc, char** argv) {
     printf("   (128^2 / gemm3 / gemm4)\n");
     return 0;
   }
-  for (int path = 2; path <= 3; path++) {
+  for (int path = 1; path <= 3; path++) {
     if (argc > 1 && atoi(argv[1]) && atoi(argv[1]) != path) continue;
-    const int t = path == 2 ? 33 : 65;
+    const int t = path == 2 ? 33 : (path == 1 ? 130 : 65);
     trace_one("N=3072 K=512 plain bf16 epilogue", plain, path, t * 12);
     trace_one("to_qkv eval", qkv, path, t * 12);
     trace_one("to_qkv train", qkvt, path, t * 12);

@@ -9,6 +9,27 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Diagnostic build only (-DVBX_GEMM_TRACE, tools/build_trace_lib.sh): per-workgroup timestamps of gemm_kernel_v2 (entry, k-loop end,
+// end; 100 MHz s_memrealtime) for tools/native/gemm_trace.cpp.
+#ifdef VBX_GEMM_TRACE
+static __device__ unsigned long long* g_gemm2_trace = nullptr;
+extern "C" int vbx_debug_gemm2_trace(void* buf) {  // buf = [workgroups][5] u64, null to stop
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm2_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define GEMM2_TRACE_DECL() unsigned long long gtr0 = __builtin_amdgcn_s_memrealtime(), gtr2 = 0
+#define GEMM2_TRACE_MARK() gtr2 = __builtin_amdgcn_s_memrealtime()
+#define GEMM2_TRACE_END()                                                                                          \
+  if (g_gemm2_trace && threadIdx.x == 0) {                                                                         \
+    unsigned long long* r = g_gemm2_trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5;                     \
+    r[0] = gtr0; r[1] = 0; r[2] = gtr2; r[3] = __builtin_amdgcn_s_memrealtime();                                   \
+    r[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+  }
+#else
+#define GEMM2_TRACE_DECL()
+#define GEMM2_TRACE_MARK()
+#define GEMM2_TRACE_END()
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -290,11 +311,13 @@ struct FragPlan {
 template <int MA, int MB, class Epi, bool F16, int BM_>
 __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GEMM2_TRACE_DECL();
   if (p.stagger && gridDim.y == 1 && blockIdx.x < 768) stagger_wait(blockIdx.x >> 8, p.stagger);  // 3 workgroups per CU
 #define VBX_BX_ blockIdx.x
 #define VBX_T_ gridDim.x
 #define VBX_SPLIT_ blockIdx.y
 #include "gemm_v2_body.inc"
+  GEMM2_TRACE_END();
 #undef VBX_BX_
 #undef VBX_T_
 #undef VBX_SPLIT_
