@@ -82,6 +82,15 @@ def test_probe_mfma_layout(L, which, shape):
 
 
 # ----------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[0, 2, 3], ids=["auto", "tile256x256", "tile128x256"])
+def tile_path(request, L):
+    """Every GEMM tile family behind vbx_gemm: the automatic choice, the 256 x 256 8-wave tile (gemm3.hip) and the 128 x 256 two-per-CU
+    tile (gemm4.hip) wherever they can serve the descriptor -- both store through the row-staged epilogues of gemm_epi3.hpp."""
+    L.lib().vbx_gemm_select(request.param)
+    yield request.param
+    L.lib().vbx_gemm_select(0)
+
+
 def gemm(L, mode, epi, A, B, M, N, K, **kw):
     d = L.GemmDesc()
     d.mode, d.epilogue, d.M, d.N, d.K = mode, epi, M, N, K
@@ -93,8 +102,8 @@ def gemm(L, mode, epi, A, B, M, N, K, **kw):
     assert rc == 0, L.lib().vbx_last_error()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64)])
-def test_gemm_nt_bf16_f32(L, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64), (4160, 512, 1408)])
+def test_gemm_nt_bf16_f32(L, M, N, K, tile_path):
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
     Bw = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
@@ -115,8 +124,8 @@ def test_gemm_nt_bf16_f32(L, M, N, K):
     assert rel_err(out32b, ref) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408), (8320, 512, 3072), (8320, 512, 360)])
-def test_gemm_nn(L, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408), (8320, 512, 3072), (8320, 512, 360), (4160, 512, 1024)])
+def test_gemm_nn(L, M, N, K, tile_path):
     """dgrad layout: C[M,N] = A[M,K] . B[K,N]  (B read through the hardware transpose path)."""
     g = torch.Generator().manual_seed(M * 3 + N)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -175,7 +184,7 @@ def rot_tables(Np, R):
 
 
 @pytest.mark.parametrize("Bsz,Np,H,D,qknorm", [(2, 56, 2, 64, True), (2, 1040, 4, 256, True), (1, 40, 2, 128, False)])
-def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm):
+def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     """to_qkv + MultiheadRMSNorm + rotary fused (voicebox_pytorch.py:320-328)."""
     g = torch.Generator().manual_seed(Np)
     I = H * 64
@@ -208,7 +217,7 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm):
     assert rel_err(v, vv) < 4e-3 and rel_err(v16, vv) < 6e-4
 
 
-def test_gemm_geglu_epilogue(L):
+def test_gemm_geglu_epilogue(L, tile_path):
     """FeedForward[0] + GEGLU fused, packed/interleaved weights (voicebox_pytorch.py:338-345)."""
     g = torch.Generator().manual_seed(3)
     M, D, Fd = 200, 128, 341
