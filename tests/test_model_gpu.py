@@ -656,6 +656,42 @@ def test_well_conditioned_sampler_is_tight(golden):
             assert e < 2e-3, (steps, use_graph, e)  # measured 3.1e-4 .. 5.5e-4 for 2 .. 16 intervals
 
 
+def test_ode_step_kernels_reproduce_the_textbook_midpoint_rule():
+    """The device-side ODE helpers the captured interval is made of (vbx_ode_set_time, vbx_axpy_ctr, vbx_counter_add with the
+    sampler's own t / dt tables) integrate y' = (c0 + c1 t) y exactly as the explicit midpoint rule does: the final state is
+    y0 times the product of (1 + h a(t + h/2) (1 + h a(t) / 2)) over the grid -- independent of the restated third-party solver."""
+    from voicebox_pytorch_amd import _lib as L
+
+    c0, c1 = -1.3, 0.7
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    for steps in (3, 17, 64, 65):
+        t = torch.linspace(0, 1, steps)
+        t0, dt = t[:-1], t[1:] - t[:-1]
+        half = 0.5 * dt
+        t_table = torch.stack((t0, t0 + half), dim=1).reshape(-1).contiguous().to(dev)  # exactly solver.MidpointSampler's tables
+        c_table = torch.stack((half, dt), dim=1).reshape(-1).contiguous().to(dev)
+        B, n = 2, 4096
+        y = torch.linspace(-2, 2, B * n, device=dev).view(B, n).contiguous()
+        y0 = y.clone()
+        ymid, times = torch.empty_like(y), torch.zeros(B, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        for _ in range(steps - 1):
+            L.call("vbx_ode_set_time", times, B, t_table, counter, 0, st())
+            f = (c0 + c1 * times)[:, None] * y
+            L.call("vbx_axpy_ctr", y, f.contiguous(), c_table, counter, 0, ymid, y.numel(), st())
+            L.call("vbx_ode_set_time", times, B, t_table, counter, 1, st())
+            f = (c0 + c1 * times)[:, None] * ymid
+            L.call("vbx_axpy_ctr", y, f.contiguous(), c_table, counter, 1, y, y.numel(), st())
+            L.call("vbx_counter_add", counter, 1, st())
+        fac = 1.0
+        t64 = t.double()
+        for i in range(steps - 1):
+            h = float(t64[i + 1] - t64[i]); ti = float(t64[i])
+            fac *= 1.0 + h * (c0 + c1 * (ti + h / 2)) * (1.0 + h * (c0 + c1 * ti) / 2)
+        assert int(counter.item()) == steps - 1
+        assert rel(y, y0.double().cpu() * fac) < 2e-6, (steps, rel(y, y0.double().cpu() * fac))
+
+
 def test_sampler_concurrent_halves_equal_single_stream(golden, monkeypatch):
     """The sampler integrates a batch of >= 4 as two half-batches on two streams (two parallel branches of one hipGraph, own
     activation arenas, shared packed weights).  Batch elements are independent in every kernel of the path, so the result must

@@ -196,3 +196,26 @@ def test_restatement_vs_live_reference():
     rand = torch.zeros_like(frac).float().uniform_(0, 1)
     got = restate.cfm_loss(state, cfg, x1, x0, times, frac, rand)
     assert abs(float(got) - float(ref_loss)) < 1e-5
+
+
+def test_midpoint_restatement_reproduces_the_textbook_rule():
+    """torchdiffeq is absent (parity of the solver is unpinned against IT); what CAN be pinned is that the restated fixed-grid
+    midpoint integrator is the textbook explicit midpoint rule: for y' = a(t) y with a(t) = c0 + c1 t one step is
+    y <- y (1 + h a(t + h/2) (1 + h a(t) / 2)), and the whole grid is the product of those factors."""
+    from oracle.ref_loader import odeint_fixed_grid_midpoint
+
+    c0, c1 = -1.3, 0.7
+    for steps in (2, 3, 17, 64, 65):
+        t = torch.linspace(0, 1, steps, dtype=torch.float64)
+        y0 = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
+        ys = odeint_fixed_grid_midpoint(lambda tt, y: (c0 + c1 * tt) * y, y0, t)
+        fac = 1.0
+        for i in range(steps - 1):
+            h = float(t[i + 1] - t[i]); ti = float(t[i])
+            fac *= 1.0 + h * (c0 + c1 * (ti + h / 2)) * (1.0 + h * (c0 + c1 * ti) / 2)
+        assert ys.shape[0] == steps
+        assert torch.allclose(ys[-1], y0 * fac, rtol=1e-13, atol=0)
+        # second-order convergence towards the exact solution exp(c0 + c1/2)
+        exact = y0 * torch.exp(torch.tensor(c0 + c1 / 2, dtype=torch.float64))
+        err = float((ys[-1] - exact).abs().max())
+        assert err < 2.0 / (steps - 1) ** 2
