@@ -102,7 +102,7 @@ def gemm(L, mode, epi, A, B, M, N, K, **kw):
     assert rc == 0, L.lib().vbx_last_error()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64), (4160, 512, 1408)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64), (4160, 512, 1408), (8320, 1024, 1024)])
 def test_gemm_nt_bf16_f32(L, M, N, K, tile_path):
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -124,7 +124,7 @@ def test_gemm_nt_bf16_f32(L, M, N, K, tile_path):
     assert rel_err(out32b, ref) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408), (8320, 512, 3072), (8320, 512, 360), (4160, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408), (8320, 512, 3072), (8320, 512, 360), (4160, 512, 1024), (8320, 1024, 3072)])
 def test_gemm_nn(L, M, N, K, tile_path):
     """dgrad layout: C[M,N] = A[M,K] . B[K,N]  (B read through the hardware transpose path)."""
     g = torch.Generator().manual_seed(M * 3 + N)

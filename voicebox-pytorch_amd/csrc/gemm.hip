@@ -1046,8 +1046,14 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     // two of these launches from the two streams then share the chip (16-interval sample 82.7 -> 79.1 ms in the same run against
     // the 64- / 128-row tiles of gemm_kernel_v2).  VBX_BM160_MIN=<tiles>: smallest one-round grid served (257 = full batches only).
     static const long min160 = getenv("VBX_BM160_MIN") ? atol(getenv("VBX_BM160_MIN")) : 96;
+    // k-loop-dominated GEMMs with a light epilogue (K >= 1024, plain bf16 / fp32 stores) also run on the 64-deep tile when they
+    // need MORE than one round of 160-row tiles -- the N = 1024 GEMMs of the dim-1024 model (BASELINE config 3): dgrad
+    // FeedForward-in 155 -> 132 us, FeedForward-out 96 -> 80 us, train step 20.08 -> 19.65 ms in the same run.  VBX_BM160_MULTI=0: A/B.
+    static const bool multi160 = !(getenv("VBX_BM160_MULTI") && atoi(getenv("VBX_BM160_MULTI")) == 0);
+    const bool light = std::is_same<Epi, EpiBF16>::value || std::is_same<Epi, EpiF32>::value;
     const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 &&
-                        ((t128 > 256 && (t160 <= 256 || all160)) || (t160 <= 256 && t160 >= min160));
+                        ((t128 > 256 && (t160 <= 256 || all160)) || (t160 <= 256 && t160 >= min160) ||
+                         (multi160 && light && p.K >= 1024 && t160 > 256));
     // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
     static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
     if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
