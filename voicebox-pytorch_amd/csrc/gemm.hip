@@ -1050,10 +1050,11 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     // need MORE than one round of 160-row tiles -- the N = 1024 GEMMs of the dim-1024 model (BASELINE config 3): dgrad
     // FeedForward-in 155 -> 132 us, FeedForward-out 96 -> 80 us, train step 20.08 -> 19.65 ms in the same run.  VBX_BM160_MULTI=0: A/B.
     static const bool multi160 = !(getenv("VBX_BM160_MULTI") && atoi(getenv("VBX_BM160_MULTI")) == 0);
+    constexpr int multi_k = 1024;  // at K = 512 the same tile loses to the 128 x 256 tile (dgrad FeedForward-out 27.8 vs 20.6 us)
     const bool light = std::is_same<Epi, EpiBF16>::value || std::is_same<Epi, EpiF32>::value;
     const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 &&
                         ((t128 > 256 && (t160 <= 256 || all160)) || (t160 <= 256 && t160 >= min160) ||
-                         (multi160 && light && p.K >= 1024 && t160 > 256));
+                         (multi160 && light && p.K >= multi_k && t160 > 256));
     // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
     static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
     if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
@@ -1208,6 +1209,7 @@ extern "C" int vbx_gemm_select(int path) {
 static int gemm_tile_for(const vbx_gemm_desc* d) {
   const int path = vbx_gemm_path();
   if (path == 2) return 3;
+  if (path == 1) return 1;
   const bool ntnn = d->mode == VBX_GEMM_NT || d->mode == VBX_GEMM_NN;
   if (path == 3) return ntnn ? 4 : 1;
   // inference-mode FeedForward-in (GEGLU epilogue writing only the fp16 activations: no pre-activation copy, no bf16 copy) is the
