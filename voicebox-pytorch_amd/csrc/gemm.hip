@@ -1226,6 +1226,8 @@ static int gemm_tile_for(const vbx_gemm_desc* d) {
   if (dgrad4 && d->epilogue == VBX_EPI_BF16 && d->mode == VBX_GEMM_NN && d->K <= 512 &&
       (long)cdiv(d->M, 128) * cdiv(d->N, 256) >= 256)
     return 4;
+  // (Tried: to_qkv of HALF a batch -- 792 tiles of 128 x 128 on 768 slots, 24 of them alone at the end -- as 396 tiles of 128 x 256
+  //  in one round: 16-interval sample 83.2 vs 83.1 ms.  The other half batch's stream already fills that tail.)
   // (Tried: the 256 x 256 tile for the wide K = dim GEMMs of HALF a batch -- 17 x 12 / 17 x 11 tiles fit the chip in one round, and in
   //  the sampler the other half batch's stream could fill its epilogue phases: 16-interval sample 80.2 -> 80.5-82.8 ms.  No.)
   // (Tried: gemm3 for K >= 1024 with >= 256 tiles -- the dim-1024 model's to_qkv / FeedForward-in / FeedForward dgrad.  Back to
