@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -381,6 +381,40 @@ def gen_cfg5_wc(ref):
     print("cfg5_wc: sample norm", float(s65.norm()))
 
 
+def gen_cfg4_wc_train(ref):
+    """Four optimizer steps of the reference on the config-4 architecture (dim 512, depth 12, heads 16, B = 2 x 1024 frames,
+    well-conditioned weights of cfg4_wc): the unmodified reference's loss, then clip_grad_norm_(0.5) and torch.optim.Adam(lr 3e-4,
+    betas (0.9, 0.99)) exactly as VoiceBoxTrainer.train_step does (trainer.py:258-278, optimizer.py:10-35; no warm-up scheduler here).
+    Stored: the per-step losses, the draws of every step, and parameter-update norms of a few tensors after the four steps."""
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=4)
+    for k in state:
+        if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+            state[k] = state[k] * 0.25
+    vb, wrapper = build_reference(ref, cfg, state=state)
+    vb.train()
+    params = [p for p in vb.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=3e-4, betas=(0.9, 0.99))
+    x1 = torch.randn(2, 1024, 512, generator=torch.Generator().manual_seed(40))
+    losses, draws, gnorms = [], [], []
+    for step in range(4):
+        x0, times, frac, rand = replay_draws(x1, seed=50 + step)
+        torch.manual_seed(50 + step)
+        loss = wrapper(x1)
+        opt.zero_grad()
+        loss.backward()
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(params, 0.5)))
+        opt.step()
+        losses.append(float(loss))
+        draws.append(dict(x0_check=x0[0, 0, :4].clone(), times=times, frac=frac, rand=rand))
+        print("cfg4_wc_train step", step, "loss", float(loss), "grad norm", gnorms[-1])
+    named = dict(vb.named_parameters())
+    keys = ["to_pred.weight", "transformer.layers.0.3.to_qkv.weight", "transformer.layers.11.5.3.weight", "transformer.layers.5.2.to_gamma.weight",
+            "transformer.layers.7.3.to_out.weight", "to_embed.weight"]
+    upd = {k: float((named[k].detach() - state[k]).norm()) for k in keys}
+    torch.save(dict(losses=losses, draws=draws, grad_norms=gnorms, update_norms=upd), os.path.join(HERE, "cfg4_wc_train.pt"))
+
+
 def gen_small_wc(ref):
     """A WELL-CONDITIONED variant of `small` for the sampler: the qk-norm gammas are scaled by 0.25, so the attention logits
     10*q.k have std ~5 instead of ~80 (a trained checkpoint's regime; at std 80 the softmax is one-hot and the flow field
@@ -425,8 +459,8 @@ def gen_small_wc(ref):
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
-         "cfg5_wc": gen_cfg5_wc}[w](ref)
+         "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train}[w](ref)
