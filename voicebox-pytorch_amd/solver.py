@@ -21,7 +21,6 @@ Without a graph (use_graph=False) the halves run as fork / join branches per int
 """
 import os
 
-
 import torch
 
 from . import _lib
@@ -32,7 +31,6 @@ SPLIT_OFFSET_US = 60.0  # start delay of the second (third, ...) half-batch stre
 
 class _Part:
     """One concurrently integrated slice [lo, hi) of the batch: its engine and its views of the sampler's static buffers."""
-    pass
 
 
 class MidpointSampler:
@@ -41,7 +39,7 @@ class MidpointSampler:
         self.vb, self.B, self.N, self.steps = voicebox, B, N, steps
         if split is None:
             split = int(os.environ.get("VBX_SAMPLE_SPLIT", "2"))
-        if B < 4 or B % split or split < 1:
+        if split < 1 or B < 4 or B % split:
             split = 1
         self.split = split
         Bp = B // split
