@@ -240,15 +240,17 @@ def test_duration_predictor_host_logic(golden):
                                                                 condition_on_text=False), duration_predictor=dp)
 
 
-@pytest.mark.parametrize("which", ["gemm3", "gemm4"])
+@pytest.mark.parametrize("which", ["gemm3", "gemm4", "epi_stage"])
 def test_gemm_tile_lds_layout_emulation(tmp_path, which):
     """csrc/gemm3_layout.hpp / gemm4_layout.hpp (LDS-DMA source permutation, fragment read addresses, transposed-accumulator
-    column map of the 256 x 256 and 128 x 256 GEMM tiles) replayed on the host against a plain GEMM, plus bank-conflict
-    freedom of every fragment read and the DS-immediate identities the kernels rely on."""
+    column map of the 256 x 256 and 128 x 256 GEMM tiles; gemm3's K-contiguous layout is also the one-round 64-deep tile's)
+    replayed on the host against a plain GEMM, plus bank-conflict freedom of every fragment read and the DS-immediate identities
+    the kernels rely on; csrc/epi_stage_layout.hpp (the row-staged epilogues' transposing LDS image): every (row, chunk) comes back
+    once and in order, writes at most 2-way, reads conflict free."""
     import subprocess
 
     exe = str(tmp_path / f"{which}_layout_check")
-    src = os.path.join(ROOT, "tests", "native", f"{which}_layout_check.cpp")
+    src = os.path.join(ROOT, "tests", "native", f"{which}_layout_check.cpp" if which != "epi_stage" else "epi_stage_check.cpp")
     subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:]

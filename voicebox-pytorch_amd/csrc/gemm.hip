@@ -6,6 +6,7 @@
 // hardware transpose read ds_read_b64_tr_b16, so no transposed copies of weights or activations
 // ever exist in HBM.  The fp32 C tile is staged through LDS so every epilogue stores 16/32 B per lane.
 #include "common.hpp"
+#include "gemm3_layout.hpp"  // g3::kc_slot / g3::kc_byte: the 128-byte-row K-contiguous layout shared with the one-round 64-deep tile
 #include <stdlib.h>
 #include <type_traits>
 
@@ -592,8 +593,9 @@ struct DmaPlan64 {
   VBX_DEV void init(const u16* __restrict__ X, long ld, int o0, int olim, int tid) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      const int s = i * NTHR + tid, row = s >> 3;
-      kq[i] = (((s & 7) ^ (row & 7))) * 8;
+      int row, k8;
+      g3::kc_slot(i * NTHR + tid, row, k8);  // slot -> (row, first k of its 8): host-checked in tests/native/gemm3_layout_check.cpp
+      kq[i] = k8;
       ok[i] = (o0 + row) < olim;
       base[i] = X + (long)(o0 + row) * ld + kq[i];
     }
@@ -612,9 +614,8 @@ struct DmaPlan64 {
 struct FragPlan64 {  // 16 rows [woff + 16 S, +16) x k half KK of a [rows][64] operand stage; woff a multiple of 8
   unsigned a[2];
   VBX_DEV void init(const char* op_base, int woff, int lane) {
-    const int row = woff + (lane & 15);
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) a[kk] = lds_addr(op_base + row * 128 + ((((kk * 4 + (lane >> 4)) ^ (row & 7))) << 4));
+    for (int kk = 0; kk < 2; kk++) a[kk] = lds_addr(op_base + g3::kc_frag_byte(woff, kk, lane));
   }
   template <int S, int KK>
   VBX_DEV void read(bf16x8& out) const {

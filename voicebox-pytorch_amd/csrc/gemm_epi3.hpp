@@ -1,6 +1,7 @@
 // Register epilogues shared by the transposed-accumulator GEMM tiles (gemm3.hip: 256 x 256, gemm4.hip: 128 x 256).
 #pragma once
 #include "common.hpp"
+#include "epi_stage_layout.hpp"
 
 namespace gepi {
 
@@ -60,19 +61,15 @@ constexpr int EPI_STAGE_BYTES = 16384;  // per wave
 template <int NJ>  // 16-column blocks per row: 8 (the wave's 128 columns) or 4 (64 columns: the GEGLU output)
 struct RowStage {
   static constexpr int STRIDE = NJ * 32, CPR = 2 * NJ, RPI = 64 / CPR, ITS = 32 / RPI, BYTES = 32 * STRIDE;
-  // lane (m = lane & 15, g = lane >> 4) owns columns 16 j + 4 g .. + 3 of row 16 il + m.  16-byte chunk c of row r lives at
-  // chunk c ^ (r & (CPR - 1)): the writes are 2-way, the row-major reads conflict free (bank census: see DESIGN.md).
+  // the index functions live in epi_stage_layout.hpp (checked on the host: tests/native/epi_stage_check.cpp)
   static VBX_DEV void put(unsigned buf, int il, int j, int lane, u32x2 v) {
-    const int m = lane & 15, g = lane >> 4;
-    const int rr = il * 16 + m, c = j * 2 + (g >> 1);
-    const unsigned a = buf + rr * STRIDE + (((c ^ (rr & (CPR - 1))) << 4) | ((g & 1) << 3));
+    const unsigned a = buf + epst::put_byte(NJ, il, j, lane);
     asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
   }
-  static VBX_DEV int row_of(int it, int lane) { return it * RPI + lane / CPR; }
-  static VBX_DEV int chunk_of(int lane) { return lane % CPR; }
+  static VBX_DEV int row_of(int it, int lane) { return epst::get_row(NJ, it, lane); }
+  static VBX_DEV int chunk_of(int lane) { return epst::get_chunk(NJ, lane); }
   static VBX_DEV u32x4 get(unsigned buf, int it, int lane) {
-    const int rr = row_of(it, lane), c = chunk_of(lane);
-    const unsigned a = buf + rr * STRIDE + ((c ^ (rr & (CPR - 1))) << 4);
+    const unsigned a = buf + epst::get_byte(NJ, it, lane);
     u32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
     return v;
