@@ -103,6 +103,75 @@ def test_train_step_world2_on_one_gpu():
     assert 1.0 < loss < 10.0
 
 
+def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
+    """wd > 0 (optimizer.py:10-35): AdamW with decoupled decay on the ndim >= 2 parameters only.  TrainStep(wd=...) must equal torch:
+    the same gradients -> clip_grad_norm_(0.5) -> torch.optim.AdamW over get_optimizer's two parameter groups; and the trainer's
+    checkpoint must carry those two groups in a torch.optim.AdamW-loadable state."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    wd, lr = 0.3, 1e-3
+
+    def make():
+        vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(g["state"], strict=False)
+        vb = vb.to(dev)
+        return vb, vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+
+    def get_optimizer(params):  # optimizer.py:10-35 restated
+        params = list(params)
+        wd_p, no_wd = [p for p in params if p.ndim >= 2], [p for p in params if p.ndim < 2]
+        return torch.optim.AdamW([{"params": wd_p}, {"params": no_wd, "weight_decay": 0}], lr=lr, weight_decay=wd, betas=(0.9, 0.99), eps=1e-8)
+
+    vb_r, w_r = make()
+    opt = get_optimizer(w_r.parameters())
+    vb, w = make()
+    ts = TrainStep(w, lr=lr, max_grad_norm=0.5, wd=wd)
+    for step in range(2):
+        with rng_override(**draws):
+            w_r(g["x1"].to(dev)).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in w_r.parameters() if p.grad is not None], 0.5)
+        opt.step(); opt.zero_grad()
+        with rng_override(**draws):
+            ts.step(g["x1"].to(dev))
+    ref = dict(vb_r.named_parameters())
+    for k, p in vb.named_parameters():
+        if p.requires_grad:
+            upd, upd_r = p.detach() - g["state"][k].to(dev), ref[k].detach() - g["state"][k].to(dev)
+            e = float((upd - upd_r).norm() / upd_r.norm().clamp(min=1e-20))
+            assert e < 3e-2, (k, e)
+    # the decay really acted: a 2-D weight moved differently from an undecayed run
+    vb0, w0 = make()
+    ts0 = TrainStep(w0, lr=lr, max_grad_norm=0.5)
+    with rng_override(**draws):
+        ts0.step(g["x1"].to(dev))
+    with rng_override(**draws):
+        ts0.step(g["x1"].to(dev))
+    assert float((vb0.to_pred.weight.detach() - vb.to_pred.weight.detach()).abs().max()) > 1e-5
+
+    class Latents(torch.utils.data.Dataset):
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            return torch.randn(40, 64, generator=torch.Generator().manual_seed(i))
+
+    vb2, w2 = make()
+    tr = vbx.VoiceBoxTrainer(w2, batch_size=2, dataset=Latents(), num_train_steps=2, wd=wd, valid_frac=0.25, log_every=1,
+                             save_results_every=100, save_model_every=1, results_folder=str(tmp_path), force_clear_prev_results=True)
+    tr.train()
+    pkg = torch.load(str(tmp_path / "voicebox.1.pt"), map_location="cpu")
+    groups = pkg["optim"]["param_groups"]
+    assert len(groups) == 2 and groups[0]["weight_decay"] == wd and groups[1]["weight_decay"] == 0
+    ref_opt = get_optimizer([torch.nn.Parameter(p.detach().cpu().clone()) for p in w2.parameters()])
+    ref_opt.load_state_dict(pkg["optim"])
+    n_wd = sum(1 for p in w2.parameters() if p.ndim >= 2)
+    assert len(groups[0]["params"]) == n_wd
+
+
 def test_trainer_accumulation_and_reference_checkpoint_format(tmp_path, golden):
     """VoiceBoxTrainer (trainer.py:60-321 mirror): gradient accumulation equals one step on the concatenated batch, and the
     checkpoint is the reference's {'model','optim','scheduler'} with a torch.optim.Adam-loadable optimizer state."""

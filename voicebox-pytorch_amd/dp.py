@@ -121,9 +121,13 @@ class WarmupCosineLR:
 
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
-                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None):
+                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0.):
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        # wd > 0: AdamW as get_optimizer builds it (optimizer.py:10-35): decoupled decay p *= 1 - lr * wd on the parameters with
+        # ndim >= 2 only (separate_weight_decayable_params), applied as one multi-tensor multiply in front of the fused Adam pass
+        self.wd = float(wd)
+        self._wd_params = [p for p in wrapper.voicebox.parameters() if p.requires_grad and p.ndim >= 2] if self.wd > 0 else []
         self.lr_schedule = lr_schedule  # e.g. WarmupCosineLR; an explicit `lr=` passed to step() wins
         self.grad_comm_dtype = grad_comm_dtype  # None / torch.float32: exact fp32 exchange (the reference's DDP); torch.bfloat16 halves it
         self.group = group
@@ -234,6 +238,12 @@ class TrainStep:
         self.steps += 1
         _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
+        if self._wd_params:
+            with torch.no_grad():
+                torch._foreach_mul_(self._wd_params, 1.0 - float(lr if lr is not None else self.lr) * self.wd)
+            # the in-place multiply bumped the parameters' version counters; the fused pass below rewrites every operand copy from
+            # the updated values anyway, so the training engine need not repack first
+            eng.packed_version = self.fp.weights_key()
         # Adam + refresh of the training engine's fp16/bf16 operand copies in one pass (other engines repack lazily)
         if os.environ.get("VBX_FUSED_ADAM", "1") != "0":
             eng.adam_step_packed(self.gflat, self.m, self.v, float(lr if lr is not None else self.lr), self.betas[0], self.betas[1],

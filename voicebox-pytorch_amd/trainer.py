@@ -69,8 +69,7 @@ class VoiceBoxTrainer(nn.Module):
                  accelerate_kwargs: dict = dict()):
         super().__init__()
         assert isinstance(cfm_wrapper, ConditionalFlowMatcherWrapper)
-        if wd > 0:
-            raise NotImplementedError("AdamW weight decay is not built into the fused optimizer step (the reference default is wd = 0)")
+        self.wd = float(wd)  # > 0: AdamW with decay on the ndim >= 2 parameters (get_optimizer, optimizer.py:10-35)
         if split_batches:
             raise NotImplementedError("split_batches: every rank loads its own batch_size samples (Accelerate's default)")
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -98,7 +97,7 @@ class VoiceBoxTrainer(nn.Module):
         self.num_train_steps = len(dataset) // batch_size * num_epochs if exists(num_epochs) else num_train_steps
         self.num_warmup_steps = num_warmup_steps if exists(num_warmup_steps) else 0
         self.schedule = WarmupCosineLR(lr, self.num_train_steps, self.num_warmup_steps, initial_lr)
-        self.train_step_fn = TrainStep(cfm_wrapper, lr=lr, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=max_grad_norm,
+        self.train_step_fn = TrainStep(cfm_wrapper, lr=lr, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=max_grad_norm, wd=self.wd,
                                        lr_schedule=None)
 
         sampler = None
@@ -114,11 +113,21 @@ class VoiceBoxTrainer(nn.Module):
         self.results_folder.mkdir(parents=True, exist_ok=True)
 
     # ---- checkpoint format of the reference (trainer.py:191-207)
+    def _optim_param_order(self):
+        """Parameters in the order the reference's optimizer holds them: cfm_wrapper.parameters(), or -- with weight decay -- the
+        ndim >= 2 parameters followed by the others (the two param groups get_optimizer builds, optimizer.py:4-9,24-30)."""
+        params = list(self.cfm_wrapper.parameters())
+        if self.wd > 0:
+            wd_p = [p for p in params if p.ndim >= 2]
+            return wd_p + [p for p in params if p.ndim < 2], len(wd_p)
+        return params, len(params)
+
     def _optim_state_dict(self):
         ts = self.train_step_fn
         fp = ts.fp
         by_param = {id(fp.slots[s]): s for s in fp.order}
-        state, params = {}, list(self.cfm_wrapper.parameters())
+        state = {}
+        params, n_wd = self._optim_param_order()
         for i, p in enumerate(params):
             s = by_param.get(id(p))
             if s is None or ts.steps == 0:
@@ -126,16 +135,21 @@ class VoiceBoxTrainer(nn.Module):
             o, n = fp.offsets[s], p.numel()
             state[i] = {'step': torch.tensor(float(ts.steps)), 'exp_avg': ts.m[o:o + n].view(p.shape).clone(),
                         'exp_avg_sq': ts.v[o:o + n].view(p.shape).clone()}
-        group = dict(lr=self.schedule.cur, betas=tuple(ts.betas), eps=ts.eps, weight_decay=0, amsgrad=False, maximize=False,
-                     foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(params))))
-        return {'state': state, 'param_groups': [group]}
+        base = dict(lr=self.schedule.cur, betas=tuple(ts.betas), eps=ts.eps, amsgrad=False, maximize=False, foreach=None,
+                    capturable=False, differentiable=False, fused=None)
+        if self.wd > 0:
+            groups = [dict(base, weight_decay=self.wd, params=list(range(n_wd))),
+                      dict(base, weight_decay=0, params=list(range(n_wd, len(params))))]
+        else:
+            groups = [dict(base, weight_decay=0, params=list(range(len(params))))]
+        return {'state': state, 'param_groups': groups}
 
     def _load_optim_state_dict(self, sd):
         ts = self.train_step_fn
         fp = ts.fp
         by_param = {id(fp.slots[s]): s for s in fp.order}
         steps = 0
-        for i, p in enumerate(self.cfm_wrapper.parameters()):
+        for i, p in enumerate(self._optim_param_order()[0]):
             st = sd['state'].get(i)
             s = by_param.get(id(p))
             if st is None or s is None:
