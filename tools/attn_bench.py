@@ -1,4 +1,4 @@
-"""Stand-alone attention forward/backward timing at the benchmark shape (B=8, H=16, Np=1025, |q|=|k|=8, scale 10).
+"""Stand-alone attention forward/backward timing at the benchmark shape (B=8, H=16, Np=1040 = 1024 frames + 16 register tokens; NP=<n> overrides, |q|=|k|=8, scale 10).
 Usage: python tools/attn_bench.py [iters]   (run under rocprofv3 --kernel-trace --stats for per-kernel durations)."""
 import os, sys, torch
 
@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voicebox_pytorch_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, H, Np = 8, 16, 1025
+B, H, Np = 8, 16, int(os.environ.get("NP", 1040))  # frames + 16 register tokens
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cold = len(sys.argv) > 2 and sys.argv[2] == "cold"  # evict L2 + MALL between launches (per-kernel times then come from rocprofv3)
 scrub = torch.empty(1 << 28, dtype=torch.float32, device="cuda:0") if cold else None

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voicebox_pytorch_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, H, Np = 8, 16, int(os.environ.get("NP", 1025))
+B, H, Np = 8, 16, int(os.environ.get("NP", 1040))
 g = torch.Generator().manual_seed(0)
 q = torch.randn(B, H, Np, 64, generator=g); k = torch.randn(B, H, Np, 64, generator=g); v = torch.randn(B, H, Np, 64, generator=g)
 q = q / q.norm(dim=-1, keepdim=True) * 8; k = k / k.norm(dim=-1, keepdim=True) * 8

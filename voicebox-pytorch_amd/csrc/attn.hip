@@ -272,8 +272,8 @@ VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratc
 // and run back to back there.  With the plain (tile, h, b) grid the 9 tiles of a head sat on 9 different XCDs and every
 // panel was fetched 8-9x from HBM/MALL (rocprofv3 FETCH_SIZE: 290 MB per forward launch against 51 MB of q|k|v).
 struct AttnCoord { int tile, h, b; bool ok; };
-// blockIdx -> (128-row tile, head, batch).  The ragged tail tile of every (b, h) (Np % 128 rows: ONE row at the benchmark's
-// Np = 1025) is a workgroup with one active wave that still walks the whole key loop: it lives about as long as a full workgroup
+// blockIdx -> (128-row tile, head, batch).  The ragged tail tile of every (b, h) (Np % 128 rows: the 16 register-token rows at the
+// benchmark's Np = 1040) is a workgroup with one active wave that still walks the whole key loop: it lives about as long as a full workgroup
 // (it is bound by the tile round trip, not by throughput) while using a fraction of a CU.  Tails therefore go FIRST, where they
 // overlap with full workgroups; dispatched last they were a 30 us drain phase with the chip empty (tools/attn_timeline.py).
 // xmap bit 0: consecutive ids rotate over the 8 XCDs, all tiles of a (b, h) on one XCD sharing its L2 copy of K / V;
