@@ -2,7 +2,8 @@
 clip + Adam) of VoiceBox dim 512 / depth 12 / heads 16 on synthetic (B=8 per GPU, 1024 frames, dim 512)
 -- BASELINE.json `metric`, configs[3] (the largest single-GPU configuration at N=1; weak scaling for N>1).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1 without a launcher: re-executes itself as N ranks through
+                                                            torch.distributed.run; under a launcher it reads RANK / WORLD_SIZE)
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
   roofline     : the dominant kernel's achieved TFLOP/s (algorithmic FLOPs / HIP-event-measured launch time)
@@ -148,8 +149,9 @@ def isolated_gemm_us(args, dev, which):
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed PMC passes of this command (tools/pmc_summary.py)."""
-    for name in ("r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
+    """HBM bytes per launch of the stage's kernel from the COMMITTED PMC passes of this command (tools/pmc_summary.py) -- a
+    constant read from profiles/, not measured in this run: returns (bytes, source file)."""
+    for name in ("r03_train_pmc.json", "r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue
@@ -157,14 +159,14 @@ def pmc_traffic(stage):
         key = {"fwd ff_in": "GEGLU", "fwd to_qkv": "QKV", "wgrad (4 GEMMs)": "gemm3_grouped", "bwd attention": "attn_bwd",
                "fwd attention": "attn_fwd"}.get(stage)
         if key is None:
-            return None
+            return None, None
         tot = 0.0
         for kname, e in tab.items():
             if key in kname and "hbm_bytes_per_launch" in e:
                 tot += e["hbm_bytes_per_launch"]
         if tot:
-            return round(tot)
-    return None
+            return round(tot), f"profiles/{name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+    return None, None
 
 
 def cpu_model():
@@ -178,37 +180,63 @@ def cpu_model():
 
 
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's path, oracle/restate.py) on this box's host cores: fwd+bwd CFM steps on a
-    bounded sample -- batch 2 of the 8 (the CPU path's cost per sample does not depend on the batch: samples never interact),
-    same frames / dim / depth; 1 warm-up + 3 timed steps, best and median reported."""
+    """The CPU oracle (a port of the reference's path, oracle/restate.py, fp32 torch CPU) on this box's host cores, on a bounded
+    sample of the SAME workload: (1) a thread sweep (16 / 32 / 64 threads, capped at the host's cores) at batch 2 -- one warm-up
+    + one timed fwd+bwd CFM step each -- to find where torch's CPU kernels stop scaling; (2) the benchmark's own per-GPU batch at the
+    best thread count, one warm-up + two timed steps.  `value` = frames/s of (2), `cores` = the threads it used."""
     from oracle import restate
 
-    # torch CPU matmuls scale poorly past a few dozen threads (256 threads: 300 s/step measured); cap and report it
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     cfg = restate.Cfg(dim=args.dim, depth=args.depth, heads=args.heads, dim_head=64)
     state = restate.init_state_dict(cfg, seed=0)
     p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in state.items()}
-    Bs = 2
-    g = torch.Generator().manual_seed(0)
-    x1, x0 = torch.randn(Bs, args.frames, args.dim, generator=g), torch.randn(Bs, args.frames, args.dim, generator=g)
-    times, frac, rand = torch.rand(Bs, generator=g), 0.7 + 0.3 * torch.rand(Bs, generator=g), torch.rand(Bs, generator=g)
-    ts = []
-    for it in range(4):
-        t0 = time.perf_counter()
-        loss = restate.cfm_loss(p, cfg, x1, x0, times, frac, rand)
-        loss.backward()
-        dt = time.perf_counter() - t0
-        if it > 0:
-            ts.append(dt)
-        for v in p.values():
-            v.grad = None
-    ts.sort()
+
+    def timed_steps(Bs, n_timed):
+        g = torch.Generator().manual_seed(0)
+        x1, x0 = torch.randn(Bs, args.frames, args.dim, generator=g), torch.randn(Bs, args.frames, args.dim, generator=g)
+        times, frac, rand = torch.rand(Bs, generator=g), 0.7 + 0.3 * torch.rand(Bs, generator=g), torch.rand(Bs, generator=g)
+        ts = []
+        for it in range(1 + n_timed):
+            t0 = time.perf_counter()
+            loss = restate.cfm_loss(p, cfg, x1, x0, times, frac, rand)
+            loss.backward()
+            dt = time.perf_counter() - t0
+            if it > 0:
+                ts.append(dt)
+            for v in p.values():
+                v.grad = None
+        return sorted(ts)
+
+    host = os.cpu_count() or 1
+    sweep = {}
+    for th in sorted({min(t, host) for t in (16, 32, 64)}):
+        torch.set_num_threads(th)
+        sweep[th] = round(2 * args.frames / timed_steps(2, 1)[0], 1)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    Bs = args.batch
+    ts = timed_steps(Bs, 2)
     best, med = ts[0], ts[len(ts) // 2]
     return {"value": round(Bs * args.frames / best, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "median_value": round(Bs * args.frames / med, 1), "cpu": cpu_model(), "host_cores_total": os.cpu_count(),
-            "sample": f"oracle fwd+bwd (fp32, torch CPU, {cores} threads), batch {Bs} of {args.batch}, {args.frames} frames, "
-                      f"dim {args.dim}, depth {args.depth}; 1 warm-up + 3 timed steps; best {best:.2f} s/step, median {med:.2f} s/step"}
+            "median_value": round(Bs * args.frames / med, 1), "cpu": cpu_model(), "host_cores_total": host,
+            "thread_sweep_batch2_frames_per_s": sweep,
+            "sample": f"oracle fwd+bwd (fp32, torch CPU), batch {Bs} (the benchmark's per-GPU batch) x {args.frames} frames, dim {args.dim}, "
+                      f"depth {args.depth}, {cores} threads (best of the batch-2 sweep {sweep}); 1 warm-up + 2 timed steps; "
+                      f"best {best:.2f} s/step, median {med:.2f} s/step"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks through torch.distributed.run on this node (one process per
+    GPU, RCCL over xGMI; rendezvous on 127.0.0.1) and pass its output / exit code through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBX_SELF_LAUNCHED="1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -227,8 +255,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sample", action="store_true", help="train mode: skip the 64-interval sample leg")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
+    ap.add_argument("--bucket-mb", type=int, default=0, help="gradient all-reduce bucket size in MiB (0: the library default)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -241,7 +272,7 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     vbx, vb, wrapper = build_model(args, dev)
     torch.manual_seed(1234 + rank)
@@ -255,7 +286,8 @@ def main():
     if args.mode == "train":
         from voicebox_pytorch_amd.dp import TrainStep
 
-        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
+        kw = {"bucket_bytes": args.bucket_mb << 20} if args.bucket_mb > 0 else {}
+        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None, **kw)
         step = lambda: ts.step(x)
         units_per_step = args.batch * args.frames
         flops_per_step_per_gpu = 3.0 * fwd_flops_per_frame(args.dim, args.depth, args.heads, args.frames, 16) * units_per_step
@@ -303,15 +335,24 @@ def main():
                                    f"{args.batch}x{args.frames} frames per GPU, {args.mode}" + (", GateLoop layers" if args.gateloop else ""),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
             "step_tflops_per_gpu": round(step_tf, 1), "step_roofline_frac": round(step_tf / PEAK_MFMA_TFLOPS, 4),
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
         }
+        if dist is not None:
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001  (diagnostic field only)
+                out["rccl_version"] = f"unavailable ({type(e).__name__})"
+            out["grad_comm"] = args.grad_comm
+            out["bucket_mb"] = args.bucket_mb
         if loss_val is not None:
             out["final_loss"] = round(loss_val, 5)
         # ---- roofline: the DOMINANT MFMA stage of the timed workload, timed in situ with HIP events on the launch stream
         mf = [r for r in rows if "frac" in r]
         if mf:
             top = mf[0]
+            traffic, traffic_src = pmc_traffic(top["stage"])
             out["roofline"] = {"bound": "mfma", "kernel": top["stage"], "achieved": top["tflops"], "peak": PEAK_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": top["frac"], "traffic": pmc_traffic(top["stage"]),
+                               "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic, "traffic_source": traffic_src,
                                "flops_per_launch": top["gflop_per_launch"] * 1e9, "us_per_launch": top["us_per_launch"],
                                "measured": "HIP events around the stage's launch(es) on the launch stream, in situ (vbx_prof_*), "
                                            "averaged over the layers of 3 extra steps",

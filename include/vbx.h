@@ -127,12 +127,18 @@ int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const vo
 int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, const uint8_t* mask,
                  void* out16 /* fp16 [B,Np,H*64] */, void* out_bf16 /* optional bf16 copy (backward operand) */,
                  float* lse, int B, int H, int Np, float scale, void* stream);
-/* backward.  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
- * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d]. */
+/* backward (autograd of attend.py:121-135).  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
+ * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d].
+ * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL.  With scratch the ONE-PASS
+ * kernel runs (every S / dP block evaluated once; dq summed over the key blocks of a head by an ordered, deterministic chain of
+ * workgroups through the scratch); without it the two-body kernel of round 2 (S / dP evaluated twice).
+ * vbx_attn_bwd_select: 0 automatic (default), 1 two-body always, 2 one-pass required (error without scratch). */
+size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
+int vbx_attn_bwd_select(int variant);
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
                  const uint8_t* mask, const void* out /* forward output [B,Np,H*64] */, int out_is_f16,
                  const void* dout, const float* lse, float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H,
-                 int Np, float scale, void* stream);
+                 int Np, float scale, void* scratch, void* stream);
 /* backward of MultiheadRMSNorm + rotary (voicebox_pytorch.py:286-287,199): consumes dq/dk fp32
  * [B,H,Np,64] and the saved q16/k16 + rnorm, writes d(raw q|k) bf16 into dqkv[(b*Np+n)*ld + which*H*64
  * + h*64 + d] and partial gamma grads gpart[2][vbx_qknorm_rope_bwd_gpart_rows(B)][H][64]. */
@@ -143,7 +149,8 @@ int vbx_attn_bwd_fused_tiles(int Np);
 int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
                        const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, const float* q_rnorm,
                        const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos, const float* rot_sin,
-                       float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* stream);
+                       float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* scratch,
+                       void* stream);
 int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
                         const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
                         const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np,

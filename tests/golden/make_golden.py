@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -456,11 +456,95 @@ def gen_small_wc(ref):
     print("small_wc: loss", float(loss))
 
 
+def _wc(state):
+    for k in state:
+        if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+            state[k] = state[k] * 0.25
+    return state
+
+
+def gen_cfg4_seeds(ref):
+    """Round 3: the config-4 architecture (dim 512, depth 12, heads 16, N = 1024) at the REFERENCE'S OWN
+    initialisation over several seeds -- five at B = 2 (weights seed s, data seed 100+s, draws seed 200+s for s = 10..14) and one at
+    B = 8 (s = 15, BASELINE's batch) -- so that the GPU test can assert the |loss difference| DISTRIBUTION instead of one seed.
+    Stored per seed: the loss, every gradient norm, the total gradient norm, the draws."""
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    out = {}
+    for s, b in ((10, 2), (11, 2), (12, 2), (13, 2), (14, 2), (15, 8)):
+        state = restate.init_state_dict(cfg, seed=s)
+        vb, wrapper = build_reference(ref, cfg, state=state)
+        x1 = torch.randn(b, 1024, 512, generator=torch.Generator().manual_seed(100 + s))
+        x0, times, frac, rand = replay_draws(x1, seed=200 + s)
+        torch.manual_seed(200 + s)
+        loss = wrapper(x1)
+        loss.backward()
+        gn = {k: float(p.grad.norm()) for k, p in vb.named_parameters() if p.grad is not None}
+        tot = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in vb.parameters() if p.grad is not None)))
+        out[s] = dict(batch=b, loss=loss.detach().clone(), grad_norms=gn, grad_total=tot, x0_check=x0[0, 0, :4].clone(),
+                      times=times, frac=frac, rand=rand)
+        print("cfg4_seeds", s, "B", b, "loss", float(loss), "grad total", tot, flush=True)
+        del vb, wrapper, state
+    torch.save(out, os.path.join(HERE, "cfg4_seeds.pt"))
+
+
+def gen_cfg3(ref):
+    """Round 3: BASELINE config 3 -- dim 1024, heads 16, depth 12 -- at B = 2, N = 1024 from the unmodified
+    reference, once at the reference's initialisation and once well-conditioned (qk-norm gammas x 0.25).  Weights by
+    oracle.restate.init_state_dict(cfg, seed=3) (1.3 GB: not committed).  Stored: loss, every gradient norm + 16-element slices,
+    rows of one eval prediction."""
+    cfg = restate.Cfg(dim=1024, depth=12, heads=16, dim_head=64)
+    out = {}
+    for name in ("init", "wc"):
+        state = restate.init_state_dict(cfg, seed=3)
+        if name == "wc":
+            _wc(state)
+        vb, wrapper = build_reference(ref, cfg, state=state)
+        x1 = torch.randn(2, 1024, 1024, generator=torch.Generator().manual_seed(30))
+        x0, times, frac, rand = replay_draws(x1, seed=31)
+        torch.manual_seed(31)
+        loss = wrapper(x1)
+        loss.backward()
+        gn = {k: float(p.grad.norm()) for k, p in vb.named_parameters() if p.grad is not None}
+        gs = {k: p.grad.flatten()[:16].clone() for k, p in vb.named_parameters() if p.grad is not None}
+        vb.eval()
+        with torch.no_grad():
+            pred = vb(x1, times=torch.tensor(0.37), cond_token_ids=None, cond=x1, cond_drop_prob=0.0)
+        out[name] = dict(loss=loss.detach().clone(), grad_norms=gn, grad_slices=gs, pred_norm=float(pred.norm()),
+                         pred_rows=pred[:, 500:504, :].clone(), x0_check=x0[0, 0, :4].clone(), times=times, frac=frac, rand=rand)
+        print("cfg3", name, "loss", float(loss), "pred norm", float(pred.norm()), flush=True)
+        del vb, wrapper, state
+    torch.save(out, os.path.join(HERE, "cfg3.pt"))
+
+
+def gen_cfg5_wc_b8(ref):
+    """Round 3: BASELINE config 5 at its own batch -- cfm_wrapper.sample(cond = (8, 1024, 512), steps = 65) = 64
+    midpoint intervals = 128 function evaluations of the dim-512 / depth-12 network on the unmodified reference's CPU path, EIGHT
+    distinct samples, well-conditioned weights of cfg4_wc.  ~15-20 minutes of CPU.  Stored: 16 rows of every sample + norms."""
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    state = _wc(restate.init_state_dict(cfg, seed=4))
+    vb, wrapper = build_reference(ref, cfg, state=state)
+    vb.eval()
+    x1 = torch.randn(8, 1024, 512, generator=torch.Generator().manual_seed(48))
+    torch.manual_seed(49)
+    y0 = torch.randn_like(x1)
+    torch.manual_seed(49)
+    import time
+    t0 = time.time()
+    s65 = wrapper.sample(cond=x1, steps=65)
+    print("cfg5_wc_b8: 64-interval CPU sample of 8 took %.1f s" % (time.time() - t0), flush=True)
+    torch.save(dict(y0_check=y0[:, 0, :4].clone(), sample65_rows=s65[:, 500:516, :].clone(), sample65_first=s65[:, :4, :].clone(),
+                    sample65_norms=s65.flatten(1).norm(dim=1).clone(), sample65_absmax=float(s65.abs().max()),
+                    cpu_seconds=time.time() - t0),
+               os.path.join(HERE, "cfg5_wc_b8.pt"))
+    print("cfg5_wc_b8: sample norms", s65.flatten(1).norm(dim=1).tolist())
+
+
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
-         "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train}[w](ref)
+         "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
+         "cfg5_wc_b8": gen_cfg5_wc_b8}[w](ref)

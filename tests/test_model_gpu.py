@@ -60,6 +60,10 @@ def emulated_oracle_grads(cfg, state, x1, x0, times, frac, rand, mask=None):
     return float(loss), {k: v.grad for k, v in p.items() if v.grad is not None}
 
 
+# per-tensor relative error of the dim-64 golden's gradients against the unmodified reference's: worst tensor / median
+REF_GRAD_WORST_SMALL, REF_GRAD_MEDIAN_SMALL = 0.35, 0.12
+
+
 def test_small_golden_loss_and_grads(golden):
     from voicebox_pytorch_amd.masks import rng_override
 
@@ -83,6 +87,13 @@ def test_small_golden_loss_and_grads(golden):
         for k in ("to_pred.weight", "transformer.final_norm.gamma", "transformer.layers.1.5.3.weight",
                   "transformer.layers.1.5.0.weight", "transformer.layers.1.3.to_out.weight"):
             assert rel(named[k].grad, g[grads_key][k]) < 5e-2, (k, rel(named[k].grad, g[grads_key][k]))
+        # EVERY tensor against the unmodified reference's gradient (the emulated oracle below is a second, tighter
+        # check, not the only one).  Bounds = measured + margin: the tensors upstream of a near-one-hot softmax are the loose ones.
+        rerrs = {k: rel(named[k].grad, ref) for k, ref in g[grads_key].items()}
+        rworst = sorted(rerrs.items(), key=lambda kv: -kv[1])
+        rmed = sorted(rerrs.values())[len(rerrs) // 2]
+        print("relative grad errors vs REFERENCE", mask_key, "median", round(rmed, 4), [(k, round(v, 4)) for k, v in rworst[:8]])
+        assert rworst[0][1] < REF_GRAD_WORST_SMALL and rmed < REF_GRAD_MEDIAN_SMALL, (rmed, rworst[:8])
         # gradients vs the emulated-precision oracle: every tensor, bf16-GEMM tolerance
         eloss, egrads = emulated_oracle_grads(cfg, g["state"], g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask)
         assert abs(float(loss) - eloss) < 2e-4, (float(loss), eloss)
@@ -175,6 +186,10 @@ def test_cfg1_loss_parity(golden):
         assert errs[k] < 5e-2, (k, errs[k])
         sl = named[k].grad.flatten()[:16].cpu()
         assert float((sl - g["grad_slices"][k]).abs().max()) < 6e-2 * float(g["grad_slices"][k].abs().max()), k
+    # EVERY tensor's gradient norm against the unmodified reference's (the golden keeps norms + 16-element slices of all tensors)
+    med = sorted(errs.values())[len(errs) // 2]
+    print("cfg1 grad-norm rel errors vs REFERENCE: median", round(med, 4), "worst", worst[:4])
+    assert worst[0][1] < 0.25 and med < 0.06, (med, worst[:6])
     # every tensor against the emulated-precision oracle (see restate.py)
     eloss, egrads = emulated_oracle_grads(cfg, state, x1, x0, g["times"], g["frac"], g["rand"])
     assert abs(float(loss) - eloss) < 2e-4, (float(loss), eloss)
@@ -576,7 +591,9 @@ def test_cfg4_depth12_parity(golden):
         s = wrapper.sample(cond=x1.to(dev), steps=5)
     e_s = rel(s[:, 500:504, :], g["sample5_rows"])
     print("cfg4 4-interval sample: rows rel", e_s, "norm err", abs(float(s.norm()) - g["sample5_norm"]) / g["sample5_norm"])
-    assert torch.isfinite(s).all() and e_s < 1.0, e_s  # chaotic flow (see the loss note above): reported, not a parity claim
+    # chaotic flow (see the loss note above): the row error is REPORTED, not asserted (any bound here would be vacuous); what is
+    # asserted is finiteness and the norm, which is stable
+    assert torch.isfinite(s).all() and abs(float(s.norm()) - g["sample5_norm"]) / g["sample5_norm"] < 2e-2
 
 
 def test_cfg4_depth12_well_conditioned(golden):
@@ -621,6 +638,120 @@ def test_cfg4_depth12_well_conditioned(golden):
     # from the reference by 1.2e-3 on these rows, and the CPU oracle with this path's fp16 operand roundings emulated by 0.184
     # (tools/precision_ablation.py / DESIGN.md section 2).  The solver itself is pinned tightly by the depth-2 test below (3e-4).
     assert e_s < 0.3, e_s
+
+
+def _wc(state):
+    for k in state:
+        if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+            state[k] = state[k] * 0.25
+    return state
+
+
+def test_cfg4_depth12_reference_init_loss_distribution(golden):
+    """the config-4 architecture (dim 512, depth 12, heads 16, N = 1024) at the REFERENCE'S OWN initialisation over
+    SIX seeds of the unmodified reference (tests/golden/cfg4_seeds.pt: five at B = 2, one at BASELINE's B = 8) -- the loss-difference
+    DISTRIBUTION, not one lucky seed.  At this initialisation the attention logits have std ~80 and the 12-layer map is chaotic
+    (every single operand class rounded to fp16 moves the loss by O(1e-3) with either sign), so the fast path's
+    stated depth-12 tolerance at reference init is 3e-3 on EVERY seed and 2e-3 on the mean |difference|; the 1e-3 of the north star
+    is asserted where the problem is well posed (depth 2: cfg1; depth 12 with trained-regime logits: cfg4_wc, cfg3 "wc")."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg4_seeds")
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    diffs, gtot = {}, {}
+    for s_, rec in sorted(g.items()):
+        state = restate.init_state_dict(cfg, seed=s_)
+        vbx, vb, wrapper = build(dict(dim=512, depth=12, heads=16), state)
+        b = rec["batch"]
+        x1 = torch.randn(b, 1024, 512, generator=torch.Generator().manual_seed(100 + s_))
+        torch.manual_seed(200 + s_)
+        x0 = torch.randn_like(x1)
+        assert torch.equal(x0[0, 0, :4], rec["x0_check"])
+        with rng_override(x0=x0, times=rec["times"], frac_lengths=rec["frac"], rand=rec["rand"]):
+            loss = wrapper(x1.to(dev))
+        loss.backward()
+        tot = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in vb.parameters() if p.grad is not None)))
+        diffs[s_] = float(loss) - float(rec["loss"])
+        gtot[s_] = abs(tot - rec["grad_total"]) / rec["grad_total"]
+        assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None)
+        del vb, wrapper
+        torch.cuda.empty_cache()
+    mean_abs = sum(abs(v) for v in diffs.values()) / len(diffs)
+    print("cfg4 reference-init loss differences by seed", {k: round(v, 5) for k, v in diffs.items()}, "mean |d|", round(mean_abs, 5))
+    print("cfg4 reference-init total-gradient-norm relative differences", {k: round(v, 3) for k, v in gtot.items()})
+    assert max(abs(v) for v in diffs.values()) < 3e-3, diffs
+    assert mean_abs < 2e-3, (mean_abs, diffs)
+
+
+def test_cfg3_dim1024_depth12_vs_reference(golden):
+    """BASELINE config 3 -- dim 1024, heads 16, DEPTH 12 -- at B = 2, N = 1024 against the unmodified reference
+    (tests/golden/cfg3.pt).  Well-conditioned weights (qk-norm gammas x 0.25, the trained regime): loss within 1e-3, EVERY gradient
+    norm within 5 %, an eval prediction within 1.5 %.  Reference initialisation (logit std ~80, chaotic): loss within 3e-3 and a
+    stable prediction norm, gradient norms reported."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg3")
+    cfg = restate.Cfg(dim=1024, depth=12, heads=16, dim_head=64)
+    for name in ("wc", "init"):
+        rec = g[name]
+        state = restate.init_state_dict(cfg, seed=3)
+        if name == "wc":
+            _wc(state)
+        vbx, vb, wrapper = build(dict(dim=1024, depth=12, heads=16), state)
+        x1 = torch.randn(2, 1024, 1024, generator=torch.Generator().manual_seed(30))
+        torch.manual_seed(31)
+        x0 = torch.randn_like(x1)
+        assert torch.equal(x0[0, 0, :4], rec["x0_check"])
+        with rng_override(x0=x0, times=rec["times"], frac_lengths=rec["frac"], rand=rec["rand"]):
+            loss = wrapper(x1.to(dev))
+        dl = abs(float(loss) - float(rec["loss"]))
+        loss.backward()
+        named = dict(vb.named_parameters())
+        errs = {k: abs(float(named[k].grad.norm()) - n) / max(n, 1e-12) for k, n in rec["grad_norms"].items()}
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])
+        med = sorted(errs.values())[len(errs) // 2]
+        vb.eval()
+        with torch.no_grad():
+            pred = vb(x1.to(dev), times=torch.tensor(0.37), cond_token_ids=None, cond=x1.to(dev), cond_drop_prob=0.0)
+        e_rows = rel(pred[:, 500:504, :], rec["pred_rows"])
+        e_norm = abs(float(pred.norm()) - rec["pred_norm"]) / rec["pred_norm"]
+        print(f"cfg3 {name}: loss {float(loss):.6f} reference {float(rec['loss']):.6f} |d| {dl:.2e}; grad-norm rel err median {med:.4f} worst",
+              [(k, round(v, 4)) for k, v in worst[:4]], "pred rows rel", round(e_rows, 4), "pred norm rel", round(e_norm, 5))
+        assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None) and torch.isfinite(pred).all()
+        if name == "wc":
+            assert dl < 1e-3, dl
+            assert worst[0][1] < 5e-2, worst[:6]
+            assert e_rows < 1.5e-2 and e_norm < 2e-3, (e_rows, e_norm)
+        else:
+            assert dl < 3e-3, dl
+            assert e_norm < 5e-3, e_norm
+        del vb, wrapper, named
+        torch.cuda.empty_cache()
+
+
+def test_cfg5_b8_64_interval_sample_vs_cpu_reference(golden):
+    """BASELINE config 5 AT ITS OWN BATCH: cfm_wrapper.sample(cond = (8, 1024, 512), steps = 65) -- 64 midpoint intervals, 128
+    function evaluations under hipGraph, EIGHT DISTINCT samples, i.e. the sampler's two-stream split path meets reference data
+    directly -- against 583 s of the unmodified reference's CPU path (tests/golden/cfg5_wc_b8.pt, well-conditioned weights)."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg5_wc_b8")
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    state = _wc(restate.init_state_dict(cfg, seed=4))
+    vbx, vb, wrapper = build(dict(dim=512, depth=12, heads=16), state)
+    x1 = torch.randn(8, 1024, 512, generator=torch.Generator().manual_seed(48))
+    torch.manual_seed(49)
+    y0 = torch.randn_like(x1)
+    assert torch.equal(y0[:, 0, :4], g["y0_check"])
+    with rng_override(y0=y0):
+        s = wrapper.sample(cond=x1.to(dev), steps=65)
+    assert torch.isfinite(s).all()
+    per_sample = [rel(s[i, 500:516, :], g["sample65_rows"][i]) for i in range(8)]
+    first = [rel(s[i, :4, :], g["sample65_first"][i]) for i in range(8)]
+    norms = (s.flatten(1).norm(dim=1).cpu() - g["sample65_norms"]).abs() / g["sample65_norms"]
+    print("cfg5 B=8: rows 500-515 rel per sample", [round(v, 4) for v in per_sample], "rows 0-3", [round(v, 4) for v in first],
+          "norm rel max", float(norms.max()))
+    assert max(per_sample) < 1.5e-2 and max(first) < 1.5e-2 and float(norms.max()) < 1e-3, (per_sample, first, norms)
 
 
 def test_cfg4_depth12_training_trajectory_vs_reference(golden):

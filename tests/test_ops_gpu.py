@@ -304,6 +304,20 @@ def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
 
 
 # ----------------------------------------------------------------------------- attention
+def attn_scratch(L, Bsz, H, Np):
+    """Scratch of the one-pass attention backward (poisoned: the kernel must not depend on its contents)."""
+    return torch.full((L.lib().vbx_attn_bwd_scratch_bytes(Bsz, H, Np),), 0xFF, dtype=torch.uint8, device=dev)
+
+
+@pytest.fixture(params=[2, 1], ids=["onepass", "twobody"])
+def bwd_variant(request, L):
+    """Both attention-backward kernels behind vbx_attn_bwd / vbx_attn_bwd_fused: the one-pass chain kernel (round 3, default when
+    scratch is given) and the two-body kernel of round 2."""
+    L.lib().vbx_attn_bwd_select(request.param)
+    yield request.param
+    L.lib().vbx_attn_bwd_select(0)
+
+
 def attn_inputs(Bsz, H, Np, seed, qnorm=8.0):
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(Bsz, H, Np, 64, generator=g)
@@ -317,8 +331,9 @@ def attn_inputs(Bsz, H, Np, seed, qnorm=8.0):
 
 @pytest.mark.parametrize("Bsz,H,Np,scale,masked", [(1, 2, 64, 10.0, False), (2, 2, 1040, 10.0, False),
                                                    (2, 3, 77, 10.0, True), (1, 2, 200, 0.125, True),
-                                                   (2, 2, 1040, 10.0, True)])
-def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked):
+                                                   (2, 2, 1040, 10.0, True), (1, 2, 128, 10.0, False), (2, 2, 300, 10.0, True),
+                                                   (1, 3, 24, 10.0, False)])
+def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked, bwd_variant):
     """Attend.forward math path (attend.py:121-135) at the reference's logit scale (10 * q.k, |q|=|k|=8)."""
     q16, k16, v = attn_inputs(Bsz, H, Np, seed=Np + H, qnorm=8.0 if scale == 10.0 else None)
     mask = None
@@ -355,7 +370,7 @@ def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked):
     dv = torch.zeros(Bsz, Np, 3 * H * 64, dtype=torch.bfloat16, device=dev)
     dv_view = dv[:, :, 2 * H * 64:]
     L.call("vbx_attn_bwd", qd, kd, qb, kb, bf(v.float()).to(dev), md, out16, 1, dout.to(dev), lse, delta, dq, dk,
-           dv_view.data_ptr(), 3 * H * 64, Bsz, H, Np, scale, st())
+           dv_view.data_ptr(), 3 * H * 64, Bsz, H, Np, scale, attn_scratch(L, Bsz, H, Np), st())
     torch.cuda.synchronize()
     dv_got = dv_view.float().cpu().view(Bsz, Np, H, 64).permute(0, 2, 1, 3)
     # operands of the backward GEMMs (P, dS, q, k, dO) are bf16 -> ~1e-2 relative on the result
@@ -394,7 +409,7 @@ def test_qknorm_rope_bwd(L, qknorm):
 
 
 @pytest.mark.parametrize("Bsz,H,Np,qknorm,masked", [(2, 2, 1040, True, False), (2, 2, 77, True, True), (1, 2, 200, False, False)])
-def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked):
+def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked, bwd_variant):
     """vbx_attn_bwd_fused (rotary + qk-norm backward inside the dq / dkdv epilogues) against vbx_attn_bwd followed by
     vbx_qknorm_rope_bwd on the same inputs: same d(qkv) up to the bf16 rounding of the output, same gamma gradients."""
     scale = 10.0 if qknorm else 0.125
@@ -425,7 +440,7 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked):
     dq, dk = torch.zeros(Bsz, H, Np, 64, device=dev), torch.zeros(Bsz, H, Np, 64, device=dev)
     d1 = torch.zeros(Bsz * Np, 3 * I, dtype=torch.bfloat16, device=dev)
     L.call("vbx_attn_bwd", q16, k16, qb, kb, vb, mask, out16, 1, dout, lse, delta, dq, dk, d1.view(-1)[2 * I:].data_ptr(), 3 * I,
-           Bsz, H, Np, scale, st())
+           Bsz, H, Np, scale, attn_scratch(L, Bsz, H, Np), st())
     rows1 = L.lib().vbx_qknorm_rope_bwd_gpart_rows(Bsz)
     gp1 = torch.zeros(2, rows1, H, 64, device=dev)
     gq, gk = gam[0].float().to(dev), gam[1].float().to(dev)
@@ -436,7 +451,7 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked):
     rows2 = Bsz * L.lib().vbx_attn_bwd_fused_tiles(Np)
     gp2 = torch.zeros(2, rows2, H, 64, device=dev)
     L.call("vbx_attn_bwd_fused", q16, k16, qb, kb, vb, mask, out16, 1, dout, lse, delta, rn[0].to(dev), rn[1].to(dev), gq, gk,
-           rc.to(dev), rs.to(dev), 8.0 if qknorm else 0.0, d2, 3 * I, gp2, Bsz, H, Np, scale, st())
+           rc.to(dev), rs.to(dev), 8.0 if qknorm else 0.0, d2, 3 * I, gp2, Bsz, H, Np, scale, attn_scratch(L, Bsz, H, Np), st())
     torch.cuda.synchronize()
     assert torch.equal(d1[:, 2 * I:], d2[:, 2 * I:])  # dv: same code path
     for blk in range(2):
@@ -444,6 +459,91 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked):
         assert rel_err(b, a) < 4e-3, (blk, rel_err(b, a))  # identical fp32 math, one bf16 rounding each
     if qknorm:
         assert rel_err(gp2.sum(1), gp1.sum(1)) < 1e-4
+
+
+def _bwd_case(L, Bsz, H, Np, seed, masked=False):
+    """Inputs of one fused attention backward at the reference's logit scale (qk-norm, rotary, scale 10)."""
+    g = torch.Generator().manual_seed(seed)
+    pre = torch.randn(2, Bsz, H, Np, 64, generator=g)
+    gam = 1 + 0.2 * torch.randn(2, H, 64, generator=g)
+    fr, rc, rs = rot_tables(Np, 16 if Np > 16 else 0)
+    hats = [restate.apply_rotary(fr, restate.l2norm_scale(pre[w], 64) * gam[w][:, None, :]) for w in range(2)]
+    rn = (1 / pre.norm(dim=-1)).float()
+    c = dict(Bsz=Bsz, H=H, Np=Np, q16=hats[0].half().to(dev), k16=hats[1].half().to(dev),
+             v=torch.randn(Bsz, H, Np, 64, generator=g).half().to(dev), rn=rn.to(dev), gam=gam.float().to(dev), rc=rc.to(dev),
+             rs=rs.to(dev), mask=None)
+    if masked:
+        m = torch.ones(Bsz, Np, dtype=torch.bool)
+        m[0, Np - 9:] = False
+        m[Bsz - 1, 3:7] = False
+        c["mask"] = m.to(dev)
+    c["out16"] = torch.empty(Bsz, Np, H * 64, dtype=torch.float16, device=dev)
+    c["lse"] = torch.empty(Bsz, H, Np, device=dev)
+    L.call("vbx_attn_fwd", c["q16"], c["k16"], c["v"], c["mask"], c["out16"], None, c["lse"], Bsz, H, Np, 10.0, st())
+    c["dout"] = bf(torch.randn(Bsz, Np, H * 64, generator=g) * 1e-3).to(dev)
+    return c
+
+
+def _bwd_fused(L, c, variant, scratch=None):
+    Bsz, H, Np = c["Bsz"], c["H"], c["Np"]
+    I = H * 64
+    L.lib().vbx_attn_bwd_select(variant)
+    try:
+        d = torch.zeros(Bsz * Np, 3 * I, dtype=torch.bfloat16, device=dev)
+        gp = torch.zeros(2, Bsz * L.lib().vbx_attn_bwd_fused_tiles(Np), H, 64, device=dev)
+        delta = torch.empty(Bsz, H, Np, device=dev)
+        scratch = attn_scratch(L, Bsz, H, Np) if scratch is None else scratch
+        L.call("vbx_attn_bwd_fused", c["q16"], c["k16"], bf(c["q16"].float()), bf(c["k16"].float()), bf(c["v"].float()), c["mask"],
+               c["out16"], 1, c["dout"], c["lse"], delta, c["rn"][0], c["rn"][1], c["gam"][0], c["gam"][1], c["rc"], c["rs"], 8.0, d,
+               3 * I, gp, Bsz, H, Np, 10.0, scratch, st())
+        torch.cuda.synchronize()
+    finally:
+        L.lib().vbx_attn_bwd_select(0)
+    return d, gp, scratch
+
+
+def _chain_bookkeeping_ok(scratch, Bsz, H, Np):
+    """Sync words of the one-pass kernel after a launch: no spin timed out, and every XCD queue was drained (each of the 8 queue heads
+    was advanced past its item count -- a queue nobody served would leave that XCD's heads without gradients)."""
+    w = scratch[:64].view(torch.int32).cpu()
+    n_kb, BH = (Np + 127) // 128, Bsz * H
+    assert int(w[8]) == 0, "a chain member timed out waiting for its predecessor"
+    for x in range(8):
+        heads = len(range(x, BH, 8))
+        assert int(w[x]) >= heads * n_kb, (x, int(w[x]), heads * n_kb)
+
+
+@pytest.mark.parametrize("Bsz,H,Np,masked", [(8, 16, 1040, False), (2, 16, 1040, True), (3, 5, 520, False), (1, 2, 130, False)])
+def test_attn_bwd_onepass_equals_two_body(L, Bsz, H, Np, masked):
+    """The one-pass backward (every S / dP block evaluated once, dq summed by the ordered chain of a head's key-block workgroups)
+    against the two-body kernel of round 2 on the same inputs -- including the BENCHMARK GRID B = 8, H = 16, Np = 1040 (1152 chain
+    items on 512 persistent workgroups).  dv / dk come out of the same arithmetic in the same order: bit-identical.  dq sums the same
+    bf16-rounded dS blocks in a different association: equal up to the bf16 rounding of the output."""
+    c = _bwd_case(L, Bsz, H, Np, seed=Np + Bsz, masked=masked)
+    d1, g1, _ = _bwd_fused(L, c, 1)
+    d2, g2, scratch = _bwd_fused(L, c, 2)
+    I = H * 64
+    _chain_bookkeeping_ok(scratch, Bsz, H, Np)
+    assert torch.isfinite(d2.float()).all()
+    assert torch.equal(d1[:, 2 * I:], d2[:, 2 * I:]), "dv"
+    assert torch.equal(d1[:, I:2 * I], d2[:, I:2 * I]), "dk"
+    assert rel_err(d2[:, :I].float(), d1[:, :I].float()) < 6e-3, rel_err(d2[:, :I].float(), d1[:, :I].float())
+    assert torch.equal(g1[1], g2[1]), "k gamma partials"
+    assert rel_err(g2[0].sum(0), g1[0].sum(0)) < 2e-3
+
+
+def test_attn_bwd_onepass_is_deterministic_and_ignores_scratch_contents(L):
+    """Two launches of the one-pass backward on the same inputs give bit-identical d(qkv) and gamma partials although the chain
+    members run in whatever order the hardware schedules them (the ORDER of the additions is fixed by the chain, not by timing) and the
+    scratch holds different garbage each time."""
+    c = _bwd_case(L, 4, 16, 1040, seed=77)
+    n = L.lib().vbx_attn_bwd_scratch_bytes(4, 16, 1040)
+    outs = []
+    for fill in (0x00, 0xFF, 0x5A):
+        d, gp, _ = _bwd_fused(L, c, 2, scratch=torch.full((n,), fill, dtype=torch.uint8, device=dev))
+        outs.append((d.clone(), gp.clone()))
+    for d, gp in outs[1:]:
+        assert torch.equal(d, outs[0][0]) and torch.equal(gp, outs[0][1])
 
 
 # ----------------------------------------------------------------------------- small ops

@@ -25,12 +25,15 @@ dq = torch.zeros(B, H, Np, 64, device=dev); dk = torch.zeros(B, H, Np, 64, devic
 dv = torch.zeros(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
 
 
+scratch = torch.empty(L.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward (VBX_ATTN_BWD_ONEPASS=0: two-body)
+
+
 def fwd():
     L.call("vbx_attn_fwd", qd, kd, vd, None, out16, out, lse, B, H, Np, 10.0, st)
 
 
 def bwd():
-    L.call("vbx_attn_bwd", qd, kd, qb, kb, vb, None, out16, 1, dout, lse, delta, dq, dk, dv.data_ptr(), H * 64, B, H, Np, 10.0, st)
+    L.call("vbx_attn_bwd", qd, kd, qb, kb, vb, None, out16, 1, dout, lse, delta, dq, dk, dv.data_ptr(), H * 64, B, H, Np, 10.0, scratch, st)
 
 
 for fn, name in ((fwd, "fwd"), (bwd, "bwd")):

@@ -28,9 +28,12 @@ fn = L.lib().vbx_debug_attn_trace
 fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 
 
+scratch = torch.empty(L.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device="cuda:0")
+
+
 def run():
     L.call("vbx_attn_fwd", qd, kd, vd, None, out16, out, lse, B, H, Np, 10.0, st)
-    L.call("vbx_attn_bwd", qd, kd, qb, kb, vb, None, out16, 1, dout, lse, delta, dq, dk, dv.data_ptr(), H * 64, B, H, Np, 10.0, st)
+    L.call("vbx_attn_bwd", qd, kd, qb, kb, vb, None, out16, 1, dout, lse, delta, dq, dk, dv.data_ptr(), H * 64, B, H, Np, 10.0, scratch, st)
 
 
 for _ in range(3):

@@ -84,7 +84,7 @@ if __name__ == "__main__":
         delta = torch.empty(B, H, Np, device=dev); dq = torch.empty(B, H, Np, 64, device=dev); dk = torch.empty_like(dq)
         dv = torch.empty(B, Np, H * 64, device=dev, dtype=torch.bfloat16)
         qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
-        sec = timeit(lambda: L.call("vbx_attn_bwd", q, k, qb, kb, vb, None, out, 1, do, lse, delta, dq, dk, dv, H * 64, B, H, Np, 10.0, st))
+        sec = timeit(lambda: L.call("vbx_attn_bwd", q, k, qb, kb, vb, None, out, 1, do, lse, delta, dq, dk, dv, H * 64, B, H, Np, 10.0, None, st))
         print(f"attn bwd  {sec*1e6:8.1f} us  {2.5*fl/sec/1e12:7.1f} TF/s (algorithmic 2.5x fwd)")
 
 

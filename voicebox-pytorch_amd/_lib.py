@@ -38,8 +38,9 @@ _PROTOS = {
     "vbx_rmsnorm_bwd_chunks": [I],
     "vbx_rmsnorm_bwd": [P, P, L, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_attn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
-    "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P],
-    "vbx_attn_bwd_fused": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P],
+    "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P],
+    "vbx_attn_bwd_fused": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P, P],
+    "vbx_attn_bwd_select": [I],
     "vbx_attn_bwd_fused_tiles": [I],
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
@@ -116,12 +117,14 @@ def lib():
         fn = getattr(l, name)  # AttributeError here == header/library mismatch
         fn.argtypes = argtypes
         fn.restype = I
+    l.vbx_attn_bwd_scratch_bytes.argtypes = [I, I, I]
+    l.vbx_attn_bwd_scratch_bytes.restype = C.c_size_t
     _lib = l
     return l
 
 
 def exported_symbols():
-    return sorted(_PROTOS) + ["vbx_last_error"]  # + the stage-level entries bound in engine.py
+    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes"]  # + the stage-level entries bound in engine.py
 
 
 def ptr(t):

@@ -11,6 +11,7 @@
 // and the P^T accumulator registers are already the B operand of the next MFMA (slot s of half hi <->
 // key (s&3) + 8*(s>>2) + 4*hi inside each 16-key group; the V^T fragment uses the same key order).
 #include "common.hpp"
+#include "attn_bwd1_layout.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -779,8 +780,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
 //  launch they replace.  Kept as a separate streaming pass at 4 TB/s.)
 template <bool O_F16>
 __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
-                                  int Np, long total_chunks) {
+                                  int Np, long total_chunks, unsigned* __restrict__ sync, int nsync) {
   const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one 8-element chunk per thread
+  if (c < nsync) sync[c] = 0u;  // queue heads / error word / chain flags of the one-pass backward that follows on this stream
   const long cc = min(c, total_chunks - 1);
   const uint4 a = *reinterpret_cast<const uint4*>(o + cc * 8);
   const uint4 g = *reinterpret_cast<const uint4*>(dout + cc * 8);
@@ -1537,6 +1539,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs 
                            a.scale2, a.scale, a.BH, a.xmap, a.fk);
 }
 
+#include "attn_bwd1.inc"
+
 }  // namespace
 
 #ifdef VBX_ATTN_TRACE
@@ -1589,12 +1593,44 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   return 0;
 }
 
+// Backward variant: 0 = automatic (the one-pass kernel whenever the caller provides scratch), 1 = the two-body kernel (round 2),
+// 2 = one-pass required.  VBX_ATTN_BWD_ONEPASS=0 presets 1 (A/B); vbx_attn_bwd_select() switches at run time (tests, tools).
+static int g_attn_bwd_variant = (getenv("VBX_ATTN_BWD_ONEPASS") && atoi(getenv("VBX_ATTN_BWD_ONEPASS")) == 0) ? 1 : 0;
+extern "C" int vbx_attn_bwd_select(int variant) {
+  VBX_REQUIRE(variant >= 0 && variant <= 2, "vbx_attn_bwd_select: 0 auto, 1 two-body, 2 one-pass");
+  g_attn_bwd_variant = variant;
+  return 0;
+}
+static inline size_t b1_sync_words(int B, int H, int Np) { return (size_t)B1_SYNC_HDR + (size_t)B * H * cdiv(Np, 64); }
+static inline size_t b1_acc_floats(int B, int H, int Np) { return (size_t)B * H * cdiv(Np, 64) * 4096; }
+extern "C" size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np) {
+  if (B <= 0 || H <= 0 || Np <= 0) return 0;
+  return ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255) + b1_acc_floats(B, H, Np) * sizeof(float);
+}
+static int attn_xcds() {  // XCC ids the one-pass kernel folds its queues over: 8 on an SPX MI355X (256 CUs), fewer in partitioned modes
+  static int nx = 0;
+  if (!nx) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    nx = cus / 32;
+    if (nx < 1) nx = 1;
+    if (nx > 8) nx = 8;
+  }
+  return nx;
+}
+
 static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
                          const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, float* dq, float* dk,
-                         void* dv, int dv_ld, int B, int H, int Np, float scale, const QKBwd& fq, const QKBwd& fk, void* stream) {
+                         void* dv, int dv_ld, int B, int H, int Np, float scale, const QKBwd& fq, const QKBwd& fk, void* scratch,
+                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
+  const bool onepass = scratch && g_attn_bwd_variant != 1;
+  VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
+  unsigned* sync = onepass ? (unsigned*)scratch : nullptr;
+  const int nsync = onepass ? (int)b1_sync_words(B, H, Np) : 0;
   if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
@@ -1603,11 +1639,23 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   const long chunks = (long)B * Np * H * 8;
   if (out_is_f16)
     hipLaunchKernelGGL(attn_delta_kernel<true>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
-                       delta, H, Np, chunks);
+                       delta, H, Np, chunks, sync, nsync);
   else
     hipLaunchKernelGGL(attn_delta_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
-                       delta, H, Np, chunks);
+                       delta, H, Np, chunks, sync, nsync);
   VBX_LAUNCH_CHECK();
+  if (onepass) {
+    AttnBwd1Args g;
+    g.q16 = (const u16*)q16; g.k16 = (const u16*)k16; g.qb16 = (const u16*)qb; g.kb16 = (const u16*)kb; g.vv = (const u16*)v;
+    g.dout = (const u16*)dout; g.mask = mask; g.lse = lse; g.delta = delta; g.dq = dq; g.dk = dk; g.dv = (u16*)dv;
+    g.sync = sync;
+    g.dqacc = (float*)((char*)scratch + ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255));
+    g.dv_ld = dv_ld; g.H = H; g.Np = Np; g.BH = B * H; g.nx = attn_xcds(); g.scale2 = scale * LOG2E; g.scale = scale; g.fq = fq; g.fk = fk;
+    // 512 persistent workgroups = two per CU: each pulls (head, key block) items from the queue of the XCD it runs on
+    hipLaunchKernelGGL(attn_bwd1_kernel, dim3(512), dim3(256), B1_LDS, st, g);
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
@@ -1647,12 +1695,12 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
 extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
                             const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
                             float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
-                            void* stream) {
+                            void* scratch, void* stream) {
   VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
   const QKBwd none{};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
-                       stream);
+                       scratch, stream);
 }
 
 extern "C" int vbx_attn_bwd_fused_tiles(int Np) { return cdiv(Np, 128); }
@@ -1661,7 +1709,7 @@ extern "C" int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* 
                                   const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
                                   float* delta, const float* q_rnorm, const float* k_rnorm, const float* q_gamma,
                                   const float* k_gamma, const float* rot_cos, const float* rot_sin, float qk_scale, void* dqkv,
-                                  int ld, float* gpart, int B, int H, int Np, float scale, void* stream) {
+                                  int ld, float* gpart, int B, int H, int Np, float scale, void* scratch, void* stream) {
   VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dqkv && rot_cos && rot_sin, "vbx_attn_bwd_fused: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && ld % 8 == 0 && ld >= 3 * H * 64, "vbx_attn_bwd_fused: bad dims");
   VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma && gpart), "vbx_attn_bwd_fused: qk-norm needs norms, gammas, gpart");
@@ -1670,5 +1718,5 @@ extern "C" int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* 
   QKBwd fk{(const u16*)k16, k_rnorm, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, I,
            gpart ? gpart + (size_t)B * tiles * H * 64 : nullptr};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, nullptr, nullptr, (u16*)dqkv + 2 * I, ld, B, H, Np,
-                       scale, fq, fk, stream);
+                       scale, fq, fk, scratch, stream);
 }

@@ -103,6 +103,7 @@ struct Acts {
   float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
+  char* attn_scratch = nullptr;  // one-pass attention backward: chain flags + running dq sums (vbx_attn_bwd_scratch_bytes)
   u16* dxb2 = nullptr;  // bf16 dx of the attention half, so that FeedForward-out's dx operand survives to the layer's grouped wgrad launch
   float* gl_ds;
   size_t slab_floats;
@@ -274,6 +275,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.gl_dp = m->gateloop ? c.take<u16>((size_t)d.M * 3 * d.D) : nullptr;
     a.demb = d.E ? c.take<u16>((size_t)d.M0 * d.E) : nullptr;
     a.dxb2 = c.take<u16>((size_t)d.M * d.D);  // always carved: the arena layout must not depend on run-time tuning knobs
+    a.attn_scratch = c.take<char>(vbx_attn_bwd_scratch_bytes(d.B, d.H, d.Np));
   }
   a.bytes = al256(c.off);
 }
@@ -696,7 +698,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     ProfScope ps("bwd attention", st);
     CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
                           m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin,
-                          m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, stream));
+                          m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     if (m->qk_norm && !batched) {
       const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
       CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
@@ -704,7 +706,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   } else {
   CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
-                    a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, stream));
+                    a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                            m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
                            3 * d.I, a.gpart, d.B, d.H, d.Np, stream));

@@ -52,8 +52,9 @@ class _AttendFn(torch.autograd.Function):
         dq = torch.empty(B, H, Np, 64, dtype=torch.float32, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward
         _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
-                  H * 64, B, H, Np, ctx.scale, _lib.current_stream())
+                  H * 64, B, H, Np, ctx.scale, scratch, _lib.current_stream())
         dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
         return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None
 
