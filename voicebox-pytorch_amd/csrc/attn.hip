@@ -782,7 +782,7 @@ template <bool O_F16>
 __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
                                   int Np, long total_chunks, unsigned* __restrict__ sync, int nsync) {
   const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one 8-element chunk per thread
-  if (c < nsync) sync[c] = 0u;  // queue heads / error word / chain flags of the one-pass backward that follows on this stream
+  if (c < nsync) sync[c] = 0u;  // queue heads / error word of the one-pass backward that follows on this stream
   const long cc = min(c, total_chunks - 1);
   const uint4 a = *reinterpret_cast<const uint4*>(o + cc * 8);
   const uint4 g = *reinterpret_cast<const uint4*>(dout + cc * 8);
@@ -1544,6 +1544,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs 
 }  // namespace
 
 #ifdef VBX_ATTN_TRACE
+extern "C" int vbx_debug_attn_bwd1_trace(void* buf) {  // diagnostic build only: buf = [512][96][9] u64, null to stop
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_b1_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
 extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf = [2][8192][4] u64 (forward | backward launches, by blockIdx), null to stop
   return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
@@ -1601,7 +1604,7 @@ extern "C" int vbx_attn_bwd_select(int variant) {
   g_attn_bwd_variant = variant;
   return 0;
 }
-static inline size_t b1_sync_words(int B, int H, int Np) { return (size_t)B1_SYNC_HDR + (size_t)B * H * cdiv(Np, 64); }
+static inline size_t b1_sync_words(int B, int H, int Np) { return (size_t)B1_SYNC_HDR + (size_t)B * H * cdiv(Np, 64) * 4; }
 static inline size_t b1_acc_floats(int B, int H, int Np) { return (size_t)B * H * cdiv(Np, 64) * 4096; }
 extern "C" size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np) {
   if (B <= 0 || H <= 0 || Np <= 0) return 0;
@@ -1625,10 +1628,15 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
                          void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
-  const bool onepass = scratch && g_attn_bwd_variant != 1;
+  bool onepass = scratch && g_attn_bwd_variant != 1;
   VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
+  if (onepass) {  // its flags carry a per-launch epoch passed by value: a captured launch would replay a stale one
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) onepass = false;
+  }
   unsigned* sync = onepass ? (unsigned*)scratch : nullptr;
-  const int nsync = onepass ? (int)b1_sync_words(B, H, Np) : 0;
+  int nsync = onepass ? B1_SYNC_HDR : 0;  // queue heads + error word; the flags are epoch-tagged and never reset
+
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
@@ -1648,8 +1656,10 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     AttnBwd1Args g;
     g.q16 = (const u16*)q16; g.k16 = (const u16*)k16; g.qb16 = (const u16*)qb; g.kb16 = (const u16*)kb; g.vv = (const u16*)v;
     g.dout = (const u16*)dout; g.mask = mask; g.lse = lse; g.delta = delta; g.dq = dq; g.dk = dk; g.dv = (u16*)dv;
-    g.sync = sync;
+    g.sync = (unsigned*)scratch;
     g.dqacc = (float*)((char*)scratch + ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255));
+        static unsigned launch_epoch = 0;
+    g.epoch = (++launch_epoch) & 0xFFFFFFu;
     g.dv_ld = dv_ld; g.H = H; g.Np = Np; g.BH = B * H; g.nx = attn_xcds(); g.scale2 = scale * LOG2E; g.scale = scale; g.fq = fq; g.fk = fk;
     // 512 persistent workgroups = two per CU: each pulls (head, key block) items from the queue of the XCD it runs on
     hipLaunchKernelGGL(attn_bwd1_kernel, dim3(512), dim3(256), B1_LDS, st, g);
