@@ -129,10 +129,13 @@ int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, c
                  float* lse, int B, int H, int Np, float scale, void* stream);
 /* backward (autograd of attend.py:121-135).  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
  * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d].
- * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL.  With scratch the ONE-PASS
- * kernel runs (every S / dP block evaluated once; dq summed over the key blocks of a head by an ordered, deterministic chain of
- * workgroups through the scratch); without it the two-body kernel of round 2 (S / dP evaluated twice).
- * vbx_attn_bwd_select: 0 automatic (default), 1 two-body always, 2 one-pass required (error without scratch). */
+ * Two kernels serve it.  The two-body kernel (default): dq and dk/dv bodies in one launch, S / dP evaluated in both.  The ONE-PASS
+ * kernel (vbx_attn_bwd_select(2) or VBX_ATTN_BWD_ONEPASS=1; needs `scratch`): every S / dP block evaluated once, dq summed over the
+ * key blocks of a head by an ordered, deterministic chain of workgroups through the scratch -- bit-identical dk / dv, measured slower
+ * on MI355X so far, kept selectable.
+ * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL (two-body only).
+ * vbx_attn_bwd_select: 0 automatic (= two-body), 1 two-body, 2 one-pass (error without scratch; under stream capture the two-body
+ * kernel runs, because the chain's flags carry a per-launch epoch passed by value). */
 size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
 int vbx_attn_bwd_select(int variant);
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,

@@ -23,6 +23,7 @@ delta = torch.empty(B, H, Np, device=dev)
 dq = torch.zeros(B, H, Np, 64, device=dev); dk = torch.zeros(B, H, Np, 64, device=dev)
 dv = torch.zeros(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
 scratch = torch.empty(L.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)
+L.lib().vbx_attn_bwd_select(2)
 L.call("vbx_attn_fwd", qd, kd, vd, None, out16, None, lse, B, H, Np, 10.0, st)
 
 

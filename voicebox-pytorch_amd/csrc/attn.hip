@@ -1596,9 +1596,11 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   return 0;
 }
 
-// Backward variant: 0 = automatic (the one-pass kernel whenever the caller provides scratch), 1 = the two-body kernel (round 2),
-// 2 = one-pass required.  VBX_ATTN_BWD_ONEPASS=0 presets 1 (A/B); vbx_attn_bwd_select() switches at run time (tests, tools).
-static int g_attn_bwd_variant = (getenv("VBX_ATTN_BWD_ONEPASS") && atoi(getenv("VBX_ATTN_BWD_ONEPASS")) == 0) ? 1 : 0;
+// Backward variant: 0 = automatic, 1 = the two-body kernel (round 2), 2 = the one-pass chain kernel (round 3; needs scratch).
+// Automatic = two-body: measured on MI355X at the benchmark grid the one-pass kernel is correct and deterministic but SLOWER
+// (232 - 259 us against 180 - 198 us stand-alone, train step 11.5 against 10.2 ms; step-level time line in DESIGN.md section 8).
+// VBX_ATTN_BWD_ONEPASS=1 presets 2 (A/B); vbx_attn_bwd_select() switches at run time (tests, tools).
+static int g_attn_bwd_variant = (getenv("VBX_ATTN_BWD_ONEPASS") && atoi(getenv("VBX_ATTN_BWD_ONEPASS")) != 0) ? 2 : 0;
 extern "C" int vbx_attn_bwd_select(int variant) {
   VBX_REQUIRE(variant >= 0 && variant <= 2, "vbx_attn_bwd_select: 0 auto, 1 two-body, 2 one-pass");
   g_attn_bwd_variant = variant;
@@ -1628,7 +1630,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
                          void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
-  bool onepass = scratch && g_attn_bwd_variant != 1;
+  bool onepass = scratch && g_attn_bwd_variant == 2;
   VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
   if (onepass) {  // its flags carry a per-launch epoch passed by value: a captured launch would replay a stale one
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
