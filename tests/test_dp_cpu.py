@@ -129,3 +129,38 @@ def test_warmup_cosine_schedule_matches_trainer_rule():
             want = opt.param_groups[0]["lr"]
             got = mine.rate_for_step(step)
             assert abs(got - want) <= 1e-12 + 1e-9 * abs(want), (step, got, want)
+
+
+def test_last_bucket_is_small_and_staging_is_persistent():
+    """the last bucket of the gradient exchange cannot overlap any backward work, so it must hold the embed /
+    time-MLP stage only, not the last two layers as well; and the wire-dtype staging buffer is allocated once, not per bucket per step.
+    Bucket policy replayed on the host (world size 1: the collectives are skipped, the bucket boundaries are what is checked)."""
+    from voicebox_pytorch_amd.dp import GradBucketReducer
+
+    layer, head, embed = 8_500_000, 300_000, 1_200_000  # floats: dim 512 / depth 12 proportions (34 MB layers, 4.8 MB embed stage)
+    bounds = [0, head] + [head + layer * (i + 1) for i in range(12)]
+    bounds.append(bounds[-1] + embed)
+    ranges = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+    g = torch.zeros(bounds[-1])
+    red = GradBucketReducer(g, ranges, bucket_bytes=130 << 20, tail_bytes=16 << 20)  # 130 MiB: five 34 MB layers per bucket, two left over
+    for i, rng in enumerate(ranges):
+        red.stage_done(i, rng)
+    red.finish()
+    b = red.buckets_launched
+    assert b[0][0] == 0 and b[-1][1] == bounds[-1] and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))  # a partition, in order
+    assert b[-1] == ranges[-1], b[-3:]                               # the un-overlapped bucket is the embed stage alone
+    assert (b[-1][1] - b[-1][0]) * 4 <= 16 << 20
+    assert all((hi - lo) * 4 >= 130 << 20 for lo, hi in b[:-2])       # the others still fill up (the one before the tail may be short)
+    # tail policy off -> the old behaviour: the final bucket swallows the last layers
+    red0 = GradBucketReducer(g, ranges, bucket_bytes=130 << 20, tail_bytes=0)
+    for i, rng in enumerate(ranges):
+        red0.stage_done(i, rng)
+    red0.finish()
+    assert (red0.buckets_launched[-1][1] - red0.buckets_launched[-1][0]) * 4 > 16 << 20
+    # staging: one persistent buffer, reused across buckets and across reducers
+    red1 = GradBucketReducer(g, ranges, bucket_bytes=64 << 20, comm_dtype=torch.bfloat16)
+    v1 = red1._stage(*ranges[0])
+    v2 = red1._stage(*ranges[1])
+    assert v1.dtype == torch.bfloat16 and v1.untyped_storage().data_ptr() == v2.untyped_storage().data_ptr()
+    red2 = GradBucketReducer(g, ranges, bucket_bytes=64 << 20, comm_dtype=torch.bfloat16, stage_buf=red1.stage_buf)
+    assert red2._stage(*ranges[2]).untyped_storage().data_ptr() == v1.untyped_storage().data_ptr()

@@ -282,7 +282,55 @@ def test_weights_key_sees_every_kind_of_parameter_write():
     assert k3 != k2
     fp.bump()  # what the native Adam / a broadcast into the flat buffer do
     assert fp.weights_key() != k3 and fp.flat_gen == gen0
+    # a write through p.data is invisible to every version counter: the documented remedy is mark_weights_dirty()
+    k4 = fp.weights_key()
+    vb.to_pred.weight.data.mul_(2.0)
+    assert fp.weights_key() == k4
+    vb.mark_weights_dirty()
+    assert fp.weights_key() != k4
     assert vb.flat_params() is fp and fp.is_current()
     vb.double()  # dtype change: the parameters leave the flat buffer -> re-flatten, new generation
     fp2 = vb.flat_params()
     assert fp2.flat_gen == gen0 + 1 and fp2.is_current()
+
+
+def test_optimizer_state_of_the_other_weight_decay_grouping_is_rejected(tmp_path):
+    """a checkpoint written under wd = 0 numbers its optimizer state in one group, a wd > 0 trainer in two
+    (optimizer.py:10-35): loading across the two must raise (as torch.optim.load_state_dict does) BEFORE any moment is copied."""
+    import types
+
+    from voicebox_pytorch_amd.trainer import VoiceBoxTrainer
+
+    class T:  # just what _load_optim_state_dict touches
+        _load_optim_state_dict = VoiceBoxTrainer._load_optim_state_dict
+
+    p = [torch.nn.Parameter(torch.zeros(4, 4)), torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4, 4))]
+    t = T()
+    t.wd = 0.1
+    t._optim_param_order = lambda: ([p[0], p[2], p[1]], 2)  # decayed (ndim >= 2) first
+    fp = types.SimpleNamespace(order=["a", "b", "c"], slots={"a": p[0], "b": p[1], "c": p[2]}, offsets={"a": 0, "b": 16, "c": 20})
+    t.train_step_fn = types.SimpleNamespace(fp=fp, m=torch.zeros(36), v=torch.zeros(36), steps=0)
+    st = lambda shape: {"step": torch.tensor(3.0), "exp_avg": torch.ones(shape), "exp_avg_sq": torch.ones(shape)}
+    one_group = {"state": {0: st((4, 4)), 1: st((4,)), 2: st((4, 4))}, "param_groups": [{"params": [0, 1, 2]}]}
+    with pytest.raises(ValueError, match="parameter groups"):
+        t._load_optim_state_dict(one_group)
+    assert float(t.train_step_fn.m.abs().sum()) == 0.0  # nothing was copied
+    wrong_shape = {"state": {0: st((4, 4)), 1: st((4,)), 2: st((4,))}, "param_groups": [{"params": [0, 1]}, {"params": [2]}]}
+    with pytest.raises(ValueError, match="shape"):
+        t._load_optim_state_dict(wrong_shape)
+    assert float(t.train_step_fn.m.abs().sum()) == 0.0
+    good = {"state": {0: st((4, 4)), 1: st((4, 4)), 2: st((4,))}, "param_groups": [{"params": [0, 1]}, {"params": [2]}]}
+    t._load_optim_state_dict(good)
+    assert float(t.train_step_fn.m.sum()) == 36.0 and t.train_step_fn.steps == 3
+
+
+def test_sampler_split_is_validated(monkeypatch):
+    """VBX_SAMPLE_SPLIT / MidpointSampler(split=) accept 1 and 2 only (nothing else is measured or tested)."""
+    from voicebox_pytorch_amd import solver
+
+    monkeypatch.setenv("VBX_SAMPLE_SPLIT", "three")
+    with pytest.raises(ValueError, match="VBX_SAMPLE_SPLIT"):
+        solver.MidpointSampler(None, 8, 16, 3)
+    monkeypatch.delenv("VBX_SAMPLE_SPLIT")
+    with pytest.raises(ValueError, match="split=4"):
+        solver.MidpointSampler(None, 8, 16, 3, split=4)

@@ -217,11 +217,12 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     assert rel_err(v, vv) < 4e-3 and rel_err(v16, vv) < 6e-4
 
 
-def test_gemm_geglu_epilogue(L, tile_path):
-    """FeedForward[0] + GEGLU fused, packed/interleaved weights (voicebox_pytorch.py:338-345)."""
+@pytest.mark.parametrize("Fd,Fp", [(341, 384), (405, 448)])
+def test_gemm_geglu_epilogue(L, tile_path, Fd, Fp):
+    """FeedForward[0] + GEGLU fused, packed/interleaved weights (voicebox_pytorch.py:338-345).  Fp = 448: 2 * Fp = 896 leaves a
+    128-column tail tile on the 128 x 256 kernel (the dim-1024 model's 2 * Fp = 5504 does too): its `col0 >= N` branch."""
     g = torch.Generator().manual_seed(3)
-    M, D, Fd = 200, 128, 341
-    Fp = 384
+    M, D = 200, 128
     x = bf(torch.randn(M, D, generator=g)).to(dev)
     W1 = torch.randn(2 * Fd, D, generator=g) * D ** -0.5
     b1 = torch.randn(2 * Fd, generator=g) * 0.1

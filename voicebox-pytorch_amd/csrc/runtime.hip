@@ -295,6 +295,11 @@ struct ProfScope {
   int idx = -1;
   ProfScope(const char* label, hipStream_t st_) : st(st_) {
     if (!g_prof.on) return;
+    // never grow without bound (vbx_prof_collect never called) and never record into a capturing stream (an event record would
+    // become a graph node and the elapsed-time query on it fails): profiling simply pauses there
+    if (g_prof.recs.size() >= 8192) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     ProfRec r{label, nullptr, nullptr};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, st);

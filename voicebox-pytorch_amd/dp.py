@@ -24,8 +24,16 @@ class GradBucketReducer:
     Device-agnostic (gloo on CPU in tests, RCCL on GPUs).  xGMI is point-to-point (ring all-reduce is per-link
     bound) so buckets are large: whole backward stages are merged until `bucket_bytes` is reached."""
 
-    def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None, comm_dtype=None):
+    def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None, comm_dtype=None, tail_bytes=16 << 20,
+                 stage_buf=None):
         self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
+        # The LAST bucket cannot overlap any backward work (nothing is left to run), so it must be small: as soon as what remains
+        # to be produced fits `tail_bytes`, the pending stages are flushed instead of being merged with the tail.  With the model's
+        # stage order (head, layer L-1 .. 0, embed + time MLP) only the embed stage (a few MB) is exchanged un-overlapped; before,
+        # layers 1-0 + embed (~70 MB at dim 512) formed the final bucket.
+        self.tail_bytes = tail_bytes
+        self.total_hi = max((hi for _, hi in stage_ranges), default=gflat.numel()) if stage_ranges else gflat.numel()
+        self.stage_buf = stage_buf  # persistent wire-dtype staging buffer (same numel as gflat); allocated on demand otherwise
         # optional gradient compression on the wire (DDP's bf16_compress_hook): halves the 4 B/param exchange; off by default
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.staged = []
@@ -60,7 +68,10 @@ class GradBucketReducer:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _stage(self, lo, hi):
-        buf = self.g[lo:hi].to(self.comm_dtype)
+        if self.stage_buf is None or self.stage_buf.dtype != self.comm_dtype or self.stage_buf.numel() < self.g.numel():
+            self.stage_buf = torch.empty(self.g.numel(), dtype=self.comm_dtype, device=self.g.device)  # once, not per bucket per step
+        buf = self.stage_buf[lo:hi]
+        buf.copy_(self.g[lo:hi])
         self.staged.append((lo, hi, buf))
         return buf
 
@@ -71,7 +82,11 @@ class GradBucketReducer:
         else:
             assert lo == self.pending_hi, "stages must complete in flat-buffer order"
             self.pending_hi = hi
-        if (self.pending_hi - self.pending_lo) * self.g.element_size() >= self.bucket_bytes:
+        es = self.g.element_size()
+        remaining = (self.total_hi - self.pending_hi) * es  # gradients still to be produced by later stages
+        pending = (self.pending_hi - self.pending_lo) * es
+        # (a small pending range is simply merged with the tail: the final bucket then stays <= 2 * tail_bytes)
+        if pending >= self.bucket_bytes or (0 < remaining <= self.tail_bytes < pending):
             self._launch(self.pending_lo, self.pending_hi)
             self.pending_lo = None
 
@@ -83,9 +98,7 @@ class GradBucketReducer:
             w.wait()  # makes the current stream wait for the collective
         self.works = []
         for lo, hi, buf in self.staged:  # decompress the reduced buckets back into the fp32 gradient buffer
-            if self.comm_stream is not None:
-                buf.record_stream(torch.cuda.current_stream())
-            self.g[lo:hi].copy_(buf)
+            self.g[lo:hi].copy_(buf)   # (the staging buffer is persistent and owned by the caller: no record_stream needed)
         self.staged = []
 
 
@@ -149,6 +162,7 @@ class TrainStep:
         self.exchange = self.world > 1 or (force_dist() and self.distributed)
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and dev.type == "cuda") else None
         self.bucket_bytes = bucket_bytes
+        self._stage_buf = None  # wire-dtype staging of the gradient exchange, allocated once (grad_comm_dtype only)
 
     def _dirty(self, keep=None):
         """The flat parameter buffer was written behind PyTorch's version counters (native Adam, broadcast): bump the weights
@@ -173,18 +187,48 @@ class TrainStep:
         self.acc_pending = True
         return loss
 
+    def _reducer(self, comm_dtype=None):
+        red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
+                                comm_stream=self.comm_stream, comm_dtype=comm_dtype, stage_buf=self._stage_buf)
+        return red
+
+    def accumulate_last_and_apply(self, x1, weight, mask=None, cond_token_ids=None, lr=None):
+        """The LAST micro-batch of an accumulation window, with the exchange overlapped with its backward (DDP leaves `no_sync`
+        for exactly this micro-batch, trainer.py:258-272): as each backward stage completes, its slice of the accumulator is
+        folded in (g = acc + weight * g) and the bucketed all-reduce of that slice starts while earlier layers are still running --
+        instead of exchanging all 410 MB after the backward with nothing to overlap (apply_accumulated).  Then clip + Adam."""
+        if getattr(self, "gacc", None) is None or not getattr(self, "acc_pending", False):
+            self.gacc = torch.zeros_like(self.gflat) if getattr(self, "gacc", None) is None else self.gacc
+        red = self._reducer(self.grad_comm_dtype)
+
+        def on_stage(i, rng=None):
+            lo, hi = rng if rng is not None else self.fp.stage_ranges[i]
+            g, a = self.gflat[lo:hi], self.gacc[lo:hi]
+            torch.add(a, g, alpha=float(weight), out=g)  # g = acc + weight * g, in place on the stage's slice
+            if self.exchange:
+                red.stage_done(i, rng)
+
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=on_stage)
+        red.finish()
+        self._stage_buf = red.stage_buf
+        self.gacc.zero_()
+        self.acc_pending = False
+        self._clip_adam(self._last_eng, lr)
+        return loss
+
     def apply_accumulated(self, lr=None):
-        """all-reduce (sum) of the accumulated gradients, clip, Adam; clears the accumulator."""
+        """all-reduce (sum) of the accumulated gradients, clip, Adam; clears the accumulator.  (No backward is left to overlap the
+        exchange with: prefer accumulate_last_and_apply for the window's last micro-batch.)"""
         assert getattr(self, "acc_pending", False), "nothing accumulated"
         self.gflat.copy_(self.gacc)
         self.gacc.zero_()
         self.acc_pending = False
         if self.exchange:
-            red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
-                                    comm_stream=self.comm_stream)
+            red = self._reducer(self.grad_comm_dtype)
             for i, rng in enumerate(self.fp.stage_ranges):
                 red.stage_done(i, rng)
             red.finish()
+            self._stage_buf = red.stage_buf
         self._clip_adam(self._last_eng, lr)
 
     def _forward_backward(self, x1, mask, cond_token_ids, on_stage):
@@ -257,9 +301,9 @@ class TrainStep:
         """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
         Returns the (un-synchronised) local loss tensor."""
         # --- backward with overlapped gradient exchange
-        red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
-                                comm_stream=self.comm_stream, comm_dtype=self.grad_comm_dtype)
+        red = self._reducer(self.grad_comm_dtype)
         loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None)
         red.finish()
+        self._stage_buf = red.stage_buf
         self._clip_adam(self._last_eng, lr)
         return loss

@@ -148,8 +148,12 @@ class FlatParams:
         return flat
 
     def bump(self):
-        """Call after writing parameter values behind PyTorch's back (raw-pointer kernels, collectives into `flat`)."""
+        """Call after writing parameter values behind PyTorch's back (raw-pointer kernels, collectives into `flat`) -- and after
+        writes through `p.data` (p.data.copy_(), p.data.mul_(), EMA weight swaps): `.data` has its own version counter, so such a
+        write changes neither p._version nor flat._version and the engines (and the hipGraph samplers that hold them) would keep
+        serving the previous fp16 / bf16 packed copies.  Public spelling: VoiceBox.mark_weights_dirty()."""
         self.epoch += 1
+        self._key_cache = None
 
     def weights_key(self):
         """Changes whenever any parameter value may have changed.  The nn.Parameters are `p.data = view` tensors with their OWN
@@ -159,6 +163,16 @@ class FlatParams:
         for s in self.order:
             ver += self.slots[s]._version
         return (self.flat.data_ptr(), self.flat._version, self.epoch, ver)
+
+    def weights_key_cached(self, token):
+        """weights_key() is an O(#parameters) Python loop; callers that evaluate it several times with nothing in between that can
+        write a parameter (the slot engines of one sampler call, bind_params right after adam_step_packed) pass the same `token`
+        and get the first evaluation back."""
+        kc = getattr(self, "_key_cache", None)
+        if kc is None or kc[0] is not token:
+            kc = (token, self.weights_key())
+            self._key_cache = kc
+        return kc[1]
 
     def offset_table(self):
         tab = (C.c_long * (NG + self.depth * NL))()

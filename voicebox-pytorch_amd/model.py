@@ -412,11 +412,25 @@ class VoiceBox(nn.Module):
         if eng is not None and eng.wpack_owner is not wpack_from:
             eng = None
         if eng is None:
-            if len(self._engines) >= 4 and key not in self._engines:  # arenas are large: keep a few shapes only
-                self._engines.pop(next(k for k in self._engines if self._engines[k] is not wpack_from))
+            # Arenas are large (3.6 GB for dim 512 / depth 12 / 8 x 1024 in training), so only FOUR shapes are kept.  A shape = an
+            # owner engine (key of length 3) plus the slot engines that share its packed weights (the sampler's second half batch:
+            # one more activation arena); they are evicted TOGETHER -- a slot engine must not outlive its owner in the cache, and an
+            # owner is not dropped while a sibling slot still shares its arena of packed weights.
+            owners = [k for k in self._engines if len(k) == 3]
+            if len(owners) >= 4 and key[:3] not in owners:
+                victim = next(k for k in owners if self._engines[k] is not wpack_from)
+                for k in [k for k in self._engines if k[:3] == victim]:
+                    self._engines.pop(k)
             eng = Engine(self._cfg, fp, B, N, training, dev, wpack_from=wpack_from)
             self._engines[key] = eng
         return eng
+
+    def mark_weights_dirty(self):
+        """Call after writing parameter values through `p.data` (p.data.copy_(), EMA weight swaps, ...): such writes bump neither the
+        parameter's nor the flat buffer's version counter, so nothing else tells the engines -- and the hipGraph samplers holding
+        them -- that their fp16 / bf16 packed operand copies are stale.  Writes through the parameters themselves (optimizer steps,
+        load_state_dict, p.copy_()) and this package's own training step are detected automatically."""
+        self.flat_params().bump()
 
     @property
     def device(self):

@@ -38,8 +38,13 @@ class MidpointSampler:
         assert steps >= 2, "need at least two time points"
         self.vb, self.B, self.N, self.steps = voicebox, B, N, steps
         if split is None:
-            split = int(os.environ.get("VBX_SAMPLE_SPLIT", "2"))
-        if split < 1 or B < 4 or B % split:
+            env = os.environ.get("VBX_SAMPLE_SPLIT", "2")
+            if env not in ("1", "2"):
+                raise ValueError(f"VBX_SAMPLE_SPLIT must be 1 or 2 (concurrent half batches are the only measured, tested split), got {env!r}")
+            split = int(env)
+        if split not in (1, 2):
+            raise ValueError(f"MidpointSampler(split={split}): only 1 (one stream) and 2 (two concurrent half batches) are supported")
+        if B < 4 or B % split:
             split = 1
         self.split = split
         Bp = B // split

@@ -149,7 +149,19 @@ class VoiceBoxTrainer(nn.Module):
         fp = ts.fp
         by_param = {id(fp.slots[s]): s for s in fp.order}
         steps = 0
-        for i, p in enumerate(self._optim_param_order()[0]):
+        params, n_wd = self._optim_param_order()
+        # Validate BEFORE copying anything: a checkpoint saved under the other weight-decay grouping (a reference wd = 0
+        # checkpoint into a wd > 0 trainer, or the reverse) numbers its parameters differently; torch.optim.load_state_dict raises a
+        # ValueError here, and so do we -- a partial, silently mis-assigned Adam state is never left behind.
+        want = [n_wd, len(params) - n_wd] if self.wd > 0 else [len(params)]
+        got = [len(g['params']) for g in sd['param_groups']]
+        if got != want:
+            raise ValueError(f"loaded state dict has parameter groups of sizes {got}, this trainer (wd = {self.wd}) has {want}")
+        for i, p in enumerate(params):
+            st = sd['state'].get(i)
+            if st is not None and (tuple(st['exp_avg'].shape) != tuple(p.shape) or tuple(st['exp_avg_sq'].shape) != tuple(p.shape)):
+                raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter has {tuple(p.shape)}")
+        for i, p in enumerate(params):
             st = sd['state'].get(i)
             s = by_param.get(id(p))
             if st is None or s is None:
@@ -218,11 +230,13 @@ class VoiceBoxTrainer(nn.Module):
             logs['loss'] = float(loss)
         else:
             total = 0.
-            for _ in range(self.grad_accum_every):
+            for i in range(self.grad_accum_every):
                 x, kw = self._model_kwargs(next(self.dl_iter))
-                loss = ts.accumulate(x, 1.0 / self.grad_accum_every, **kw)
+                if i + 1 < self.grad_accum_every:   # accelerator.no_sync: no exchange (trainer.py:258-272)
+                    loss = ts.accumulate(x, 1.0 / self.grad_accum_every, **kw)
+                else:                              # last micro-batch: exchange overlapped with ITS backward, then clip + Adam
+                    loss = ts.accumulate_last_and_apply(x, 1.0 / self.grad_accum_every, lr=lr, **kw)
                 total += float(loss) / self.grad_accum_every
-            ts.apply_accumulated(lr=lr)
             logs['loss'] = total
         if not steps % self.log_every:
             self.print(f"{steps}: loss: {logs['loss']:0.3f}")
