@@ -86,6 +86,72 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def test_last_micro_batch_with_overlapped_exchange_equals_deferred_exchange():
+    """accumulate_last_and_apply (the accumulation window's last micro-batch folds the accumulator in stage by stage and starts each
+    stage's exchange under its own backward) against accumulate + apply_accumulated (everything exchanged after the backward):
+    same parameters after the step up to the rounding of one fused multiply-add per gradient element."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 72, 128, generator=g) for _ in range(2)]
+    draws = [dict(x0=torch.randn(2, 72, 128, generator=g), times=torch.rand(2, generator=g), frac_lengths=0.7 + 0.3 * torch.rand(2, generator=g),
+                  rand=torch.rand(2, generator=g)) for _ in range(2)]
+    flats = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False).to("cuda:0")
+        ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb), lr=3e-4, max_grad_norm=0.5)
+        with rng_override(**draws[0]):
+            ts.accumulate(xs[0].cuda(), 0.5)
+        with rng_override(**draws[1]):
+            if fused:
+                ts.accumulate_last_and_apply(xs[1].cuda(), 0.5)
+            else:
+                ts.accumulate(xs[1].cuda(), 0.5)
+                ts.apply_accumulated()
+        torch.cuda.synchronize()
+        flats.append((ts.fp.flat.clone(), ts.m.clone()))
+    dm = float((flats[0][1] - flats[1][1]).abs().max()) / float(flats[0][1].abs().max())
+    assert dm < 1e-5, dm                                       # first moments = (1 - beta1) * clipped gradient: the gradients agree
+    assert float((flats[0][0] - flats[1][0]).abs().max()) < 1e-6  # and so do the updated parameters
+
+
+def test_length_bucketing_pads_with_masked_frames_only():
+    """TrainStep(length_bucket=64): a batch of 203 frames runs on the 256-frame engine (padded frames are masked everywhere) and gives
+    the loss and the gradients of the exact-length run up to summation order; ragged key-padding masks included."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = torch.Generator().manual_seed(9)
+    B, N = 3, 203
+    x = torch.randn(B, N, 128, generator=g)
+    draws = dict(x0=torch.randn(B, N, 128, generator=g), times=torch.rand(B, generator=g), frac_lengths=0.7 + 0.3 * torch.rand(B, generator=g),
+                 rand=torch.rand(B, generator=g))
+    mask = torch.ones(B, N, dtype=torch.bool)
+    mask[1, 150:] = False
+    res = []
+    for lb in (0, 64):
+        torch.manual_seed(1)
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False).to("cuda:0")
+        with torch.no_grad():
+            for name, p in vb.named_parameters():
+                if ".to_gamma.weight" in name or ".to_beta." in name:
+                    p.normal_(0.0, 0.02, generator=None)
+        ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb), lr=3e-4, max_grad_norm=0.5, length_bucket=lb)
+        with rng_override(**draws):
+            loss = ts._forward_backward(x.cuda(), mask.cuda(), None, on_stage=None)
+        torch.cuda.synchronize()
+        res.append((float(loss), ts.gflat.clone(), sorted(k[1] for k in vb._engines)))
+    assert res[0][2] == [203] and res[1][2] == [256]
+    assert abs(res[0][0] - res[1][0]) < 1e-5, (res[0][0], res[1][0])
+    rel = float((res[0][1] - res[1][1]).norm() / res[0][1].norm())
+    assert rel < 2e-3, rel  # bf16-operand GEMMs over a different number of rows: split-K boundaries and tile tails move
+
+
 def test_train_step_world2_on_one_gpu():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()

@@ -165,6 +165,42 @@ def test_small_golden_eval_and_sample(golden):
     assert torch.equal(a, b)
 
 
+def test_two_training_forwards_in_flight(golden):
+    """The reference's autograd keeps several graphs alive (voicebox_pytorch.py:1416-1425).  Two forwards of the SAME shape before any
+    backward -- (loss_a + loss_b).backward() -- must give the sum of the two separate gradients (two activation arenas per shape, the
+    second sharing the first one's packed weights); a third forward in flight raises; dropping a graph frees its arena."""
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    vbx, vb, wrapper = build(g["cfg"], g["state"])
+    x1 = g["x1"].to(dev)
+    x2 = torch.randn(x1.shape, generator=torch.Generator().manual_seed(77)).to(dev)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    grads = []
+    for xs in ((x1,), (x2,), (x1, x2)):
+        vb.zero_grad(set_to_none=True)
+        losses = []
+        for x in xs:
+            with rng_override(**draws):
+                losses.append(wrapper(x))
+        sum(losses).backward()
+        grads.append({k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None})
+    for k in grads[2]:
+        want = grads[0][k] + grads[1][k]
+        assert rel(grads[2][k], want) < 1e-5, (k, rel(grads[2][k], want))
+    with rng_override(**draws):
+        la = wrapper(x1)
+    with rng_override(**draws):
+        lb = wrapper(x2)
+    with pytest.raises(RuntimeError, match="two training forwards"):
+        with rng_override(**draws):
+            wrapper(x1)
+    del la  # its graph dies -> its arena is free again
+    with rng_override(**draws):
+        lc = wrapper(x1)
+    (lb + lc).backward()
+
+
 def test_error_conventions(golden):
     g = golden("small")
     vbx, vb, wrapper = build(g["cfg"], g["state"])

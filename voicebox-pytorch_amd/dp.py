@@ -134,7 +134,7 @@ class WarmupCosineLR:
 
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
-                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0.):
+                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0., length_bucket=0):
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         # wd > 0: AdamW as get_optimizer builds it (optimizer.py:10-35): decoupled decay p *= 1 - lr * wd on the parameters with
@@ -162,6 +162,11 @@ class TrainStep:
         self.exchange = self.world > 1 or (force_dist() and self.distributed)
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and dev.type == "cuda") else None
         self.bucket_bytes = bucket_bytes
+        # length_bucket > 0: batches are padded (with masked frames) up to the next multiple of it, so that a dataset of varying
+        # lengths (pad_to_longest collation, data.py:60-75) runs on a handful of engines instead of building a 3.6 GB activation
+        # arena per distinct length.  Masked frames change nothing for the valid ones (the conv positional embedding, the attention
+        # keys and the loss are all masked: voicebox_pytorch.py:220-233, attend.py:118-125, :1099-1115); 0 = exact lengths.
+        self.length_bucket = int(length_bucket)
         self._stage_buf = None  # wire-dtype staging of the gradient exchange, allocated once (grad_comm_dtype only)
 
     def _dirty(self, keep=None):
@@ -267,6 +272,15 @@ class TrainStep:
                 mask = torch.nn.functional.interpolate(m4, (N, 1), mode="bilinear")[:, 0, :, 0].to(torch.bool)
             text = (ids, vb.null_cond_id, drop, vb.null_cond)
         loss_mask = cond_mask if mask is None else (cond_mask & mask)  # reduce_masks_with_and (:1099)
+        if self.length_bucket > 0 and N % self.length_bucket and text is None:  # (token ids are resized to the frame count: :1055-1062)
+            Nb = -(-N // self.length_bucket) * self.length_bucket
+            pad = Nb - N
+            padf = lambda t: torch.nn.functional.pad(t, (0, 0, 0, pad))           # (B, N, D) -> (B, Nb, D), zeros
+            padm = lambda t: torch.nn.functional.pad(t, (0, pad), value=False)    # (B, N) -> (B, Nb), False
+            wt, flow = padf(wt), padf(flow)
+            mask = padm(mask if mask is not None else torch.ones(B, N, dtype=torch.bool, device=dev))
+            cond_mask, loss_mask = padm(cond_mask), padm(loss_mask)
+            N = Nb
         eng = vb.engine(B, N, training=True)
         loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
         eng.backward(self.gflat, gscale=None, on_stage=on_stage)

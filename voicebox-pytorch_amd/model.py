@@ -8,6 +8,8 @@ shared library raises.  The sub-modules below (Linear, Conv1d, ...) only *hold* 
 import math
 from pathlib import Path
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -302,6 +304,16 @@ class Transformer(nn.Module):
 
 
 # --------------------------------------------------------------------------------------- VoiceBox
+class _InFlight:
+    """Token of a training forward whose backward has not run yet (held by its autograd node, weakly referenced by the engine)."""
+    __slots__ = ("__weakref__",)
+
+
+def _arena_busy(eng):
+    ref = getattr(eng, "_in_flight", None)
+    return ref is not None and ref() is not None
+
+
 class _VoiceBoxLossFn(torch.autograd.Function):
     """loss = VoiceBox(w, target=flow) as ONE autograd node: forward = vbx_model_forward, backward =
     vbx_model_backward_{head,layer,embed} into a fresh flat gradient buffer whose views are returned per parameter."""
@@ -310,6 +322,8 @@ class _VoiceBoxLossFn(torch.autograd.Function):
     def forward(ctx, vb, eng, x, cond, cond_mask, times, attn_mask, target, loss_mask, text, *params):
         loss = eng.forward(x, cond, cond_mask, times, attn_mask=attn_mask, target=target, loss_mask=loss_mask, text=text)
         ctx.vb, ctx.eng, ctx.gen = vb, eng, eng.generation
+        ctx.token = _InFlight()           # dies with the autograd graph: the arena is free again when nobody can call backward
+        eng._in_flight = weakref.ref(ctx.token)
         return loss.clone().reshape(())
 
     @staticmethod
@@ -321,6 +335,7 @@ class _VoiceBoxLossFn(torch.autograd.Function):
         gflat = torch.zeros(vb._flat.numel, dtype=torch.float32, device=eng.device)
         gscale = gloss.detach().to(torch.float32).reshape(1).contiguous()
         eng.backward(gflat, gscale=gscale)
+        eng._in_flight = None
         return (None,) * 10 + tuple(vb._flat.grad_views(gflat))
 
 
@@ -492,7 +507,16 @@ class VoiceBox(nn.Module):
         target = target.to(dev, torch.float32)
         loss_mask = reduce_masks_with_and(cond_mask, self_attn_mask)  # :1099
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # The reference's autograd keeps any number of graphs alive (voicebox_pytorch.py:1416-1425); an activation arena holds ONE
+            # training forward.  Two arenas per shape form a ring: a second forward before the first one's backward (two micro-batch
+            # losses summed before .backward(), a regulariser evaluated on a second input) takes the other arena, which shares the
+            # first one's packed weights.  A third raises.
             eng = self.engine(batch, seq_len, training=True)
+            if _arena_busy(eng):
+                eng = self.engine(batch, seq_len, training=True, slot=1, wpack_from=eng)
+                if _arena_busy(eng):
+                    raise RuntimeError("VoiceBox: two training forwards of this (batch, frames) shape are already waiting for their "
+                                       "backward; call .backward() (or drop a graph) before running a third")
             fp = self._flat
             params = [fp.slots[s] for s in fp.order]
             return _VoiceBoxLossFn.apply(self, eng, x, cond, cond_mask, times, self_attn_mask, target, loss_mask, text, *params)

@@ -66,7 +66,9 @@ class VoiceBoxTrainer(nn.Module):
                  num_warmup_steps=None, num_epochs=None, lr=3e-4, initial_lr=1e-5, grad_accum_every=1, wd=0., max_grad_norm=0.5,
                  valid_frac=0.05, random_split_seed=42, log_every=10, save_results_every=100, save_model_every=1000,
                  results_folder='./results', force_clear_prev_results=None, split_batches=False, drop_last=False,
-                 accelerate_kwargs: dict = dict()):
+                 accelerate_kwargs: dict = dict(), length_bucket=64):
+        # length_bucket (not a reference keyword): batches of a varying-length dataset are padded with masked frames to the next
+        # multiple of it, so that training runs on a handful of activation arenas (dp.TrainStep); 0 = exact lengths
         super().__init__()
         assert isinstance(cfm_wrapper, ConditionalFlowMatcherWrapper)
         self.wd = float(wd)  # > 0: AdamW with decay on the ndim >= 2 parameters (get_optimizer, optimizer.py:10-35)
@@ -98,7 +100,7 @@ class VoiceBoxTrainer(nn.Module):
         self.num_warmup_steps = num_warmup_steps if exists(num_warmup_steps) else 0
         self.schedule = WarmupCosineLR(lr, self.num_train_steps, self.num_warmup_steps, initial_lr)
         self.train_step_fn = TrainStep(cfm_wrapper, lr=lr, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=max_grad_norm, wd=self.wd,
-                                       lr_schedule=None)
+                                       lr_schedule=None, length_bucket=length_bucket)
 
         sampler = None
         if self.world > 1:  # what accelerator.prepare(dl) does: each rank sees its own shard
