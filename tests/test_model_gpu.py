@@ -168,7 +168,8 @@ def test_small_golden_eval_and_sample(golden):
 def test_two_training_forwards_in_flight(golden):
     """The reference's autograd keeps several graphs alive (voicebox_pytorch.py:1416-1425).  Two forwards of the SAME shape before any
     backward -- (loss_a + loss_b).backward() -- must give the sum of the two separate gradients (two activation arenas per shape, the
-    second sharing the first one's packed weights); a third forward in flight raises; dropping a graph frees its arena."""
+    second sharing the first one's packed weights); a third forward in flight takes over the OLDEST arena (only that graph's backward
+    then raises, forwards never fail); dropping a graph frees its arena."""
     from voicebox_pytorch_amd.masks import rng_override
 
     g = golden("small")
@@ -192,13 +193,19 @@ def test_two_training_forwards_in_flight(golden):
         la = wrapper(x1)
     with rng_override(**draws):
         lb = wrapper(x2)
-    with pytest.raises(RuntimeError, match="two training forwards"):
-        with rng_override(**draws):
-            wrapper(x1)
-    del la  # its graph dies -> its arena is free again
     with rng_override(**draws):
-        lc = wrapper(x1)
-    (lb + lc).backward()
+        lc = wrapper(x1)          # third in flight: takes over la's arena
+    (lb + lc).backward()          # the two most recent graphs are intact
+    with pytest.raises(RuntimeError, match="two later forwards"):
+        la.backward()
+    with rng_override(**draws):
+        ld = wrapper(x1)
+    del ld                        # a dropped graph frees its arena: the next two forwards both keep theirs
+    with rng_override(**draws):
+        le = wrapper(x1)
+    with rng_override(**draws):
+        lf = wrapper(x2)
+    (le + lf).backward()
 
 
 def test_error_conventions(golden):

@@ -6,12 +6,12 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/final; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout 600 python bench.py > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > $O/r02_bench_train.json; tail -c 700 $O/r02_bench_train.json
-timeout 300 python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_sample.json
-timeout 300 python bench.py --dim 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-sample 2>/dev/null | tail -1 > $O/r02_bench_train_dim1024.json
+timeout 600 python bench.py > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > $O/r03_bench_train.json; tail -c 700 $O/r03_bench_train.json
+timeout 300 python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_sample.json
+timeout 300 python bench.py --dim 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-sample 2>/dev/null | tail -1 > $O/r03_bench_train_dim1024.json
 python - <<'PY'
 import json
-for n in ("r02_bench_train","r02_bench_sample","r02_bench_train_dim1024"):
+for n in ("r03_bench_train","r03_bench_sample","r03_bench_train_dim1024"):
     try:
         d=json.loads(open(f"gpurun_out/final/{n}.json").read())
         print(n, d["value"], d["ms_per_step"], d.get("roofline",{}).get("kernel"), d.get("roofline",{}).get("frac"), d.get("sample",{}).get("ms"), (d.get("cpu_baseline") or {}).get("value"))
@@ -26,8 +26,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o run -- $B > $R/$O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_mfma -o run -- $B > $R/$O/pmc_mfma.log 2>&1
 cd $R
-python tools/prof_summary.py $(find $O/prof_train -name "*.db" | head -1) 9 > $O/r02_train_step_kernel_stats.txt 2>&1
-python tools/prof_summary.py $(find $O/prof_sample -name "*.db" | head -1) 18 > $O/r02_sample_kernel_stats.txt 2>&1
-python tools/pmc_summary.py $O/r02_train_pmc.json $O/pmc_fetch $O/pmc_write $O/pmc_mfma > $O/r02_train_pmc.txt 2>&1
+python tools/prof_summary.py $(find $O/prof_train -name "*.db" | head -1) 9 > $O/r03_train_step_kernel_stats.txt 2>&1
+python tools/prof_summary.py $(find $O/prof_sample -name "*.db" | head -1) 18 > $O/r03_sample_kernel_stats.txt 2>&1
+python tools/pmc_summary.py $O/r03_train_pmc.json $O/pmc_fetch $O/pmc_write $O/pmc_mfma > $O/r03_train_pmc.txt 2>&1
 rm -rf $O/prof_train $O/prof_sample $O/pmc_fetch $O/pmc_write $O/pmc_mfma
-head -24 $O/r02_train_step_kernel_stats.txt
+head -24 $O/r03_train_step_kernel_stats.txt

@@ -330,8 +330,8 @@ class _VoiceBoxLossFn(torch.autograd.Function):
     def backward(ctx, gloss):
         vb, eng = ctx.vb, ctx.eng
         if eng.generation != ctx.gen:
-            raise RuntimeError("VoiceBox: another forward of the same (batch, frames) shape ran before this backward; the "
-                               "activation arena holds one training forward at a time")
+            raise RuntimeError("VoiceBox: two later forwards of the same (batch, frames) shape ran before this backward; the two "
+                               "activation arenas of a shape hold the two most recent training forwards")
         gflat = torch.zeros(vb._flat.numel, dtype=torch.float32, device=eng.device)
         gscale = gloss.detach().to(torch.float32).reshape(1).contiguous()
         eng.backward(gflat, gscale=gscale)
@@ -510,13 +510,15 @@ class VoiceBox(nn.Module):
             # The reference's autograd keeps any number of graphs alive (voicebox_pytorch.py:1416-1425); an activation arena holds ONE
             # training forward.  Two arenas per shape form a ring: a second forward before the first one's backward (two micro-batch
             # losses summed before .backward(), a regulariser evaluated on a second input) takes the other arena, which shares the
-            # first one's packed weights.  A third raises.
+            # first one's packed weights.  A third forward while both are still waiting takes over the OLDER arena: that graph's
+            # backward then raises (as every second forward did before round 3) -- forwards themselves never fail.
             eng = self.engine(batch, seq_len, training=True)
             if _arena_busy(eng):
-                eng = self.engine(batch, seq_len, training=True, slot=1, wpack_from=eng)
-                if _arena_busy(eng):
-                    raise RuntimeError("VoiceBox: two training forwards of this (batch, frames) shape are already waiting for their "
-                                       "backward; call .backward() (or drop a graph) before running a third")
+                eng1 = self.engine(batch, seq_len, training=True, slot=1, wpack_from=eng)
+                if not _arena_busy(eng1) or getattr(eng1, "_flight_seq", 0) < getattr(eng, "_flight_seq", 0):
+                    eng = eng1
+            self._flight_counter = getattr(self, "_flight_counter", 0) + 1
+            eng._flight_seq = self._flight_counter
             fp = self._flat
             params = [fp.slots[s] for s in fp.order]
             return _VoiceBoxLossFn.apply(self, eng, x, cond, cond_mask, times, self_attn_mask, target, loss_mask, text, *params)
