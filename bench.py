@@ -40,7 +40,8 @@ def build_model(args, dev):
 
     torch.manual_seed(0)  # identical weights on every rank
     vb = vbx.VoiceBox(dim=args.dim, num_cond_tokens=500, depth=args.depth, dim_head=64, heads=args.heads,
-                      condition_on_text=False, use_gateloop_layers=args.gateloop)
+                      condition_on_text=False, use_gateloop_layers=args.gateloop, attn_dropout=args.attn_dropout,
+                      ff_dropout=args.ff_dropout)
     with torch.no_grad():  # exercise the time conditioning (adaLN projections are zero-initialised)
         for name, p in vb.named_parameters():
             if ".to_gamma.weight" in name or ".to_beta." in name:
@@ -252,6 +253,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--intervals", type=int, default=64, help="sample mode: midpoint intervals (NFE = 2x)")
+    ap.add_argument("--attn-dropout", type=float, default=0.0, help="not a BASELINE config (the reference's default is 0): A/B only")
+    ap.add_argument("--ff-dropout", type=float, default=0.0, help="not a BASELINE config: A/B only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sample", action="store_true", help="train mode: skip the 64-interval sample leg")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
@@ -332,7 +335,8 @@ def main():
             "vs_baseline": None, "dtype": "f16/bf16 (fp16 forward operands, bf16 backward operands, fp32 accumulate/master)",
             "data": "synthetic",
             "config": {"workload": f"VoiceBox dim {args.dim} depth {args.depth} heads {args.heads} unconditional, "
-                                   f"{args.batch}x{args.frames} frames per GPU, {args.mode}" + (", GateLoop layers" if args.gateloop else ""),
+                                   f"{args.batch}x{args.frames} frames per GPU, {args.mode}" + (", GateLoop layers" if args.gateloop else "")
+                                   + (f", dropout attn {args.attn_dropout} ff {args.ff_dropout}" if args.attn_dropout or args.ff_dropout else ""),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
             "step_tflops_per_gpu": round(step_tf, 1), "step_roofline_frac": round(step_tf / PEAK_MFMA_TFLOPS, 4),
             "n_ranks_seen": dist.get_world_size() if dist is not None else 1,

@@ -154,6 +154,38 @@ int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* qb, const v
                        const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos, const float* rot_sin,
                        float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* scratch,
                        void* stream);
+/* ---- training-time dropout (attend.py:131 attention probabilities, voicebox_pytorch.py:346 GEGLU output)
+ * The mask is a pure function of (seed, stream_id, element index) through Philox4x32-10, 16 random bits per element: an element is
+ * kept iff its lot < thr16 = round((1 - p) * 65536), survivors are scaled by vbx_dropout_keep_scale(p) = 65536 / thr16 (exactly
+ * unbiased for the realised keep rate).  Counters: attention element (bh, q, key) -> (4 * (key / 32) + (key % 32) / 8, q, bh, stream_id),
+ * lot key % 8; FeedForward element (row, col) -> (col / 8, row, 0, stream_id), lot col % 8; Philox key = (seed low, seed high);
+ * lot e of a call = 16-bit half e % 2 (low first) of output word e / 2.  The runtime uses stream_id = 2 * layer (attention) and
+ * 2 * layer + 1 (FeedForward) with one seed per forward (vbx_io.drop_seed).
+ * vbx_attn_dropout_bits writes one layer's keep bits in both orientations the kernels read: bits_rm [B*H][Np][W] (bit key % 32 of
+ * word key / 32) and bits_cm [B*H][Np keys][W] (bit q % 32 of word q / 32), W = vbx_dropout_bits_words(Np) 32-bit words per row.
+ * The *_dropout attention entry points take them: the forward keeps the softmax statistics of the undropped probabilities; the
+ * backward runs on the two-body kernel.  vbx_dropout_rows drops a [rows, cols] 16-bit matrix in place (fp16 copy and / or bf16
+ * copy of the same values; cols and ld multiples of 8) -- applied to the GEGLU output in the forward and to its gradient in the
+ * backward. */
+int vbx_dropout_bits_words(int Np);
+float vbx_dropout_keep_scale(float p);
+int vbx_attn_dropout_bits(void* bits_rm, void* bits_cm, int BH, int Np, unsigned long long seed, unsigned stream_id, float p,
+                          void* stream);
+int vbx_dropout_rows(void* x_f16, void* x_bf16, long rows, int cols, int ld, unsigned long long seed, unsigned stream_id, float p,
+                     void* stream);
+int vbx_attn_fwd_dropout(const void* q16, const void* k16, const void* v16, const uint8_t* mask, void* out16, void* out_bf16,
+                         float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p, void* stream);
+int vbx_attn_bwd_dropout(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
+                         const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, float* dq, float* dk,
+                         void* dv, int dv_ld, int B, int H, int Np, float scale, const void* bits_rm, const void* bits_cm, float p,
+                         void* stream);
+/* bits_rm == NULL: identical to vbx_attn_bwd_fused */
+int vbx_attn_bwd_fused_dropout(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
+                               const void* out, int out_is_f16, const void* dout, const float* lse, float* delta,
+                               const float* q_rnorm, const float* k_rnorm, const float* q_gamma, const float* k_gamma,
+                               const float* rot_cos, const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B,
+                               int H, int Np, float scale, void* scratch, const void* bits_rm, const void* bits_cm, float p,
+                               void* stream);
 int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
                         const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
                         const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np,
@@ -376,6 +408,9 @@ typedef struct {
                              to_embed is Linear(2*D + E, D) over [x | cond_emb | cond] (:1071-1076) */
   int V1;                 /* rows of the conditioning embedding table (num_cond_tokens + 1) */
   int plain_norm;         /* 1: non-adaptive RMSNorm (adaptive_rmsnorm = False, :386-389): gammas at VBX_L_N1G / VBX_L_N2G */
+  float attn_dropout;     /* attn_dropout (:895, attend.py:131) and ff_dropout (:891, :346) of the module: applied in a forward whose */
+  float ff_dropout;       /* vbx_io.dropout != 0 (nn.Dropout: module.training), keyed by vbx_io.drop_seed; with attn_dropout > 0 the
+                             arena holds the attention keep bits (per layer when training != 0, for the backward) */
 } vbx_model;
 
 typedef struct {
@@ -396,6 +431,8 @@ typedef struct {
   const float* null_cond;       /* E > 0: [D] null_cond parameter (:944), required with drop_mask */
   float* dx;                    /* stack_only backward: [B,N,D] gradient of the stack input */
   float* dcond;                 /* stack_only backward: [B,Th] gradient of the adaptive-norm condition (NULL with plain_norm) */
+  int dropout;                  /* 1: apply the model's attn_dropout / ff_dropout in this forward (the module is in train() mode) */
+  unsigned long long drop_seed; /* Philox key of this forward's masks (the backward entry points must see the same io) */
 } vbx_io;
 
 size_t vbx_model_wpack_bytes(const vbx_model* m);

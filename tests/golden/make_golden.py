@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -456,6 +456,57 @@ def gen_small_wc(ref):
     print("small_wc: loss", float(loss))
 
 
+def gen_small_dropout(ref):
+    """Training-time dropout (attn_dropout = 0.1 on the attention probabilities, attend.py:131; ff_dropout = 0.2 between GEGLU and the
+    output projection, voicebox_pytorch.py:346) on the well-conditioned small model: one training step of the UNMODIFIED reference
+    with forward hooks on its nn.Dropout modules recording which entries survived.  Pins WHERE the restatement applies the masks
+    and how they scale; the product path draws its own (Philox) masks and is compared through the restatement."""
+    from torch import nn
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    pa, pf = 0.1, 0.2
+    torch.manual_seed(0)
+    vb = ref.VoiceBox(dim=cfg.dim, num_cond_tokens=500, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads,
+                      condition_on_text=False, num_register_tokens=cfg.num_register_tokens, attn_dropout=pa, ff_dropout=pf)
+    wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb)
+    g = torch.Generator().manual_seed(124)
+    with torch.no_grad():
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or ".to_beta." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            if name.endswith("final_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+            if name.endswith("q_norm.gamma") or name.endswith("k_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+                prm.mul_(0.25)
+    state = {k: v.detach().clone() for k, v in vb.state_dict().items()}
+    keep = {"attn": {}, "ff": {}}
+
+    def hook(kind, layer):
+        def fn(mod, inp, out):
+            keep[kind][layer] = ((out != 0) | (inp[0] == 0)).detach().clone()
+        return fn
+
+    n_hooks = 0
+    for name, mod in vb.named_modules():
+        if isinstance(mod, nn.Dropout) and name.startswith("transformer.layers."):
+            layer = int(name.split(".")[2])
+            mod.register_forward_hook(hook("attn" if name.endswith("attn_dropout") else "ff", layer))
+            n_hooks += 1
+    assert n_hooks == 2 * cfg.depth, n_hooks
+    b, n = 2, 40
+    x1 = torch.randn(b, n, cfg.dim, generator=torch.Generator().manual_seed(71))
+    x0, times, frac, rand = replay_draws(x1, seed=96)
+    torch.manual_seed(96)
+    loss = wrapper(x1)  # wrapper.forward puts the voicebox in train() mode (:1414)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    assert sorted(keep["attn"]) == sorted(keep["ff"]) == list(range(cfg.depth))
+    torch.save(dict(cfg=dict(dim=64, depth=2, heads=2, dim_head=64), attn_dropout=pa, ff_dropout=pf, state=state, x1=x1, x0=x0,
+                    times=times, frac=frac, rand=rand, keep_attn=keep["attn"], keep_ff=keep["ff"], loss=loss.detach(), grads=grads),
+               os.path.join(HERE, "small_dropout.pt"))
+    print("small_dropout: loss", float(loss), "kept attn", float(keep["attn"][0].float().mean()), "ff", float(keep["ff"][0].float().mean()))
+
+
 def _wc(state):
     for k in state:
         if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
@@ -542,9 +593,9 @@ def gen_cfg5_wc_b8(ref):
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
          "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
-         "cfg5_wc_b8": gen_cfg5_wc_b8}[w](ref)
+         "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout}[w](ref)

@@ -109,8 +109,7 @@ def test_no_cpu_fallback(golden):
 def test_unsupported_configurations_raise():
     import voicebox_pytorch_amd as vbx
 
-    for kw in (dict(dim_head=32), dict(attn_dropout=0.1), dict(ff_dropout=0.1),
-               dict(conv_pos_embed_kernel_size=15), dict(dim=100)):
+    for kw in (dict(dim_head=32), dict(conv_pos_embed_kernel_size=15), dict(dim=100)):
         base = dict(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
         base.update(kw)
         with pytest.raises((NotImplementedError, AssertionError)):
@@ -118,6 +117,33 @@ def test_unsupported_configurations_raise():
     vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
     with pytest.raises(NotImplementedError):
         vbx.ConditionalFlowMatcherWrapper(voicebox=vb, use_torchode=True)
+
+
+def test_philox_restatement_known_answers_and_dropout_modules():
+    """tests/philox_ref.py (the host statement of the dropout mask definition the GPU tests compare the kernels with) reproduces
+    the published Philox4x32-10 known-answer vectors (Random123 kat_vectors); a model built with dropout carries the reference's
+    parameter-free nn.Dropout holders (attend.py:47, voicebox_pytorch.py:346) and the same state-dict keys as one without."""
+    import numpy as np
+    import philox_ref as PR
+    import voicebox_pytorch_amd as vbx
+
+    kat = (((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)))
+    for ctr, key, want in kat:
+        got = PR.philox4x32_10(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    assert PR.thr16(0.1) == 58982 and PR.thr16(0.5) == 32768 and PR.thr16(1e-9) == 65535
+    keep = PR.rows_keep(64, 64, 0.25, 12345, 3)
+    assert 0.70 < keep.mean() < 0.80
+    base = dict(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    vb = vbx.VoiceBox(**base, attn_dropout=0.1, ff_dropout=0.2)
+    assert list(vb.state_dict()) == list(vbx.VoiceBox(**base).state_dict())
+    layer = vb.transformer.layers[0]
+    assert layer[3].attend.attn_dropout.p == 0.1 and layer[5][2].p == 0.2
+    assert vb._cfg["attn_dropout"] == 0.1 and vb._cfg["ff_dropout"] == 0.2
+    with pytest.raises(AssertionError):
+        vbx.VoiceBox(**base, attn_dropout=1.0)
 
 
 def test_gateloop_state_dict_layout(golden):

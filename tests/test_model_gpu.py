@@ -958,6 +958,131 @@ def test_ode_step_kernels_reproduce_the_textbook_midpoint_rule():
         assert rel(y, y0.double().cpu() * fac) < 2e-6, (steps, rel(y, y0.double().cpu() * fac))
 
 
+def _model_dropout_multipliers(vbx, eng, cfg, B, N, pa, pf):
+    """The multipliers (keep / kept fraction) the engine's last forward applied, rebuilt from its Philox key through the public
+    C-ABI entry points: attention [b, h, i, j] per layer (stream 2 * layer), FeedForward [b, n, inner] per layer (2 * layer + 1)."""
+    import philox_ref as PR
+    from voicebox_pytorch_amd import _lib as L
+    from voicebox_pytorch_amd.model import attn_dropout_bits
+
+    seed, H, Np, F = int(eng.io.drop_seed), cfg.heads, N + cfg.num_register_tokens, cfg.ff_inner
+    Fp = (F + 63) // 64 * 64
+    attn, ff = {}, {}
+    for l in range(cfg.depth):
+        if pa > 0:
+            rm, _ = attn_dropout_bits(B, H, Np, pa, seed, 2 * l, dev)
+            keep = torch.from_numpy(PR.unpack_bits(rm.cpu().numpy(), Np)).view(B, H, Np, Np)
+            attn[l] = keep.double() * L.lib().vbx_dropout_keep_scale(pa)
+        if pf > 0:
+            ones = torch.ones(B * Np, Fp, dtype=torch.bfloat16, device=dev)
+            L.call("vbx_dropout_rows", None, ones, B * Np, Fp, Fp, seed, 2 * l + 1, pf, torch.cuda.current_stream().cuda_stream)
+            ff[l] = ones.double().cpu().view(B, Np, Fp)[:, :, :F]  # bf16(65536 / thr16) is within 2^-9 of the scale: rebuild exactly
+            ff[l] = (ff[l] != 0).double() * L.lib().vbx_dropout_keep_scale(pf)
+    return attn or None, ff or None
+
+
+def test_training_dropout_vs_oracle_with_the_same_masks(golden):
+    """attn_dropout / ff_dropout (attend.py:131, voicebox_pytorch.py:346) through the whole training step: the loss and EVERY gradient
+    of VoiceBox(attn_dropout=0.1, ff_dropout=0.2) against the restatement given the masks this forward drew (rebuilt from the engine's
+    Philox key).  tests/test_oracle.py pins the restatement's mask placement on the unmodified reference's own nn.Dropout masks.
+    Also: eval() switches dropout off, a fixed torch seed reproduces the step, another seed changes it."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small_dropout")
+    cfg = restate.Cfg(**g["cfg"])
+    pa, pf = g["attn_dropout"], g["ff_dropout"]
+    vb = vbx.VoiceBox(dim=cfg.dim, num_cond_tokens=500, depth=cfg.depth, dim_head=64, heads=cfg.heads, condition_on_text=False,
+                      attn_dropout=pa, ff_dropout=pf)
+    vb.load_state_dict(g["state"], strict=False)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    B, N = g["x1"].shape[:2]
+    torch.manual_seed(1234)
+    with rng_override(**draws):
+        loss = wrapper(g["x1"].to(dev))
+    loss.backward()
+    eng = vb._engines[(B, N, True)]
+    assert eng.io.dropout == 1
+    attn, ff = _model_dropout_multipliers(vbx, eng, cfg, B, N, pa, pf)
+    assert 0.85 < float((attn[0] != 0).double().mean()) < 0.95 and 0.75 < float((ff[1] != 0).double().mean()) < 0.85
+    p = {k: v.double().clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    with restate.dropout_multipliers(attn=attn, ff=ff):
+        ref = restate.cfm_loss(p, cfg, g["x1"].double(), g["x0"].double(), g["times"].double(), g["frac"], g["rand"])
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-3, (float(loss), float(ref))
+    worst = 0.0
+    for k, prm in vb.named_parameters():
+        if p[k].grad is None:
+            continue
+        e = rel(prm.grad, p[k].grad)
+        worst = max(worst, e)
+        assert e < 0.03, (k, e)  # the bound small_wc holds without dropout
+    # the masks matter: the undropped restatement is an order of magnitude further away
+    ref0 = restate.cfm_loss(p, cfg, g["x1"].double(), g["x0"].double(), g["times"].double(), g["frac"], g["rand"])
+    assert abs(float(loss) - float(ref0)) > 10 * abs(float(loss) - float(ref))
+    # same torch seed -> same masks -> same loss, bit for bit; another seed -> other masks
+    losses = []
+    for sd in (1234, 1234, 99):
+        vb.zero_grad()
+        torch.manual_seed(sd)
+        with rng_override(**draws):
+            l2 = wrapper(g["x1"].to(dev))
+        l2.backward()
+        losses.append(float(l2))
+    assert losses[0] == float(loss) and losses[1] == losses[0] and abs(losses[2] - losses[0]) > 1e-4
+    # nn.Dropout semantics follow the MODULE's mode: eval() -> no dropout even with gradients enabled ...
+    vb.eval()
+    x, cond, t = g["x1"].to(dev), g["x0"].to(dev), g["times"].to(dev)
+    cm = torch.ones(B, N, dtype=torch.bool, device=dev)
+    with torch.no_grad():
+        pe = vb(x, times=t, cond_token_ids=None, cond=cond, cond_mask=cm, cond_drop_prob=0.0)
+        pe2 = vb(x, times=t, cond_token_ids=None, cond=cond, cond_mask=cm, cond_drop_prob=0.0)
+    assert torch.equal(pe, pe2)
+    p32 = {k: v.clone() for k, v in g["state"].items()}
+    want = restate.voicebox_forward(p32, cfg, g["x1"], g["times"], g["x0"], cm.cpu())
+    assert rel(pe, want) < 0.02
+    # ... and train() under no_grad -> dropout IS applied (as the reference's nn.Dropout would)
+    vb.train()
+    with torch.no_grad():
+        pt = vb(x, times=t, cond_token_ids=None, cond=cond, cond_mask=cm, cond_drop_prob=0.0)
+    assert rel(pt, pe.cpu()) > 0.02
+    print(f"dropout step: |dloss| {abs(float(loss) - float(ref)):.2e}, worst gradient {worst:.3%}")
+
+
+def test_attend_module_with_dropout(golden):
+    """Attend(dropout=p) (attend.py:38-137): training mode drops attention probabilities with the mask of its last Philox key, eval
+    mode does not; gradients flow through the dropped softmax."""
+    import philox_ref as PR
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd import _lib as L
+    from voicebox_pytorch_amd.model import attn_dropout_bits
+
+    B, H, Np, p = 2, 2, 90, 0.3
+    gen = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(B, H, Np, 64, generator=gen) for _ in range(3))
+    q, k = q / q.norm(dim=-1, keepdim=True) * 3, k / k.norm(dim=-1, keepdim=True) * 3
+    att = vbx.Attend(dropout=p).to(dev)
+    assert isinstance(att.attn_dropout, torch.nn.Dropout)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = att(qd, kd, vd)
+    up = torch.randn(out.shape, generator=gen)
+    (out * up.to(dev)).sum().backward()
+    rm, _ = attn_dropout_bits(B, H, Np, p, att.last_dropout_seed, 0, dev)
+    mult = torch.from_numpy(PR.unpack_bits(rm.cpu().numpy(), Np)).view(B, H, Np, Np).double() * L.lib().vbx_dropout_keep_scale(p)
+    qr, kr, vr = (t.half().double().requires_grad_(True) for t in (q, k, v))
+    ref = restate.attend(qr, kr, vr, drop=mult)
+    (ref * up.double()).sum().backward()
+    assert rel(out, ref) < 3e-3
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        assert rel(got, want) < 2e-2, rel(got, want)
+    att.eval()
+    with torch.no_grad():
+        oe = att(qd, kd, vd)
+    assert rel(oe, restate.attend(qr, kr, vr)) < 3e-3
+
+
 def test_sampler_concurrent_halves_equal_single_stream(golden, monkeypatch):
     """The sampler integrates a batch of >= 4 as two half-batches on two streams (two parallel branches of one hipGraph, own
     activation arenas, shared packed weights).  Batch elements are independent in every kernel of the path, so the result must

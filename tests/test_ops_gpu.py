@@ -380,6 +380,137 @@ def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked, bwd_variant):
     assert rel_err(dk, kr.grad) < 2e-2, rel_err(dk, kr.grad)
 
 
+# ---------------------------------------------------------------------------------------- dropout (attend.py:131, :346)
+def _attn_bits(L, BH, Np, p, seed, stream):
+    W = L.lib().vbx_dropout_bits_words(Np)
+    rm = torch.full((BH, Np, W), -1, dtype=torch.int32, device=dev)
+    cm = torch.full((BH, Np, W), -1, dtype=torch.int32, device=dev)
+    L.call("vbx_attn_dropout_bits", rm, cm, BH, Np, seed, stream, p, st())
+    torch.cuda.synchronize()
+    return rm, cm
+
+
+@pytest.mark.parametrize("BH,Np,p", [(3, 100, 0.1), (2, 1040, 0.25), (1, 64, 0.5), (5, 33, 0.9)])
+def test_attn_dropout_bits_are_the_documented_philox_stream(L, BH, Np, p):
+    """The keep bits equal the host restatement of include/vbx.h's definition (Philox4x32-10, counter (4 * (key / 32) +
+    (key % 32) / 8, q, bh, stream), 16-bit lots) in BOTH orientations; bits past Np are zero."""
+    import philox_ref as PR
+    seed, stream = 0x1234_5678_9ABC_DEF0 >> 2, 7
+    rm, cm = _attn_bits(L, BH, Np, p, seed, stream)
+    W = rm.shape[-1]
+    assert W == 2 * ((Np + 63) // 64)
+    want = PR.attn_keep(BH, Np, p, seed, stream)  # [bh, q, key]
+    got_r = PR.unpack_bits(rm.cpu().numpy(), W * 32)
+    got_c = PR.unpack_bits(cm.cpu().numpy(), W * 32)
+    assert (got_r[:, :, :Np] == want).all()
+    assert (got_c[:, :, :Np] == want.transpose(0, 2, 1)).all()
+    assert not got_r[:, :, Np:].any() and not got_c[:, :, Np:].any()
+    # a different stream / seed gives a different mask; the same arguments the same one
+    rm2, _ = _attn_bits(L, BH, Np, p, seed, stream + 1)
+    rm3, _ = _attn_bits(L, BH, Np, p, seed + 1, stream)
+    rm4, cm4 = _attn_bits(L, BH, Np, p, seed, stream)
+    assert not torch.equal(rm, rm2) and not torch.equal(rm, rm3) and torch.equal(rm, rm4) and torch.equal(cm, cm4)
+
+
+def test_attn_dropout_bits_statistics(L):
+    """Kept fraction = thr16 / 65536 within 5 sigma over 34 M draws; no visible dependence between neighbouring keys, neighbouring
+    queries or heads; vbx_dropout_keep_scale is the exact inverse of the kept fraction."""
+    import philox_ref as PR
+    BH, Np, p = 32, 1040, 0.1
+    rm, _ = _attn_bits(L, BH, Np, p, 99, 0)
+    keep = torch.from_numpy(PR.unpack_bits(rm.cpu().numpy(), Np)).float()
+    n = keep.numel()
+    frac = PR.thr16(p) / 65536.0
+    assert abs(L.lib().vbx_dropout_keep_scale(p) * frac - 1.0) < 1e-6
+    assert abs(float(keep.mean()) - frac) < 5 * math.sqrt(frac * (1 - frac) / n)
+    c = keep - frac
+    for a, b in ((c[:, :, 1:], c[:, :, :-1]), (c[:, 1:], c[:, :-1]), (c[1:], c[:-1])):
+        corr = float((a * b).mean()) / (frac * (1 - frac))
+        assert abs(corr) < 5 / math.sqrt(a.numel()), corr
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(100, 64, 64), (8320, 1408, 1408), (33, 40, 48)])
+def test_dropout_rows(L, rows, cols, ld):
+    """nn.Dropout between GEGLU and the output projection (voicebox_pytorch.py:346): in place on the fp16 and the bf16 copy, the
+    documented Philox stream, survivors scaled by 65536 / thr16."""
+    import philox_ref as PR
+    p, seed, stream = 0.2, 424242, 5
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, ld, generator=g) * 3
+    xh, xb = x.half().to(dev), x.bfloat16().to(dev)
+    L.call("vbx_dropout_rows", xh, xb, rows, cols, ld, seed, stream, p, st())
+    torch.cuda.synchronize()
+    keep = torch.from_numpy(PR.rows_keep(rows, cols, p, seed, stream))
+    rk = L.lib().vbx_dropout_keep_scale(p)
+    for got, src, tol in ((xh.float().cpu(), x.half().float(), 1e-3), (xb.float().cpu(), x.bfloat16().float(), 8e-3)):
+        want = torch.where(keep, src[:, :cols] * rk, torch.zeros(()))
+        assert torch.allclose(got[:, :cols], want, rtol=tol, atol=1e-6)
+        assert torch.equal(got[:, cols:], src[:, cols:])  # the padding columns between cols and ld are not touched
+    # one copy only
+    yb = x.bfloat16().to(dev)
+    L.call("vbx_dropout_rows", None, yb, rows, cols, ld, seed, stream, p, st())
+    assert torch.equal(yb, xb)
+
+
+@pytest.mark.parametrize("Bsz,H,Np,scale,masked,p", [(1, 2, 64, 10.0, False, 0.1), (2, 2, 1040, 10.0, False, 0.1),
+                                                     (2, 3, 77, 10.0, True, 0.3), (1, 2, 200, 0.125, True, 0.5),
+                                                     (2, 2, 130, 10.0, False, 0.2)])
+def test_attn_dropout_fwd_bwd(L, Bsz, H, Np, scale, masked, p):
+    """attend.py:121-135 with attn_dropout: softmax -> dropout -> P.V, against the fp64 restatement given the SAME keep mask (read
+    back from the kernel's bits); forward statistics (LSE) are those of the undropped softmax."""
+    import philox_ref as PR
+    q16, k16, v = attn_inputs(Bsz, H, Np, seed=Np + H + 1, qnorm=8.0 if scale == 10.0 else None)
+    mask = None
+    if masked:
+        mask = torch.ones(Bsz, Np, dtype=torch.bool)
+        mask[0, Np - 13:] = False
+        if Bsz > 1:
+            mask[1, 5:9] = False
+    seed = 77 + Np
+    rm, cm = _attn_bits(L, Bsz * H, Np, p, seed, 4)
+    keep = torch.from_numpy(PR.unpack_bits(rm.cpu().numpy(), Np)).view(Bsz, H, Np, Np)
+    mult = keep.double() * L.lib().vbx_dropout_keep_scale(p)
+    out16 = torch.empty(Bsz, Np, H * 64, dtype=torch.float16, device=dev)
+    out = torch.empty(Bsz, Np, H * 64, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(Bsz, H, Np, device=dev)
+    qd, kd, vd = q16.to(dev), k16.to(dev), v.to(dev)
+    md = mask.to(dev) if masked else None
+    L.call("vbx_attn_fwd_dropout", qd, kd, vd, md, out16, out, lse, Bsz, H, Np, scale, rm, p, st())
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q16, k16, v))
+    ref = restate.attend(qr, kr, vr, mask=mask, scale=scale, drop=mult)
+    ref_t = ref.permute(0, 2, 1, 3).reshape(Bsz, Np, H * 64)
+    assert rel_err(out16, ref_t) < 1.5e-3, rel_err(out16, ref_t)
+    assert rel_err(out, ref_t) < 5e-3, rel_err(out, ref_t)
+    sim = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    if masked:
+        sim = sim.masked_fill(~mask[:, None, None, :], -float("inf"))
+    assert max_err(lse, torch.logsumexp(sim, dim=-1) / math.log(2.0)) < 2e-3
+    # the dropped output differs from the undropped one by far more than the tolerance above (the mask is really applied)
+    plain = restate.attend(qr, kr, vr, mask=mask, scale=scale).permute(0, 2, 1, 3).reshape(Bsz, Np, H * 64)
+    assert rel_err(out16, plain) > 0.05
+    # ---- backward
+    g = torch.Generator().manual_seed(5)
+    dout = bf(torch.randn(Bsz, Np, H * 64, generator=g) * 1e-3)
+    ref_t.backward(dout.double())
+    qb, kb = bf(q16.float()).to(dev), bf(k16.float()).to(dev)
+    delta = torch.empty(Bsz, H, Np, device=dev)
+    dq = torch.zeros(Bsz, H, Np, 64, device=dev)
+    dk = torch.zeros(Bsz, H, Np, 64, device=dev)
+    dv = torch.zeros(Bsz, Np, 3 * H * 64, dtype=torch.bfloat16, device=dev)
+    dv_view = dv[:, :, 2 * H * 64:]
+    L.call("vbx_attn_bwd_dropout", qd, kd, qb, kb, bf(v.float()).to(dev), md, out16, 1, dout.to(dev), lse, delta, dq, dk,
+           dv_view.data_ptr(), 3 * H * 64, Bsz, H, Np, scale, rm, cm, p, st())
+    torch.cuda.synchronize()
+    dv_got = dv_view.float().cpu().view(Bsz, Np, H, 64).permute(0, 2, 1, 3)
+    assert rel_err(dv_got, vr.grad) < 1.5e-2, rel_err(dv_got, vr.grad)
+    # At |q| = |k| = 8, scale 10 the softmax is one-hot: where the top key survives, dS = P (dP / keep - delta) cancels to ~0 and what
+    # remains is the fp16 rounding of O inside delta = dO . O -- a CPU emulation of exactly these roundings (fp16 P and O, bf16 dO, V,
+    # dS, q, k; fp64 otherwise) gives 3.4 % / 2.2 % / 1.4 % for Np = 64 / 77 / 130 and the kernels land on those figures (3.6 / 2.3 %).
+    tol = 5e-2 if scale == 10.0 else 2e-2
+    assert rel_err(dq, qr.grad) < tol, rel_err(dq, qr.grad)
+    assert rel_err(dk, kr.grad) < tol, rel_err(dk, kr.grad)
+
+
 @pytest.mark.parametrize("qknorm", [True, False])
 def test_qknorm_rope_bwd(L, qknorm):
     Bsz, H, Np = 2, 2, 70

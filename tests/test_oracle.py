@@ -51,6 +51,28 @@ def test_small_model_loss_and_grads(golden):
         assert torch.allclose(p2[k].grad, ref, rtol=2e-3, atol=2e-6), k
 
 
+def test_small_model_with_dropout_masks_of_the_reference(golden):
+    """attend.py:131 / voicebox_pytorch.py:346: the restatement with the keep masks the reference's own nn.Dropout modules drew
+    (recorded by forward hooks, tests/golden/make_golden.py::gen_small_dropout) reproduces the reference's loss and gradients --
+    i.e. the masks act where and how nn.Dropout acts (on the softmax output, on the GEGLU output; survivors / (1 - p))."""
+    g = golden("small_dropout")
+    cfg = _cfg(g["cfg"])
+    pa, pf = g["attn_dropout"], g["ff_dropout"]
+    attn = {l: k.float() / (1 - pa) for l, k in g["keep_attn"].items()}
+    ff = {l: k.float() / (1 - pf) for l, k in g["keep_ff"].items()}
+    assert 0.85 < float(g["keep_attn"][0].float().mean()) < 0.95 and 0.75 < float(g["keep_ff"][0].float().mean()) < 0.85
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    with restate.dropout_multipliers(attn=attn, ff=ff):
+        loss = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        assert torch.allclose(p[k].grad, ref, rtol=2e-3, atol=2e-6), (k, float((p[k].grad - ref).abs().max()))
+    # and without the masks the loss differs (the masks matter at this tolerance)
+    loss0 = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"])
+    assert abs(float(loss0) - float(g["loss"])) > 1e-3
+
+
 def test_small_model_eval_and_sample(golden):
     g = golden("small")
     cfg = _cfg(g["cfg"])

@@ -41,6 +41,11 @@ _PROTOS = {
     "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P],
     "vbx_attn_bwd_fused": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P, P],
     "vbx_attn_bwd_select": [I],
+    "vbx_dropout_bits_words": [I],
+    "vbx_attn_dropout_bits": [P, P, I, I, C.c_ulonglong, C.c_uint, F, P],
+    "vbx_dropout_rows": [P, P, L, I, I, C.c_ulonglong, C.c_uint, F, P],
+    "vbx_attn_fwd_dropout": [P, P, P, P, P, P, P, I, I, I, F, P, F, P],
+    "vbx_attn_bwd_dropout": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P, F, P],
     "vbx_attn_bwd_fused_tiles": [I],
     "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
@@ -110,6 +115,12 @@ def lib():
         raise VbxError(
             f"{LIB_PATH} not found: the HIP extension is REQUIRED (no CPU/eager fallback exists). "
             "Build it with `python voicebox-pytorch_amd/build.py` (needs hipcc).")
+    if not os.environ.get("VBX_LIB_PATH"):  # a library that was not rebuilt after a source edit must not be mistaken for the product
+        from . import build as _build
+
+        if _build.recorded_hash() != _build.source_hash():
+            raise VbxError(f"{LIB_PATH} is stale: csrc/ or include/vbx.h changed since it was built (or it predates the source-hash "
+                           "stamp).  Rebuild with `python voicebox-pytorch_amd/build.py`.")
     l = C.CDLL(LIB_PATH)
     l.vbx_last_error.restype = C.c_char_p
     l.vbx_last_error.argtypes = []
@@ -119,12 +130,14 @@ def lib():
         fn.restype = I
     l.vbx_attn_bwd_scratch_bytes.argtypes = [I, I, I]
     l.vbx_attn_bwd_scratch_bytes.restype = C.c_size_t
+    l.vbx_dropout_keep_scale.argtypes = [F]
+    l.vbx_dropout_keep_scale.restype = F
     _lib = l
     return l
 
 
 def exported_symbols():
-    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes"]  # + the stage-level entries bound in engine.py
+    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes", "vbx_dropout_keep_scale"]  # + the stage-level entries bound in engine.py
 
 
 def ptr(t):

@@ -16,12 +16,31 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """sha1 over everything the library is compiled from (csrc/* and include/vbx.h)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "vbx.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+HASH_FILE = LIB + ".srchash"  # written next to the library: a .so that was not rebuilt after a source edit is refused at load time
+
+
+def recorded_hash():
+    try:
+        return open(HASH_FILE).read().strip()
+    except OSError:
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vbx.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return not os.path.exists(LIB) or recorded_hash() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -51,6 +70,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(HASH_FILE, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

@@ -766,6 +766,17 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3(const u16* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
 #include "attn_fwd_v3_body.inc"
 }
+// the same body with attention dropout (training only; three workgroups per CU: the keep words and their selects need registers)
+#define VBX_FWD_DROP
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v3_drop(const u16* __restrict__ q16, const u16* __restrict__ k16,
+                                                                  const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
+                                                                  u16* __restrict__ out, u16* __restrict__ outb,
+                                                                  float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap,
+                                                                  const unsigned* __restrict__ dbits, int W2, float rkeep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_DROP
 
 // (Round 1 wrote a "ragged tile" role for this kernel -- the 128 workgroups per launch whose query tile holds only the 16
 //  register-token rows split their KEYS over the four waves with private tiles straight from global memory.  Round 2 ran it:
@@ -1106,13 +1117,17 @@ __device__ const float attn_big_page[4] = {1e30f, 1e30f, 1e30f, 1e30f};  // L of
 #define D3_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
 #define D3_READTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
 
+// DROP (training-time attention dropout): dbits = column-major keep bits C[bh][key][W2] (ops.hip).  dV sees the dropped
+// probabilities (its 1 / keep is applied once to the accumulator), dS = P * (keep_bit * dP / keep - delta) the undropped ones.
+template <bool DROP>
 __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, const u16* __restrict__ q16,
                                                        const u16* __restrict__ qb16, const u16* __restrict__ k16,
                                                        const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                        const u16* __restrict__ dout, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, float* __restrict__ dk,
                                                        u16* __restrict__ dv, int dv_ld, int H, int Np, float scale2, float scale,
-                                                       int BH, int xmap, const QKBwd& fk) {
+                                                       int BH, int xmap, const QKBwd& fk, const unsigned* __restrict__ dbits,
+                                                       int W2, float rkeep) {
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const AttnCoord co = attn_coord_id(wg_id, H, Np, BH, xmap);
@@ -1193,6 +1208,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
 #pragma unroll
   for (int i = 0; i < 16; i++) { adk[0][i] = 0.f; adk[1][i] = 0.f; adv[0][i] = 0.f; adv[1][i] = 0.f; }
 
+  const unsigned* bcol = DROP ? dbits + (bh * Np + keyc) * W2 : nullptr;
+  uint2 wkeep = make_uint2(0u, 0u);  // keep bits of this lane's key against the 64 queries of the current tile
+  if (DROP) wkeep = *reinterpret_cast<const uint2*>(bcol);
   issue(0);
   // one 32-row block QB of the tile in slot SO (both compile time)
   auto block = [&](auto so_c, auto qb_c) {
@@ -1244,10 +1262,22 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
       D3_READ128(d4[2], sa, SO + QB * 128 + 320); D3_READ128(d4[3], sa, SO + QB * 128 + 352);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DROP) {
+        const unsigned wk = (QB ? wkeep.y : wkeep.x) >> (4 * hi);  // register 4 * g4 + j <-> query 8 * g4 + 4 * hi + j of the block
 #pragma unroll
-      for (int g4 = 0; g4 < 4; g4++)
+        for (int g4 = 0; g4 < 4; g4++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) dp[4 * g4 + j] = s[4 * g4 + j] * (dp[4 * g4 + j] - d4[g4][j]);
+          for (int j = 0; j < 4; j++) {
+            const bool keep = (wk >> (8 * g4 + j)) & 1u;
+            dp[4 * g4 + j] = s[4 * g4 + j] * ((keep ? dp[4 * g4 + j] * rkeep : 0.f) - d4[g4][j]);
+            if (!keep) s[4 * g4 + j] = 0.f;
+          }
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) dp[4 * g4 + j] = s[4 * g4 + j] * (dp[4 * g4 + j] - d4[g4][j]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     bf16x8 pf[2], dsf[2];
@@ -1305,6 +1335,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
     if (!active) return;
     block(so_c, std::integral_constant<int, 0>{});
     if (qt * 64 + 32 < Np) block(so_c, std::integral_constant<int, 1>{});
+    if (DROP && qt + 1 < ntiles) wkeep = *reinterpret_cast<const uint2*>(bcol + 2 * (qt + 1));  // retired by the next step's vmcnt(0)
   };
   for (int qt = 0; qt < ntiles; qt += 2) {
     step(std::integral_constant<int, 0>{}, qt);
@@ -1316,6 +1347,10 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
   if (active && !kvalid) {  // out-of-range or masked key: its softmax weight is 0 for every query
 #pragma unroll
     for (int e = 0; e < 16; e++) { adk[0][e] = 0.f; adk[1][e] = 0.f; adv[0][e] = 0.f; adv[1][e] = 0.f; }
+  }
+  if constexpr (DROP) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) { adv[0][e] *= rkeep; adv[1][e] *= rkeep; }
   }
   if (fk.dqkv)  // fused rotary + qk-norm backward of dk (all waves: it ends with workgroup barriers)
     store_rows_qknorm(smem + wave * 12288, reinterpret_cast<float*>(smem + 4 * 12288), adk, scale, fk, active, b, h, H, co.tile,
@@ -1349,13 +1384,16 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
 // v1's decomposition (4 waves x 32 queries, 64-key tiles of K16 | Kb | V) with LDS-DMA staging and asm fragment reads: no staging
 // registers -> three workgroups per CU.  Key masks (user mask / keys past Np) are applied per element only in tiles that need them,
 // exactly as the forward does.
+// DROP: dbits = row-major keep bits R[bh][q][W2], as in the forward.
 constexpr int Q3_SLOT = 3 * TILE16;
+template <bool DROP>
 __device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, int wg_id, const u16* __restrict__ q16,
                                                      const u16* __restrict__ k16, const u16* __restrict__ kb16,
                                                      const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
                                                      const u16* __restrict__ dout, const float* __restrict__ lse,
                                                      const float* __restrict__ delta, float* __restrict__ dq, int H, int Np,
-                                                     float scale2, float scale, int BH, int xmap, const QKBwd& fq) {
+                                                     float scale2, float scale, int BH, int xmap, const QKBwd& fq,
+                                                     const unsigned* __restrict__ dbits, int W2, float rkeep) {
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const AttnCoord co = attn_coord_id(wg_id, H, Np, BH, xmap);
@@ -1387,6 +1425,9 @@ __device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, int wg_id, cons
     asm volatile("" ::"v"(dof[t]));
   }
   asm volatile("" ::"v"(L2), "v"(dlt));
+  const unsigned* brow = DROP ? dbits + (bh * Np + qc) * W2 : nullptr;
+  uint2 wkeep = make_uint2(0u, 0u);
+  if (DROP) wkeep = *reinterpret_cast<const uint2*>(brow);
 
   auto issue = [&](int kt) {
     char* slot = smem + (kt & 1) * Q3_SLOT;
@@ -1452,7 +1493,12 @@ __device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, int wg_id, cons
         if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
         if (!ok) pv = 0.f;
       }
-      s[r] = pv * (dp[r] - dlt);
+      if constexpr (DROP) {
+        const bool keep = (((KB ? wkeep.y : wkeep.x) >> (4 * hi)) >> (8 * (r >> 2) + (r & 3))) & 1u;
+        s[r] = pv * ((keep ? dp[r] * rkeep : 0.f) - dlt);
+      } else {
+        s[r] = pv * (dp[r] - dlt);
+      }
     }
     const bf16x8 ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1481,6 +1527,7 @@ __device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, int wg_id, cons
     const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
     block(so_c, std::integral_constant<int, 0>{}, k0, need_mask);
     if (k0 + 32 < Np) block(so_c, std::integral_constant<int, 1>{}, k0, need_mask);
+    if (DROP && kt + 1 < ntiles) wkeep = *reinterpret_cast<const uint2*>(brow + 2 * (kt + 1));  // retired by the next step's vmcnt(0)
   };
   for (int kt = 0; kt < ntiles; kt += 2) {
     step(std::integral_constant<int, 0>{}, kt);
@@ -1510,8 +1557,12 @@ struct AttnBwdArgs {
   int dv_ld, H, Np, BH, xmap, grid_one, role;
   float scale2, scale;
   QKBwd fq, fk;
+  const unsigned *bits_rm, *bits_cm;  // attention dropout keep bits (ops.hip::attn_dropout_bits_kernel), DROP instantiation only
+  int W2;
+  float rkeep;
 };
 constexpr int BWD_DMA_LDS = D3_LDS > 2 * Q3_SLOT ? D3_LDS : 2 * Q3_SLOT;
+template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int id = blockIdx.x, role;
@@ -1532,11 +1583,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs 
     }
   }
   if (role)
-    attn_bwd_dq_dma_body(smem, id, a.q16, a.k16, a.kb16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dq, a.H, a.Np, a.scale2, a.scale,
-                         a.BH, a.xmap, a.fq);
+    attn_bwd_dq_dma_body<DROP>(smem, id, a.q16, a.k16, a.kb16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dq, a.H, a.Np, a.scale2,
+                               a.scale, a.BH, a.xmap, a.fq, a.bits_rm, a.W2, a.rkeep);
   else
-    attn_bwd_dkdv_dma_body(smem, id, a.q16, a.qb16, a.k16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dk, a.dv, a.dv_ld, a.H, a.Np,
-                           a.scale2, a.scale, a.BH, a.xmap, a.fk);
+    attn_bwd_dkdv_dma_body<DROP>(smem, id, a.q16, a.qb16, a.k16, a.vv, a.mask, a.dout, a.lse, a.delta, a.dk, a.dv, a.dv_ld, a.H,
+                                 a.Np, a.scale2, a.scale, a.BH, a.xmap, a.fk, a.bits_cm, a.W2, a.rkeep);
 }
 
 #include "attn_bwd1.inc"
@@ -1554,13 +1605,24 @@ extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf 
 
 static const float LOG2E = 1.4426950408889634f;
 
-extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
-                            float* lse, int B, int H, int Np, float scale, void* stream) {
+extern "C" float vbx_dropout_keep_scale(float p);
+extern "C" int vbx_dropout_bits_words(int Np);
+
+static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
+                         float* lse, int B, int H, int Np, float scale, const void* drop_bits_rm, float drop_p, void* stream) {
   VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
   static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;  // 0: A/B against the plain tile order
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
+  if (drop_bits_rm) {  // training-time attention dropout (attend.py:131): the 4-per-CU body with the keep-bit selects
+    VBX_REQUIRE(drop_p > 0.f && drop_p < 1.f, "vbx_attn_fwd_dropout: p must be in (0, 1)");
+    hipLaunchKernelGGL(attn_fwd_kernel_v3_drop, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16,
+                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap,
+                       (const unsigned*)drop_bits_rm, vbx_dropout_bits_words(Np), vbx_dropout_keep_scale(drop_p));
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
@@ -1595,6 +1657,15 @@ extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, con
   VBX_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
+                            float* lse, int B, int H, int Np, float scale, void* stream) {
+  return attn_fwd_impl(q16, k16, v, mask, out, out_bf16, lse, B, H, Np, scale, nullptr, 0.f, stream);
+}
+extern "C" int vbx_attn_fwd_dropout(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
+                                    float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p, void* stream) {
+  VBX_REQUIRE(bits_rm, "vbx_attn_fwd_dropout: null keep bits");
+  return attn_fwd_impl(q16, k16, v, mask, out, out_bf16, lse, B, H, Np, scale, bits_rm, p, stream);
+}
 
 // Backward variant: 0 = automatic, 1 = the two-body kernel (round 2), 2 = the one-pass chain kernel (round 3; needs scratch).
 // Automatic = two-body: measured on MI355X at the benchmark grid the one-pass kernel is correct and deterministic but SLOWER
@@ -1624,14 +1695,20 @@ static int attn_xcds() {  // XCC ids the one-pass kernel folds its queues over: 
   return nx;
 }
 
+struct AttnDrop {  // training-time attention dropout: keep bits in both orientations (vbx_attn_dropout_bits) and the drop probability
+  const unsigned *rm = nullptr, *cm = nullptr;
+  float p = 0.f;
+};
 static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
                          const void* out, int out_is_f16, const void* dout, const float* lse, float* delta, float* dq, float* dk,
                          void* dv, int dv_ld, int B, int H, int Np, float scale, const QKBwd& fq, const QKBwd& fk, void* scratch,
-                         void* stream) {
+                         const AttnDrop& drop, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
-  bool onepass = scratch && g_attn_bwd_variant == 2;
-  VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
+  const bool dropout = drop.rm != nullptr;
+  VBX_REQUIRE(!dropout || (drop.cm && drop.p > 0.f && drop.p < 1.f), "vbx_attn_bwd_dropout: needs both keep-bit arrays and p in (0, 1)");
+  bool onepass = scratch && g_attn_bwd_variant == 2 && !dropout;  // dropout runs on the two-body kernel
+  VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch || dropout, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
   if (onepass) {  // its flags carry a per-launch epoch passed by value: a captured launch would replay a stale one
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) onepass = false;
@@ -1643,7 +1720,8 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     attr = true;
   }
   const long chunks = (long)B * Np * H * 8;
@@ -1673,20 +1751,23 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
   // VBX_ATTN_BWD_DMA: 0 = round-1 kernels (register-staged tiles, two launches); 1 / 2 = only dq / only dk,dv on the LDS-DMA ring
   // (separate launches); 3 = both on the ring, separate launches; 4 = both in ONE launch.
-  static const int bwd_dma = getenv("VBX_ATTN_BWD_DMA") ? atoi(getenv("VBX_ATTN_BWD_DMA")) : 4;
+  static const int bwd_dma_env = getenv("VBX_ATTN_BWD_DMA") ? atoi(getenv("VBX_ATTN_BWD_DMA")) : 4;
+  const int bwd_dma = dropout ? 4 : bwd_dma_env;
   AttnBwdArgs a;
+  a.bits_rm = drop.rm; a.bits_cm = drop.cm; a.W2 = vbx_dropout_bits_words(Np); a.rkeep = dropout ? vbx_dropout_keep_scale(drop.p) : 1.f;
   a.q16 = (const u16*)q16; a.k16 = (const u16*)k16; a.qb16 = (const u16*)qb; a.kb16 = (const u16*)kb; a.vv = (const u16*)v;
   a.dout = (const u16*)dout; a.mask = mask; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = (u16*)dv; a.dv_ld = dv_ld;
   a.H = H; a.Np = Np; a.BH = BH; a.xmap = xmap; a.grid_one = (int)grid.x; a.scale2 = scale * LOG2E; a.scale = scale; a.fq = fq; a.fk = fk;
   if (bwd_dma == 4) {
     a.role = 0;
-    hipLaunchKernelGGL(attn_bwd_kernel_dma, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+    if (dropout) hipLaunchKernelGGL(attn_bwd_kernel_dma<true>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
     VBX_LAUNCH_CHECK();
     return 0;
   }
   if (bwd_dma & 1) {
     a.role = 1;
-    hipLaunchKernelGGL(attn_bwd_kernel_dma, grid, dim3(256), BWD_DMA_LDS, st, a);
+    hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, grid, dim3(256), BWD_DMA_LDS, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
                        (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap, fq);
@@ -1694,7 +1775,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   VBX_LAUNCH_CHECK();
   if (bwd_dma & 2) {
     a.role = 2;
-    hipLaunchKernelGGL(attn_bwd_kernel_dma, grid, dim3(256), BWD_DMA_LDS, st, a);
+    hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, grid, dim3(256), BWD_DMA_LDS, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
                        (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
@@ -1712,7 +1793,17 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
   const QKBwd none{};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
-                       scratch, stream);
+                       scratch, AttnDrop{}, stream);
+}
+extern "C" int vbx_attn_bwd_dropout(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                                    const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
+                                    float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
+                                    const void* bits_rm, const void* bits_cm, float p, void* stream) {
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv && bits_rm && bits_cm, "vbx_attn_bwd_dropout: null pointer");
+  VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd_dropout: bad dims (dv_ld must be a multiple of 8)");
+  const QKBwd none{};
+  return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
+                       nullptr, AttnDrop{(const unsigned*)bits_rm, (const unsigned*)bits_cm, p}, stream);
 }
 
 extern "C" int vbx_attn_bwd_fused_tiles(int Np) { return cdiv(Np, 128); }
@@ -1722,6 +1813,15 @@ extern "C" int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* 
                                   float* delta, const float* q_rnorm, const float* k_rnorm, const float* q_gamma,
                                   const float* k_gamma, const float* rot_cos, const float* rot_sin, float qk_scale, void* dqkv,
                                   int ld, float* gpart, int B, int H, int Np, float scale, void* scratch, void* stream) {
+  return vbx_attn_bwd_fused_dropout(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, q_rnorm, k_rnorm, q_gamma, k_gamma,
+                                    rot_cos, rot_sin, qk_scale, dqkv, ld, gpart, B, H, Np, scale, scratch, nullptr, nullptr, 0.f, stream);
+}
+extern "C" int vbx_attn_bwd_fused_dropout(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
+                                          const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
+                                          float* delta, const float* q_rnorm, const float* k_rnorm, const float* q_gamma,
+                                          const float* k_gamma, const float* rot_cos, const float* rot_sin, float qk_scale,
+                                          void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* scratch,
+                                          const void* bits_rm, const void* bits_cm, float p, void* stream) {
   VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dqkv && rot_cos && rot_sin, "vbx_attn_bwd_fused: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && ld % 8 == 0 && ld >= 3 * H * 64, "vbx_attn_bwd_fused: bad dims");
   VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma && gpart), "vbx_attn_bwd_fused: qk-norm needs norms, gammas, gpart");
@@ -1730,5 +1830,5 @@ extern "C" int vbx_attn_bwd_fused(const void* q16, const void* k16, const void* 
   QKBwd fk{(const u16*)k16, k_rnorm, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, I,
            gpart ? gpart + (size_t)B * tiles * H * 64 : nullptr};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, nullptr, nullptr, (u16*)dqkv + 2 * I, ld, B, H, Np,
-                       scale, fq, fk, scratch, stream);
+                       scale, fq, fk, scratch, AttnDrop{(const unsigned*)bits_rm, (const unsigned*)bits_cm, p}, stream);
 }

@@ -76,6 +76,40 @@ VBX_DEV void stagger_wait(int slot, int ticks) {
   }
 }
 
+// ---- dropout: Philox4x32-10 (Salmon et al., SC'11), the counter-based generator torch / JAX dropout use --------------------------
+// One call = 128 random bits = EIGHT 16-bit lots: element e of a call is kept iff lot_e < thr16, thr16 = round(keep * 65536)
+// (<= 65535), so the kept fraction is thr16 / 65536 and the survivors are scaled by 65536 / thr16 -- exactly unbiased.
+//   attention   element (bh, q, key):  counter = (4 * (key / 32) + (key % 32) / 8, q, bh, stream),  lot e = key % 8
+//   feed-forward element (row, col):   counter = (col / 8, row, 0, stream),                       lot e = col % 8
+// key = the 64-bit seed of this forward; stream = 2 * layer (attention) / 2 * layer + 1 (FeedForward).  The mask is a pure
+// function of (seed, stream, index): backward recomputes or reloads it, nothing depends on launch geometry.
+struct Philox4 { unsigned x, y, z, w; };
+VBX_DEV Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// the 8 keep bits of one call (bit e = lot e kept)
+VBX_DEV unsigned philox_keep8(const Philox4& r, unsigned thr16) {
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+  unsigned bits = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    bits |= ((w[i] & 0xFFFFu) < thr16 ? 1u : 0u) << (2 * i);
+    bits |= ((w[i] >> 16) < thr16 ? 1u : 0u) << (2 * i + 1);
+  }
+  return bits;
+}
+static inline unsigned dropout_thr16(float p) {  // host: keep threshold of a drop probability p in (0, 1)
+  long t = (long)((1.0 - (double)p) * 65536.0 + 0.5);
+  return (unsigned)(t < 1 ? 1 : (t > 65535 ? 65535 : t));
+}
+
 // ---- wave64 reductions ----------------------------------------------------------------------
 VBX_DEV float wave_sum(float v) {
 #pragma unroll

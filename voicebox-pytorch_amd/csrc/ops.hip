@@ -1636,3 +1636,102 @@ extern "C" int vbx_probe_mfma(int which, const float* a, const float* b, float* 
   VBX_LAUNCH_CHECK();
   return 0;
 }
+
+// ============================================================================ dropout (attend.py:131, voicebox_pytorch.py:346)
+// Training-time dropout of the attention probabilities and of the GEGLU output.  The mask is a pure function of
+// (seed, stream, element index) through Philox4x32-10 (common.hpp): nothing is drawn from a stateful generator on the device.
+namespace {
+
+// Attention keep bits of one layer, in BOTH orientations the attention kernels read them in:
+//   R[bh][q][W2]    bit (key % 32) of word key / 32  -- forward and the dq body: a lane owns one query, its registers 32 keys
+//   C[bh][key][W2]  bit (q % 32)   of word q / 32    -- the dk/dv body: a lane owns one key, its registers 32 queries
+// W2 = 2 * ceil(Np / 64) words per row (even, so a 64-wide tile's two words are one aligned 8-byte load); bits past Np are 0.
+// One workgroup = 64 queries of one head; wave w walks the key words w, w + 4, ...; a lane draws the 32 keys of its query
+// (4 Philox calls) and the wave transposes the 64 x 32 bit block with 32 ballots.
+__global__ __launch_bounds__(256) void attn_dropout_bits_kernel(unsigned* __restrict__ R, unsigned* __restrict__ C, int Np, int W2,
+                                                                unsigned k0, unsigned k1, unsigned stream_id, unsigned thr16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane, bh = blockIdx.y;
+  for (int kw = wave; kw < W2; kw += 4) {
+    unsigned word = 0;
+    const int valid = Np - kw * 32;
+    if (q < Np && valid > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        word |= philox_keep8(philox4x32_10((unsigned)(kw * 4 + i), (unsigned)q, (unsigned)bh, stream_id, k0, k1), thr16) << (8 * i);
+      if (valid < 32) word &= (1u << valid) - 1u;
+    }
+    if (q < Np) R[((long)bh * Np + q) * W2 + kw] = word;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      const unsigned long long m = __ballot((word >> j) & 1u);
+      if (lane == j) mine = m;
+    }
+    const int key = kw * 32 + lane;
+    if (lane < 32 && key < Np)
+      *reinterpret_cast<uint2*>(C + ((long)bh * Np + key) * W2 + blockIdx.x * 2) = make_uint2((unsigned)mine, (unsigned)(mine >> 32));
+  }
+}
+
+// In-place dropout of a [rows, cols] 16-bit matrix (row stride ld) held as an fp16 copy and / or a bf16 copy: 8 elements
+// (one Philox call, one 16-byte access per copy) per thread.  cols, ld multiples of 8.
+__global__ __launch_bounds__(256) void dropout_rows_kernel(u16* __restrict__ xh, u16* __restrict__ xb, long rows, int cols, int ld,
+                                                           unsigned k0, unsigned k1, unsigned stream_id, unsigned thr16, float rkeep) {
+  const int c8 = cols >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * c8) return;
+  const long row = idx / c8;
+  const int cb = (int)(idx - row * c8);
+  const unsigned keep = philox_keep8(philox4x32_10((unsigned)cb, (unsigned)row, (unsigned)(row >> 32), stream_id, k0, k1), thr16);
+  const long off = row * ld + cb * 8;
+  if (xh) {
+    uint4 v = *reinterpret_cast<const uint4*>(xh + off);
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float lo = ((keep >> (2 * i)) & 1u) ? f16_to_f32((u16)(w[i] & 0xFFFFu)) * rkeep : 0.f;
+      const float hi = ((keep >> (2 * i + 1)) & 1u) ? f16_to_f32((u16)(w[i] >> 16)) * rkeep : 0.f;
+      w[i] = pack_f16x2_sat(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(xh + off) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  if (xb) {
+    uint4 v = *reinterpret_cast<const uint4*>(xb + off);
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float lo = ((keep >> (2 * i)) & 1u) ? bf16_to_f32((u16)(w[i] & 0xFFFFu)) * rkeep : 0.f;
+      const float hi = ((keep >> (2 * i + 1)) & 1u) ? bf16_to_f32((u16)(w[i] >> 16)) * rkeep : 0.f;
+      w[i] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(xb + off) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vbx_dropout_bits_words(int Np) { return Np > 0 ? 2 * cdiv(Np, 64) : 0; }
+
+extern "C" int vbx_attn_dropout_bits(void* bits_rm, void* bits_cm, int BH, int Np, unsigned long long seed, unsigned stream_id,
+                                     float p, void* stream) {
+  VBX_REQUIRE(bits_rm && bits_cm && BH > 0 && BH <= 65535 && Np > 0, "vbx_attn_dropout_bits: bad args");
+  VBX_REQUIRE(p > 0.f && p < 1.f, "vbx_attn_dropout_bits: p must be in (0, 1)");
+  hipLaunchKernelGGL(attn_dropout_bits_kernel, dim3(cdiv(Np, 64), BH), dim3(256), 0, ST, (unsigned*)bits_rm, (unsigned*)bits_cm, Np,
+                     vbx_dropout_bits_words(Np), (unsigned)seed, (unsigned)(seed >> 32), stream_id, dropout_thr16(p));
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" float vbx_dropout_keep_scale(float p) { return 65536.0f / (float)dropout_thr16(p); }
+
+extern "C" int vbx_dropout_rows(void* x_f16, void* x_bf16, long rows, int cols, int ld, unsigned long long seed, unsigned stream_id,
+                                float p, void* stream) {
+  VBX_REQUIRE((x_f16 || x_bf16) && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vbx_dropout_rows: bad args (cols, ld multiples of 8)");
+  VBX_REQUIRE(p > 0.f && p < 1.f, "vbx_dropout_rows: p must be in (0, 1)");
+  const long n = rows * (cols / 8);
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (u16*)x_f16, (u16*)x_bf16, rows, cols, ld,
+                     (unsigned)seed, (unsigned)(seed >> 32), stream_id, dropout_thr16(p), vbx_dropout_keep_scale(p));
+  VBX_LAUNCH_CHECK();
+  return 0;
+}

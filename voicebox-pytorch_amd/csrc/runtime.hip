@@ -88,6 +88,7 @@ void carve_wpack(const vbx_model* m, WPack& w) {
 struct ALayer {
   u16 *hn1, *hn1h, *q16, *k16, *qb, *kb, *v, *vh, *o, *oh, *hn2, *hn2h, *h1, *g, *gh;
   float *qrn, *krn, *lse;
+  unsigned *dbr = nullptr, *dbc = nullptr;  // attention dropout keep bits, row- / column-major (training with attn_dropout > 0)
   // GateLoop: normed input (bf16 | fp16), projection q|kv|a, scan state h, scan output s
   u16 *hg, *hgh;
   float *glp, *glh, *gls;
@@ -212,6 +213,11 @@ void carve_acts(const vbx_model* m, Acts& a) {
       y.h1 = tr ? c.take<u16>((size_t)d.M * 2 * d.Fp) : nullptr;
       y.g = tr ? c.take<u16>((size_t)d.M * d.Fp) : nullptr;
       y.gh = c.take<u16>((size_t)d.M * d.Fp);
+      if (m->attn_dropout > 0.f) {
+        const size_t words = (size_t)d.B * d.H * d.Np * vbx_dropout_bits_words(d.Np);
+        y.dbr = c.take<unsigned>(words);
+        y.dbc = c.take<unsigned>(words);
+      }
       if (m->gateloop) {
         y.hg = tr ? c.take<u16>((size_t)d.M * d.D) : nullptr;
         y.hgh = c.take<u16>((size_t)d.M * d.D);
@@ -339,6 +345,7 @@ int check_model(const vbx_model* m) {
                 "vbx_model: GateLoop post-LayerNorm weight and bias of layer %d are not contiguous", l);
   }
   VBX_REQUIRE(!m->plain_norm || m->stack_only, "vbx_model: plain_norm is only used by the standalone stack (VoiceBox is adaptive)");
+  VBX_REQUIRE(m->attn_dropout >= 0.f && m->attn_dropout < 1.f && m->ff_dropout >= 0.f && m->ff_dropout < 1.f, "vbx_model: dropout must be in [0, 1)");
   return 0;
 }
 
@@ -579,8 +586,16 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     g.rot_cos = m->rot_cos; g.rot_sin = m->rot_sin;
     g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.v16 = y.vh; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
     { ProfScope ps("fwd to_qkv", st); CK(vbx_gemm(&g, stream)); }
-    { ProfScope ps("fwd attention", st);
-      CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream)); }
+    const bool drop_on = io->dropout != 0;
+    if (y.dbr && drop_on) {  // attend.py:131: keep bits of this layer, kept in the arena for the backward
+      CK(vbx_attn_dropout_bits(y.dbr, y.dbc, d.B * d.H, d.Np, io->drop_seed, 2u * l, m->attn_dropout, stream));
+      ProfScope ps("fwd attention", st);
+      CK(vbx_attn_fwd_dropout(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, y.dbr,
+                              m->attn_dropout, stream));
+    } else {
+      ProfScope ps("fwd attention", st);
+      CK(vbx_attn_fwd(y.q16, y.k16, y.vh, io->attn_mask_p, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
+    }
     { ProfScope ps("fwd to_out", st);
       CK(gemm_nt(y.oh, d.I, w.layer[l].outh, d.I, (int)d.M, d.D, d.I, VBX_EPI_F32, x_mid, d.D, nullptr, x_in, nullptr, nullptr, st)); }
     // ff_prenorm -> FeedForward (GEGLU) + residual   (:471-472, :337-349)
@@ -589,6 +604,8 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     { ProfScope ps("fwd ff_in", st);
       CK(gemm_nt(y.hn2h, d.D, w.layer[l].w1h, d.D, (int)d.M, 2 * d.Fp, d.D, VBX_EPI_GEGLU, y.gh, d.Fp, w.layer[l].b1, nullptr,
                  tr ? y.h1 : nullptr, y.g, st)); }
+    if (drop_on && m->ff_dropout > 0.f)  // nn.Dropout between GEGLU and the output projection (:346): both copies of the GEGLU output
+      CK(vbx_dropout_rows(y.gh, tr ? y.g : nullptr, d.M, d.Fp, d.Fp, io->drop_seed, 2u * l + 1u, m->ff_dropout, stream));
     { ProfScope ps("fwd ff_out", st);
       CK(gemm_nt(y.gh, d.Fp, w.layer[l].w2h, d.Fp, (int)d.M, d.D, d.Fp, VBX_EPI_F32, x_out, d.D, P + o[VBX_L_FF2B], x_mid, nullptr,
                  nullptr, st)); }
@@ -673,6 +690,10 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   // ---- FeedForward
   { ProfScope ps("dgrad ff_out", st); CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st)); }
   CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp, gs));
+  VBX_REQUIRE(io || !(m->ff_dropout > 0.f || m->attn_dropout > 0.f), "vbx_model_backward_layer: a model with dropout needs the forward's io");
+  const bool drop_on = io && io->dropout != 0;
+  if (drop_on && m->ff_dropout > 0.f)  // the same mask on the gradient of the GEGLU output
+    CK(vbx_dropout_rows(nullptr, a.dg, d.M, d.Fp, d.Fp, io->drop_seed, 2u * l + 1u, m->ff_dropout, stream));
   if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
     CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
   } else {
@@ -701,17 +722,22 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     ProfScope ps("bwd attention", st);
-    CK(vbx_attn_bwd_fused(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn, y.krn,
-                          m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin,
-                          m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
+    CK(vbx_attn_bwd_fused_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn,
+                                  y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos,
+                                  m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale,
+                                  a.attn_scratch, drop_on ? y.dbr : nullptr, y.dbc, m->attn_dropout, stream));
     if (m->qk_norm && !batched) {
       const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
       CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
       CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
     }
   } else {
-  CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
-                    a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
+    if (y.dbr && drop_on)
+      CK(vbx_attn_bwd_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
+                              a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, y.dbr, y.dbc, m->attn_dropout, stream));
+    else
+      CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
+                      a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                            m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
                            3 * d.I, a.gpart, d.B, d.H, d.Np, stream));

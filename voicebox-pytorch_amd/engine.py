@@ -20,13 +20,13 @@ class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
-                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I)]
+                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F)]
 
 
 class VbxIO(C.Structure):
     _fields_ = [("x", P), ("cond", P), ("cond_mask", P), ("attn_mask", P), ("attn_mask_p", P), ("loss_mask", P),
                 ("times", P), ("target", P), ("pred", P), ("loss", P), ("cond_ids", P), ("T", I), ("null_id", C.c_long),
-                ("drop_mask", P), ("null_cond", P), ("dx", P), ("dcond", P)]
+                ("drop_mask", P), ("null_cond", P), ("dx", P), ("dcond", P), ("dropout", I), ("drop_seed", C.c_ulonglong)]
 
 
 class VbxAdamSeg(C.Structure):
@@ -208,6 +208,10 @@ class Engine:
         m.stack_only = 1 if cfg.get("stack_only") else 0
         m.E, m.V1 = int(cfg.get("E", 0)), int(cfg.get("V1", 0))
         m.plain_norm = 1 if cfg.get("plain_norm") else 0
+        m.attn_dropout = float(cfg.get("attn_dropout", 0.))
+        m.ff_dropout = float(cfg.get("ff_dropout", 0.))
+        self.has_dropout = m.attn_dropout > 0. or m.ff_dropout > 0.
+        self.dropout_active = False  # nn.Dropout semantics: the owning module sets this to its .training flag before a forward
         self.off_table = flat.offset_table()
         m.off = C.cast(self.off_table, P)
         self.rot_cos, self.rot_sin = rotary_tables(N, cfg["R"], 64, cfg["theta"], device)
@@ -301,8 +305,17 @@ class Engine:
             text = (ids, drop8, null_cond)
         self._keep = (x, cond, cm, am, amp, lm, times, target, pred, text)  # keep inputs alive until backward
         self.generation += 1
+        self._draw_dropout_seed()
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
         return self.loss if target is not None else pred
+
+    def _draw_dropout_seed(self):
+        """One Philox key per training forward, drawn from torch's CPU generator (so torch.manual_seed reproduces a run); the
+        backward calls reuse it through self.io (masks are a pure function of seed, layer and element index)."""
+        self.io.dropout = 0
+        if self.has_dropout and self.dropout_active:
+            self.io.dropout = 1
+            self.io.drop_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     # -- standalone Transformer.forward / backward (vbx_model.stack_only)
     def forward_stack(self, x, cond=None, attn_mask=None):
@@ -324,6 +337,7 @@ class Engine:
         io.pred = out.data_ptr()
         self._keep = (x, cond, am, amp, out)
         self.generation += 1
+        self._draw_dropout_seed()
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
         return out
 

@@ -27,9 +27,19 @@ def default(v, d):
 
 
 # --------------------------------------------------------------------------------------- Attend
+def attn_dropout_bits(B, H, Np, p, seed, stream_id, device):
+    """Keep bits of one attention call in the two orientations the kernels read (vbx_attn_dropout_bits): int32 tensors
+    [B*H, Np, W] row-major (bit key % 32 of word key // 32) and column-major (bit q % 32 of word q // 32)."""
+    W = _lib.lib().vbx_dropout_bits_words(Np)
+    rm = torch.empty(B * H, Np, W, dtype=torch.int32, device=device)
+    cm = torch.empty_like(rm)
+    _lib.call("vbx_attn_dropout_bits", rm, cm, B * H, Np, int(seed), int(stream_id), float(p), _lib.current_stream())
+    return rm, cm
+
+
 class _AttendFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale):
+    def forward(ctx, q, k, v, mask, scale, drop_p=0., drop_seed=0):
         B, H, Np, dh = q.shape
         dev = q.device
         q16, k16 = q.to(torch.float16).contiguous(), k.to(torch.float16).contiguous()
@@ -38,14 +48,21 @@ class _AttendFn(torch.autograd.Function):
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
         out16 = torch.empty(B, Np, H * 64, dtype=torch.float16, device=dev)
         lse = torch.empty(B, H, Np, dtype=torch.float32, device=dev)
-        _lib.call("vbx_attn_fwd", q16, k16, v16, m8, out16, None, lse, B, H, Np, float(scale), _lib.current_stream())
-        ctx.save_for_backward(q16, k16, vb, out16, lse, m8 if m8 is not None else torch.empty(0, device=dev))
-        ctx.has_mask, ctx.scale, ctx.in_dtype = m8 is not None, float(scale), q.dtype
+        none = torch.empty(0, device=dev)
+        rm = cm = none
+        if drop_p > 0.:  # attend.py:131 -- the keep bits are saved for the backward (1 bit per score, both orientations)
+            rm, cm = attn_dropout_bits(B, H, Np, drop_p, drop_seed, 0, dev)
+            _lib.call("vbx_attn_fwd_dropout", q16, k16, v16, m8, out16, None, lse, B, H, Np, float(scale), rm, float(drop_p),
+                      _lib.current_stream())
+        else:
+            _lib.call("vbx_attn_fwd", q16, k16, v16, m8, out16, None, lse, B, H, Np, float(scale), _lib.current_stream())
+        ctx.save_for_backward(q16, k16, vb, out16, lse, m8 if m8 is not None else none, rm, cm)
+        ctx.has_mask, ctx.scale, ctx.in_dtype, ctx.drop_p = m8 is not None, float(scale), q.dtype, float(drop_p)
         return out16.view(B, Np, H, 64).permute(0, 2, 1, 3).to(q.dtype)
 
     @staticmethod
     def backward(ctx, dout):
-        q16, k16, vb, out, lse, m8 = ctx.saved_tensors
+        q16, k16, vb, out, lse, m8, rm, cm = ctx.saved_tensors
         B, H, Np, _ = q16.shape
         dev = q16.device
         do = dout.permute(0, 2, 1, 3).reshape(B, Np, H * 64).to(torch.bfloat16).contiguous()
@@ -54,11 +71,15 @@ class _AttendFn(torch.autograd.Function):
         dq = torch.empty(B, H, Np, 64, dtype=torch.float32, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
-        scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward
-        _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
-                  H * 64, B, H, Np, ctx.scale, scratch, _lib.current_stream())
+        if ctx.drop_p > 0.:
+            _lib.call("vbx_attn_bwd_dropout", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
+                      H * 64, B, H, Np, ctx.scale, rm, cm, ctx.drop_p, _lib.current_stream())
+        else:
+            scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward
+            _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
+                      H * 64, B, H, Np, ctx.scale, scratch, _lib.current_stream())
         dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
-        return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None
+        return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None, None, None
 
 
 class Attend(nn.Module):
@@ -67,9 +88,10 @@ class Attend(nn.Module):
 
     def __init__(self, dropout=0., flash=False, scale=None):
         super().__init__()
-        if dropout != 0.:
-            raise NotImplementedError("attention dropout > 0 is not implemented in the HIP path")
+        assert 0. <= dropout < 1.
         self.dropout, self.flash, self.scale = dropout, flash, scale
+        self.attn_dropout = nn.Dropout(dropout)  # attend.py:49: a parameter-free holder; the mask is drawn inside the kernels
+        self.last_dropout_seed = None
 
     def forward(self, q, k, v, mask=None):
         if q.shape[-1] != 64:
@@ -77,6 +99,9 @@ class Attend(nn.Module):
         if exists(mask) and mask.ndim != 2:
             raise NotImplementedError("only (batch, keys) key-padding masks are supported")
         scale = default(self.scale, q.shape[-1] ** -0.5)
+        if self.training and self.dropout > 0.:  # one Philox key per call from torch's CPU generator (torch.manual_seed reproduces it)
+            self.last_dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            return _AttendFn.apply(q, k, v, mask, scale, float(self.dropout), self.last_dropout_seed)
         return _AttendFn.apply(q, k, v, mask, scale)
 
 
@@ -150,9 +175,8 @@ class GEGLU(nn.Module):  # voicebox_pytorch.py:337-340 (fused into the FF-in GEM
     pass
 
 
-def FeedForward(dim, mult=4, dropout=0.):  # voicebox_pytorch.py:342-349
-    if dropout != 0.:
-        raise NotImplementedError("feed-forward dropout > 0 is not implemented in the HIP path")
+def FeedForward(dim, mult=4, dropout=0.):  # voicebox_pytorch.py:342-349 (parameter holder; the dropout runs in the stage runtime)
+    assert 0. <= dropout < 1.
     dim_inner = int(dim * mult * 2 / 3)
     return nn.Sequential(nn.Linear(dim, dim_inner * 2), GEGLU(), nn.Dropout(dropout), nn.Linear(dim_inner, dim))
 
@@ -220,7 +244,8 @@ class Transformer(nn.Module):
         self._cfg = dict(D=dim, H=heads, L=depth, F=int(dim * ff_mult * 2 / 3), Th=cond_dim if adaptive_rmsnorm else 8,
                          R=int(num_register_tokens), ksize=31, qk_norm=bool(attn_qk_norm),
                          attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
-                         gateloop=bool(use_gateloop_layers), stack_only=True, plain_norm=not adaptive_rmsnorm)
+                         gateloop=bool(use_gateloop_layers), stack_only=True, plain_norm=not adaptive_rmsnorm,
+                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout))
         self._flat = None
         self._engines = {}
         norm = (lambda: AdaptiveRMSNorm(dim, cond_dim=adaptive_rmsnorm_cond_dim_in)) if adaptive_rmsnorm else (lambda: RMSNorm(dim))
@@ -293,6 +318,7 @@ class Transformer(nn.Module):
                 self._engines.pop(next(iter(self._engines)))
             eng = Engine(self._cfg, fp, B, N, training, dev)
             self._engines[key] = eng
+        eng.dropout_active = self.training  # nn.Dropout: the module's mode, not the autograd mode
         x32 = x.to(dev, torch.float32)
         c32 = adaptive_rmsnorm_cond.to(dev, torch.float32) if exists(adaptive_rmsnorm_cond) else None
         if exists(c32):
@@ -387,7 +413,8 @@ class VoiceBox(nn.Module):
                          R=int(num_register_tokens), ksize=conv_pos_embed_kernel_size, qk_norm=bool(attn_qk_norm),
                          attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
                          gateloop=bool(use_gateloop_layers), E=dim_cond_emb,
-                         V1=(num_cond_tokens + 1) if condition_on_text else 0)
+                         V1=(num_cond_tokens + 1) if condition_on_text else 0,
+                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout))
         self._flat = None
         self._engines = {}
 
@@ -438,6 +465,7 @@ class VoiceBox(nn.Module):
                     self._engines.pop(k)
             eng = Engine(self._cfg, fp, B, N, training, dev, wpack_from=wpack_from)
             self._engines[key] = eng
+        eng.dropout_active = self.training  # nn.Dropout semantics (attend.py:131, voicebox_pytorch.py:346): the module's mode
         return eng
 
     def mark_weights_dirty(self):
