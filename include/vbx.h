@@ -411,6 +411,8 @@ typedef struct {
   float attn_dropout;     /* attn_dropout (:895, attend.py:131) and ff_dropout (:891, :346) of the module: applied in a forward whose */
   float ff_dropout;       /* vbx_io.dropout != 0 (nn.Dropout: module.training), keyed by vbx_io.drop_seed; with attn_dropout > 0 the
                              arena holds the attention keep bits (per layer when training != 0, for the backward) */
+  int Din;                /* dim_in (:884,905): width of x / cond / target / pred and of null_cond; to_embed is Linear(2*Din + E, D)
+                             (:938), to_pred Linear(D, Din) (:964-966).  0 = D.  Multiple of 8. */
 } vbx_model;
 
 typedef struct {

@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -507,6 +507,49 @@ def gen_small_dropout(ref):
     print("small_dropout: loss", float(loss), "kept attn", float(keep["attn"][0].float().mean()), "ff", float(keep["ff"][0].float().mean()))
 
 
+def gen_small_dimin(ref):
+    """dim_in != dim (voicebox_pytorch.py:884,905,938,964): 80-wide data (mel bins) into a dim-64 model -- to_embed is
+    Linear(160, 64), to_pred Linear(64, 80), x / cond / target / prediction / ODE state are 80 wide.  Well-conditioned weights;
+    loss, every gradient, an eval prediction and a 5-point sample of the unmodified reference."""
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    torch.manual_seed(0)
+    vb = ref.VoiceBox(dim=64, dim_in=80, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False,
+                      num_register_tokens=cfg.num_register_tokens)
+    wrapper = ref.ConditionalFlowMatcherWrapper(voicebox=vb)
+    g = torch.Generator().manual_seed(125)
+    with torch.no_grad():
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or ".to_beta." in name:
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+            if name.endswith("final_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+            if name.endswith("q_norm.gamma") or name.endswith("k_norm.gamma"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+                prm.mul_(0.25)
+    state = {k: v.detach().clone() for k, v in vb.state_dict().items()}
+    assert state["to_embed.weight"].shape == (64, 160) and state["to_pred.weight"].shape == (80, 64) and state["null_cond"].shape == (80,)
+    b, n = 2, 40
+    x1 = torch.randn(b, n, 80, generator=torch.Generator().manual_seed(72))
+    x0, times, frac, rand = replay_draws(x1, seed=95)
+    torch.manual_seed(95)
+    loss = wrapper(x1)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in vb.named_parameters() if p.grad is not None}
+    vb.eval()
+    cond = torch.randn(b, n, 80, generator=torch.Generator().manual_seed(81))
+    tt = torch.tensor([0.25, 0.8])
+    with torch.no_grad():
+        pred = vb(x1, times=tt, cond_token_ids=None, cond=cond, cond_drop_prob=0.0)
+    torch.manual_seed(31)
+    y0 = torch.randn_like(cond)
+    torch.manual_seed(31)
+    s5 = wrapper.sample(cond=cond, steps=5)
+    torch.save(dict(cfg=dict(dim=64, depth=2, heads=2, dim_head=64), dim_in=80, state=state, x1=x1, x0=x0, times=times, frac=frac,
+                    rand=rand, loss=loss.detach(), grads=grads, cond=cond, eval_times=tt, pred=pred, y0=y0, sample5=s5),
+               os.path.join(HERE, "small_dimin.pt"))
+    print("small_dimin: loss", float(loss), "pred", tuple(pred.shape), "sample", tuple(s5.shape))
+
+
 def _wc(state):
     for k in state:
         if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
@@ -593,9 +636,9 @@ def gen_cfg5_wc_b8(ref):
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
          "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
-         "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout}[w](ref)
+         "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout, "small_dimin": gen_small_dimin}[w](ref)

@@ -109,7 +109,7 @@ def test_no_cpu_fallback(golden):
 def test_unsupported_configurations_raise():
     import voicebox_pytorch_amd as vbx
 
-    for kw in (dict(dim_head=32), dict(conv_pos_embed_kernel_size=15), dict(dim=100)):
+    for kw in (dict(dim_head=32), dict(conv_pos_embed_kernel_size=33), dict(conv_pos_embed_kernel_size=16), dict(dim=100)):
         base = dict(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
         base.update(kw)
         with pytest.raises((NotImplementedError, AssertionError)):

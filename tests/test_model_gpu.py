@@ -7,6 +7,8 @@ reference; sampled frames / predictions within the fp tolerance below (bf16 GEMM
 accumulation and residual stream, fp16 q/k for the attention logits).
 """
 import pytest
+import os
+
 import torch
 
 from oracle import restate
@@ -1049,6 +1051,82 @@ def test_training_dropout_vs_oracle_with_the_same_masks(golden):
         pt = vb(x, times=t, cond_token_ids=None, cond=cond, cond_mask=cm, cond_drop_prob=0.0)
     assert rel(pt, pe.cpu()) > 0.02
     print(f"dropout step: |dloss| {abs(float(loss) - float(ref)):.2e}, worst gradient {worst:.3%}")
+
+
+def test_conv_pos_embed_kernel_size_other_than_31():
+    """conv_pos_embed_kernel_size (voicebox_pytorch.py:893) is an argument of the reference: a model with a 15-tap positional
+    convolution against the restatement (well-conditioned qk-norm gammas), loss and every gradient."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64, conv_kernel=15)
+    state = restate.init_state_dict(cfg, seed=21)
+    state = {k: (v * 0.25 if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma") else v) for k, v in state.items()}
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False, conv_pos_embed_kernel_size=15)
+    assert vb.conv_embed.dw_conv1d[0].weight.shape == (64, 1, 15)
+    vb.load_state_dict(state, strict=False)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    gen = torch.Generator().manual_seed(22)
+    B, N = 2, 70
+    x1, x0 = torch.randn(B, N, 64, generator=gen), torch.randn(B, N, 64, generator=gen)
+    times, frac, rand = torch.rand(B, generator=gen), 0.7 + 0.3 * torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
+        loss = wrapper(x1.to(dev))
+    loss.backward()
+    p = {k: v.double().clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in state.items()}
+    ref = restate.cfm_loss(p, cfg, x1.double(), x0.double(), times.double(), frac, rand)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-3, (float(loss), float(ref))
+    for k, prm in vb.named_parameters():
+        if p[k].grad is not None:
+            assert rel(prm.grad, p[k].grad) < 0.03, (k, rel(prm.grad, p[k].grad))
+    with pytest.raises(NotImplementedError):
+        vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False, conv_pos_embed_kernel_size=33)
+
+
+def test_dim_in_other_than_dim_vs_reference(golden):
+    """dim_in != dim (voicebox_pytorch.py:884,905,938,964; e.g. 80 mel bins into a wider model): x / cond / target / prediction /
+    ODE state are dim_in wide, to_embed is Linear(2 * dim_in, dim), to_pred Linear(dim, dim_in).  Loss, every gradient, an eval
+    prediction and a 5-point sample (eager and under hipGraph) against the unmodified reference (golden small_dimin)."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small_dimin")
+    vb = vbx.VoiceBox(dim=64, dim_in=g["dim_in"], num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    assert vb.to_embed.weight.shape == (64, 160) and vb.to_pred.weight.shape == (80, 64) and vb.null_cond.shape == (80,)
+    missing = vb.load_state_dict(g["state"], strict=False)
+    assert not missing.unexpected_keys and all("inv_freq" in k for k in missing.missing_keys)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    with rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+        loss = wrapper(g["x1"].to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-3, (float(loss), float(g["loss"]))
+    named = dict(vb.named_parameters())
+    for k, ref in g["grads"].items():
+        assert rel(named[k].grad, ref) < 0.03, (k, rel(named[k].grad, ref))
+    vb.eval()
+    with torch.no_grad():
+        pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev), cond_drop_prob=0.0)
+    assert pred.shape == (2, 40, 80) and rel(pred, g["pred"]) < 0.01, rel(pred, g["pred"])
+    for graph in (False, True):
+        with rng_override(y0=g["y0"]):
+            s5 = wrapper.sample(cond=g["cond"].to(dev), steps=5, use_graph=graph)
+        assert s5.shape == (2, 40, 80) and rel(s5, g["sample5"]) < 0.02, (graph, rel(s5, g["sample5"]))
+    # one optimizer step through the fused Adam keeps the re-shaped operand copies (to_pred [80, 64], to_embed [64, 160]) in step
+    from voicebox_pytorch_amd.dp import TrainStep
+    ts = TrainStep(wrapper, lr=1e-3, max_grad_norm=0.5)
+    with rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+        ts.step(g["x1"].to(dev))
+    sd = {k: v.detach().cpu().clone() for k, v in vb.state_dict().items()}
+    vb2 = vbx.VoiceBox(dim=64, dim_in=80, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    vb2.load_state_dict(sd, strict=False)
+    vb2 = vb2.to(dev).eval()
+    vb.eval()
+    with torch.no_grad():
+        kw = dict(times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev), cond_drop_prob=0.0)
+        assert torch.equal(vb(g["x1"].to(dev), **kw), vb2(g["x1"].to(dev), **kw))
 
 
 def test_attend_module_with_dropout(golden):

@@ -703,9 +703,10 @@ def test_attn_bwd_onepass_is_deterministic_and_ignores_scratch_contents(L):
 
 
 # ----------------------------------------------------------------------------- small ops
-@pytest.mark.parametrize("masked", [False, True])
-def test_convpos_fwd_bwd(L, masked):
-    Bsz, N, R, D, ks = 2, 150, 16, 128, 31
+@pytest.mark.parametrize("masked,ks", [(False, 31), (True, 31), (True, 7), (False, 1), (True, 17), (False, 29)])
+def test_convpos_fwd_bwd(L, masked, ks):
+    """ConvPositionEmbed (voicebox_pytorch.py:203-233) at the reference's default kernel size and at other odd sizes."""
+    Bsz, N, R, D = 2, 150, 16, 128
     g = torch.Generator().manual_seed(2)
     e = torch.randn(Bsz, N, D, generator=g, dtype=torch.float64, requires_grad=True)
     w = (torch.randn(D, 1, ks, generator=g, dtype=torch.float64) * ks ** -0.5).requires_grad_(True)

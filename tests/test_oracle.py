@@ -73,6 +73,25 @@ def test_small_model_with_dropout_masks_of_the_reference(golden):
     assert abs(float(loss0) - float(g["loss"])) > 1e-3
 
 
+def test_small_model_with_dim_in_other_than_dim(golden):
+    """dim_in != dim (voicebox_pytorch.py:884,905,938,964): the restatement follows the weight shapes, so 80-wide data through a
+    dim-64 model needs no special case -- pinned on the unmodified reference's loss, gradients, prediction and 5-point sample."""
+    g = golden("small_dimin")
+    cfg = _cfg(g["cfg"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    loss = restate.cfm_loss(p, cfg, g["x1"], g["x0"], g["times"], g["frac"], g["rand"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k, ref in g["grads"].items():
+        assert torch.allclose(p[k].grad, ref, rtol=2e-3, atol=2e-6), (k, float((p[k].grad - ref).abs().max()))
+    with torch.no_grad():
+        ones = torch.ones(g["x1"].shape[:2], dtype=torch.bool)
+        pred = restate.voicebox_forward(g["state"], cfg, g["x1"], g["eval_times"], g["cond"], ones)
+        assert pred.shape[-1] == 80 and torch.allclose(pred, g["pred"], rtol=1e-4, atol=1e-5)
+        s5 = restate.sample_midpoint(g["state"], cfg, g["y0"], 5, cond=g["cond"])
+        assert torch.allclose(s5, g["sample5"], rtol=1e-3, atol=1e-4), float((s5 - g["sample5"]).abs().max())
+
+
 def test_small_model_eval_and_sample(golden):
     g = golden("small")
     cfg = _cfg(g["cfg"])

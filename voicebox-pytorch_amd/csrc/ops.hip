@@ -1291,14 +1291,28 @@ extern "C" int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, 
   return 0;
 }
 
+// The tap loops are fully unrolled over a compile-time kernel size (the weights live in registers): one instantiation per odd
+// size up to 31 (the reference default, voicebox_pytorch.py:893; ConvPositionEmbed asserts an odd size, :211).
+#define VBX_CONV_KS_SWITCH(ks, CALL)                                                                                      \
+  switch (ks) {                                                                                                           \
+    case 1: CALL(1); break;   case 3: CALL(3); break;   case 5: CALL(5); break;   case 7: CALL(7); break;                 \
+    case 9: CALL(9); break;   case 11: CALL(11); break; case 13: CALL(13); break; case 15: CALL(15); break;               \
+    case 17: CALL(17); break; case 19: CALL(19); break; case 21: CALL(21); break; case 23: CALL(23); break;               \
+    case 25: CALL(25); break; case 27: CALL(27); break; case 29: CALL(29); break; default: CALL(31); break;               \
+  }
+static inline bool conv_ks_ok(int ks) { return ks >= 1 && ks <= 31 && (ks & 1); }
+
 extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
                                float* xs, int B, int N, int R, int D, int ksize, void* stream) {
   VBX_REQUIRE(e && w && bias && xs, "vbx_convpos_fwd: null pointer");
-  VBX_REQUIRE(ksize == 31, "vbx_convpos_fwd: only conv_pos_embed_kernel_size == 31 is built (got %d)", ksize);
+  VBX_REQUIRE(conv_ks_ok(ksize), "vbx_convpos_fwd: conv_pos_embed_kernel_size must be odd and <= 31 (got %d)", ksize);
   VBX_REQUIRE(R == 0 || reg, "vbx_convpos_fwd: register tokens missing");
   dim3 grid(cdiv(N, CT), cdiv(D, 64), B);
-  hipLaunchKernelGGL((convpos_fwd_kernel<0, 31>), grid, dim3(256), (CT + ksize - 1) * 64 * sizeof(float), ST, e, w, bias, mask,
-                     (const float*)nullptr, xs, N, R, D);
+#define VBX_CALL(KS)                                                                                                         \
+  hipLaunchKernelGGL((convpos_fwd_kernel<0, KS>), grid, dim3(256), (CT + KS - 1) * 64 * sizeof(float), ST, e, w, bias, mask, \
+                     (const float*)nullptr, xs, N, R, D)
+  VBX_CONV_KS_SWITCH(ksize, VBX_CALL)
+#undef VBX_CALL
   VBX_LAUNCH_CHECK();
   if (R > 0) {
     hipLaunchKernelGGL(regs_fill_kernel, dim3(grid_for((long)B * R * D)), dim3(256), 0, ST, reg, xs, B, N + R, R, D);
@@ -1335,21 +1349,31 @@ extern "C" int vbx_convpos_bwd(const float* e, const float* w, const float* bias
                                float* dpre_tmp, float* de, void* de_bf16, float* wpart, float* dreg, int B, int N, int R,
                                int D, int ksize, void* stream) {
   VBX_REQUIRE(e && w && bias && dxs && dpre_tmp && de && wpart, "vbx_convpos_bwd: null pointer");
-  VBX_REQUIRE(ksize == 31, "vbx_convpos_bwd: only conv_pos_embed_kernel_size == 31 is built (got %d)", ksize);
+  VBX_REQUIRE(conv_ks_ok(ksize), "vbx_convpos_bwd: conv_pos_embed_kernel_size must be odd and <= 31 (got %d)", ksize);
   dim3 grid(cdiv(N, CT), cdiv(D, 64), B);
   const int rows = CT + ksize - 1;
-  hipLaunchKernelGGL((convpos_fwd_kernel<1, 31>), grid, dim3(256), rows * 64 * sizeof(float), ST, e, w, bias, mask, dxs, dpre_tmp,
-                     N, R, D);
+#define VBX_CALL(KS)                                                                                                            \
+  hipLaunchKernelGGL((convpos_fwd_kernel<1, KS>), grid, dim3(256), rows * 64 * sizeof(float), ST, e, w, bias, mask, dxs, dpre_tmp, \
+                     N, R, D)
+  VBX_CONV_KS_SWITCH(ksize, VBX_CALL)
+#undef VBX_CALL
   VBX_LAUNCH_CHECK();
-  const size_t lds = (size_t)(2 * rows * 64) * sizeof(float);  // >= the [4][64][33] reduction buffer that reuses it
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_bwd_kernel<31>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr = true;
+  // the two tiles, or the [4][64][33] reduction buffer that reuses their space, whichever is larger
+  size_t lds = (size_t)(2 * rows * 64) * sizeof(float);
+  if (lds < (size_t)4 * 64 * 33 * sizeof(float)) lds = (size_t)4 * 64 * 33 * sizeof(float);
+  static bool attr[32] = {};
+#define VBX_CALL(KS)                                                                                                              \
+  {                                                                                                                               \
+    if (!attr[KS]) {                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_bwd_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                                        \
+      attr[KS] = true;                                                                                                            \
+    }                                                                                                                             \
+    hipLaunchKernelGGL(convpos_bwd_kernel<KS>, grid, dim3(256), lds, ST, e, w, mask, dxs, dpre_tmp, de, (u16*)de_bf16, wpart, N,   \
+                       R, D);                                                                                                     \
   }
-  hipLaunchKernelGGL(convpos_bwd_kernel<31>, grid, dim3(256), lds, ST, e, w, mask, dxs, dpre_tmp, de, (u16*)de_bf16, wpart, N, R,
-                     D);
+  VBX_CONV_KS_SWITCH(ksize, VBX_CALL)
+#undef VBX_CALL
   VBX_LAUNCH_CHECK();
   if (R > 0 && dreg) {
     hipLaunchKernelGGL(dreg_kernel, dim3(cdiv((long)R * D, 256)), dim3(256), 0, ST, dxs, dreg, B, N + R, R, D);

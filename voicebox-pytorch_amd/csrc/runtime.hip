@@ -36,13 +36,14 @@ struct Carver {
 };
 
 struct Dims {
-  int B, N, R, Np, D, H, I, F, Fp, Th, L, ks, J, E, Ke;  // Ke = to_embed input width 2*D + E
+  int B, N, R, Np, D, H, I, F, Fp, Th, L, ks, J, E, Ke, Din;  // Din = data width (dim_in), Ke = to_embed input width 2*Din + E
   long M, M0;
 };
 Dims dims_of(const vbx_model* m) {
   Dims d;
   d.B = m->B; d.N = m->N; d.R = m->R; d.Np = m->N + m->R; d.D = m->D; d.H = m->H; d.I = m->H * 64;
-  d.E = m->E; d.Ke = 2 * m->D + m->E;
+  d.Din = m->Din > 0 ? m->Din : m->D;
+  d.E = m->E; d.Ke = 2 * d.Din + m->E;
   d.F = m->F; d.Fp = ((m->F + 63) / 64) * 64; d.Th = m->Th; d.L = m->L; d.ks = m->ksize; d.J = m->L * 4 * m->D;
   d.M = (long)d.B * d.Np; d.M0 = (long)d.B * d.N;
   return d;
@@ -64,8 +65,8 @@ void carve_wpack(const vbx_model* m, WPack& w) {
   Carver c(m->wpack);
   w.embh = c.take<u16>((size_t)d.D * d.Ke);
   w.embb = d.E ? c.take<u16>((size_t)d.D * d.Ke) : nullptr;
-  w.pred = c.take<u16>((size_t)d.D * d.D);
-  w.predh = c.take<u16>((size_t)d.D * d.D);
+  w.pred = c.take<u16>((size_t)d.Din * d.D);
+  w.predh = c.take<u16>((size_t)d.Din * d.D);
   w.adah = c.take<u16>((size_t)d.J * d.Th);
   w.bada = c.take<float>(d.J);
   w.layer.resize(d.L);
@@ -232,7 +233,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
   }
   a.hf = tr ? c.take<u16>((size_t)d.M0 * d.D) : nullptr;
   a.hfh = c.take<u16>((size_t)d.M0 * d.D);
-  a.pred = c.take<float>((size_t)d.M0 * d.D);
+  a.pred = c.take<float>((size_t)d.M0 * d.Din);
   a.per_b = c.take<float>(vbx_masked_mse_scratch_floats(d.B));
   if (tr) {
     a.dx = c.take<float>((size_t)d.M * d.D);
@@ -253,7 +254,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
       if (n > sf) sf = n;
     };
     upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
-    upd(d.D, d.Ke, d.M0); upd(d.D, d.D, d.M0);
+    upd(d.D, d.Ke, d.M0); upd(d.Din, d.D, d.M0);
     if (m->gateloop) upd(3 * d.D, d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(4 * sf);  // four regions: the layer's weight-gradient slabs stay live until its batched reduce
@@ -274,7 +275,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.dpre = c.take<float>((size_t)d.M0 * d.D);
     a.de = c.take<float>((size_t)d.M0 * d.D);
     a.deb = c.take<u16>((size_t)d.M0 * d.D);
-    a.dpb = c.take<u16>((size_t)d.M0 * d.D);
+    a.dpb = c.take<u16>((size_t)d.M0 * d.Din);
     a.wpart = c.take<float>((size_t)vbx_convpos_bwd_chunks(d.B, d.N) * d.D * 64);
     a.tscratch = c.take<float>((size_t)vbx_time_embed_bwd_scratch_floats(d.B, d.D));
     a.gl_ds = m->gateloop ? c.take<float>((size_t)d.M * d.D) : nullptr;
@@ -328,7 +329,7 @@ int check_model(const vbx_model* m) {
   VBX_REQUIRE(m->D % 64 == 0 && m->D <= 2048, "vbx_model: dim must be a multiple of 64 and <= 2048 (got %d)", m->D);
   VBX_REQUIRE(m->H > 0 && m->H % 2 == 0, "vbx_model: heads must be even (dim_head is fixed at 64)");
   VBX_REQUIRE(m->Th % 8 == 0 && m->L > 0 && m->B > 0 && m->N > 0 && m->R >= 0 && m->F > 0, "vbx_model: bad dims");
-  VBX_REQUIRE(m->ksize == 31, "vbx_model: conv_pos_embed_kernel_size must be 31");
+  VBX_REQUIRE(m->ksize >= 1 && m->ksize <= 31 && (m->ksize & 1), "vbx_model: conv_pos_embed_kernel_size must be odd and <= 31 (got %d)", m->ksize);
   VBX_REQUIRE(m->E >= 0 && m->E % 8 == 0 && (m->E == 0 || (m->V1 > 0 && !m->stack_only)), "vbx_model: bad dim_cond_emb / table size");
   const long DT = (long)m->D * m->Th;
   for (int l = 0; l < m->L; l++) {
@@ -345,6 +346,7 @@ int check_model(const vbx_model* m) {
                 "vbx_model: GateLoop post-LayerNorm weight and bias of layer %d are not contiguous", l);
   }
   VBX_REQUIRE(!m->plain_norm || m->stack_only, "vbx_model: plain_norm is only used by the standalone stack (VoiceBox is adaptive)");
+  VBX_REQUIRE(m->Din >= 0 && m->Din % 8 == 0 && (m->Din == 0 || !m->stack_only), "vbx_model: dim_in must be a multiple of 8 (got %d)", m->Din);
   VBX_REQUIRE(m->attn_dropout >= 0.f && m->attn_dropout < 1.f && m->ff_dropout >= 0.f && m->ff_dropout < 1.f, "vbx_model: dropout must be in [0, 1)");
   return 0;
 }
@@ -482,7 +484,7 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
   const long* G = m->off;
   if (!m->stack_only) {
     CK(vbx_pack_weight(P + G[VBX_P_EMBW], d.D, d.Ke, w.embb, w.embh, d.D, d.Ke, 0, 0, stream));
-    CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, d.D, d.D, 0, 0, stream));
+    CK(vbx_pack_weight(P + G[VBX_P_PREDW], d.Din, d.D, w.pred, w.predh, d.Din, d.D, 0, 0, stream));
   }
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
@@ -543,9 +545,9 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   if (d.E) {
     VBX_REQUIRE(io->cond_ids && io->T > 0, "vbx_model_forward: a text-conditioned model needs cond_ids");
     CK(vbx_pack_embed_input_text(io->x, io->cond, io->cond_mask, io->drop_mask, io->null_cond, io->cond_ids, io->T,
-                                 P + G[VBX_P_CEMB], d.E, io->null_id, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
+                                 P + G[VBX_P_CEMB], d.E, io->null_id, a.embed_inh, a.embed_in, d.B, d.N, d.Din, stream));
   } else {
-    CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.D, stream));
+    CK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a.embed_inh, a.embed_in, d.B, d.N, d.Din, stream));
   }
   CK(gemm_nt(a.embed_inh, d.Ke, w.embh, d.Ke, (int)d.M0, d.D, d.Ke, VBX_EPI_F32, a.e, d.D, P + G[VBX_P_EMBB], nullptr,
              nullptr, nullptr, st));
@@ -616,8 +618,8 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   // strip registers, final RMSNorm, to_pred   (:476-479, :1092)
   CK(vbx_rmsnorm_fwd(a.xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, a.hf, a.hfh, d.B, d.Np, d.R, d.N, d.D, stream));
   float* pred = io->pred ? io->pred : a.pred;
-  CK(gemm_nt(a.hfh, d.D, w.predh, d.D, (int)d.M0, d.D, d.D, VBX_EPI_F32, pred, d.D, nullptr, nullptr, nullptr, nullptr, st));
-  if (io->target) CK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a.per_b, io->loss, d.B, d.N, d.D, stream));
+  CK(gemm_nt(a.hfh, d.D, w.predh, d.D, (int)d.M0, d.Din, d.D, VBX_EPI_F32, pred, d.Din, nullptr, nullptr, nullptr, nullptr, st));
+  if (io->target) CK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a.per_b, io->loss, d.B, d.N, d.Din, stream));
   return 0;
 }
 
@@ -639,9 +641,9 @@ static int backward_head_impl(const vbx_model* m, const vbx_io* io, const float*
     CK(vbx_pack_weight(io->target, (int)d.M0, d.D, a.dhn, nullptr, (int)d.M0, d.D, 0, 0, stream));
   } else {
     const float* pred = io->pred ? io->pred : a.pred;
-    CK(vbx_masked_mse_bwd(pred, io->target, io->loss_mask, a.per_b, gscale, nullptr, a.dpb, d.B, d.N, d.D, stream));
-    CK(wgrad(a.dpb, d.D, a.hf, d.D, d.D, d.D, d.M0, a.slabs, Gd + G[VBX_P_PREDW], d.D, d.D, 0, 0, st));
-    CK(gemm_nn_bf16(a.dpb, d.D, w.pred, d.D, (int)d.M0, d.D, d.D, a.dhn, d.D, st));
+    CK(vbx_masked_mse_bwd(pred, io->target, io->loss_mask, a.per_b, gscale, nullptr, a.dpb, d.B, d.N, d.Din, stream));
+    CK(wgrad(a.dpb, d.Din, a.hf, d.D, d.Din, d.D, d.M0, a.slabs, Gd + G[VBX_P_PREDW], d.Din, d.D, 0, 0, st));
+    CK(gemm_nn_bf16(a.dpb, d.Din, w.pred, d.D, (int)d.M0, d.D, d.Din, a.dhn, d.D, st));
   }
   // gradient wrt the last residual snapshot: zero at the register rows, final-norm backward elsewhere
   if (hipMemsetAsync(a.dx, 0, (size_t)d.M * d.D * sizeof(float), st) != hipSuccess ||
@@ -837,7 +839,7 @@ static int backward_embed_impl(const vbx_model* m, const vbx_io* io, void* strea
     // d(cond_emb) = de . W_embed[:, D:D+E]  ->  scatter into the embedding table gradient   (:1055, :1075-1076)
     WPack w;
     carve_wpack(m, w);
-    CK(gemm_nn_bf16(a.deb, d.D, w.embb + d.D, d.Ke, (int)d.M0, d.E, d.D, a.demb, d.E, st));
+    CK(gemm_nn_bf16(a.deb, d.D, w.embb + d.Din, d.Ke, (int)d.M0, d.E, d.D, a.demb, d.E, st));
     if (hipMemsetAsync(Gd + G[VBX_P_CEMB], 0, (size_t)m->V1 * d.E * sizeof(float), st) != hipSuccess) {
       vbx_set_error("vbx_model_backward_embed: memset of the embedding gradient failed");
       return VBX_EINVAL;
@@ -886,7 +888,7 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
   };
   if (!m->stack_only) {
     add(G[VBX_P_EMBW], d.D, d.Ke, w.embb, w.embh, nullptr, d.Ke, 0, 0);
-    add(G[VBX_P_PREDW], d.D, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
+    add(G[VBX_P_PREDW], d.Din, d.D, w.pred, w.predh, nullptr, d.D, 0, 0);
   }
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;

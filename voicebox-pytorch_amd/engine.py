@@ -20,7 +20,7 @@ class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
-                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F)]
+                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I)]
 
 
 class VbxIO(C.Structure):
@@ -210,6 +210,8 @@ class Engine:
         m.plain_norm = 1 if cfg.get("plain_norm") else 0
         m.attn_dropout = float(cfg.get("attn_dropout", 0.))
         m.ff_dropout = float(cfg.get("ff_dropout", 0.))
+        m.Din = int(cfg.get("Din", 0) or 0)  # data width (dim_in); 0 = D
+        self.Din = m.Din or cfg["D"]
         self.has_dropout = m.attn_dropout > 0. or m.ff_dropout > 0.
         self.dropout_active = False  # nn.Dropout semantics: the owning module sets this to its .training flag before a forward
         self.off_table = flat.offset_table()
@@ -271,7 +273,8 @@ class Engine:
         else the prediction (B,N,D).  text (text-conditioned models): (ids int64 (B,T), null_id, drop_mask bool (B,) or None,
         null_cond fp32 (D,))."""
         self.bind_params()
-        B, N, D = self.B, self.N, self.cfg["D"]
+        B, N, D = self.B, self.N, self.Din
+        assert x.shape == (B, N, D) and cond.shape == (B, N, D), (tuple(x.shape), tuple(cond.shape), (B, N, D))
         x, cond = x.contiguous(), cond.contiguous()
         cm = _u8(cond_mask)
         am = amp = lm = None

@@ -379,14 +379,14 @@ class VoiceBox(nn.Module):
             raise NotImplementedError("dim_cond_emb must be a multiple of 8 (16-byte GEMM rows)")
         if exists(audio_enc_dec):
             raise NotImplementedError("audio codecs are out of scope of the hot path: feed latents directly")
-        if dim_in != dim:
-            raise NotImplementedError("dim_in != dim (proj_in) is not built")
+        if dim_in % 8 != 0:  # data width of x / cond / target / pred (e.g. 80 mel bins into a dim-512 model, :905,938,964)
+            raise NotImplementedError("dim_in must be a multiple of 8 (16-byte rows of the to_embed / to_pred operands)")
         if dim_head != 64:
             raise NotImplementedError("the HIP kernels are built for dim_head == 64")
         if dim % 64 != 0 or dim > 2048 or heads % 2 != 0:
             raise NotImplementedError("dim must be a multiple of 64 (<= 2048) and heads even")
-        if conv_pos_embed_kernel_size != 31:
-            raise NotImplementedError("conv_pos_embed_kernel_size must be 31")
+        if conv_pos_embed_kernel_size % 2 != 1 or not 1 <= conv_pos_embed_kernel_size <= 31:
+            raise NotImplementedError("conv_pos_embed_kernel_size must be odd (as in the reference, :211) and <= 31")
         self.audio_enc_dec = None
         self.proj_in = nn.Identity()
         self.sinu_pos_emb = nn.Sequential(LearnedSinusoidalPosEmb(dim), nn.Linear(dim, time_hidden_dim), nn.SiLU())
@@ -414,7 +414,7 @@ class VoiceBox(nn.Module):
                          attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
                          gateloop=bool(use_gateloop_layers), E=dim_cond_emb,
                          V1=(num_cond_tokens + 1) if condition_on_text else 0,
-                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout))
+                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout), Din=int(dim_in))
         self._flat = None
         self._engines = {}
 

@@ -54,7 +54,7 @@ class MidpointSampler:
         self.eng = engines[0]
         self.flat_gen = self.eng.fp.flat_gen  # the captured graph bakes in addresses inside this flat parameter buffer
         dev = self.eng.device
-        D = voicebox._cfg["D"]
+        D = voicebox._cfg.get("Din") or voicebox._cfg["D"]  # the ODE state lives in data space (dim_in)
         t = torch.linspace(0, 1, steps)  # host fp32, as the CPU oracle
         t0, dt = t[:-1], t[1:] - t[:-1]
         half = 0.5 * dt
