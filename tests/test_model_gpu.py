@@ -1129,6 +1129,44 @@ def test_dim_in_other_than_dim_vs_reference(golden):
         assert torch.equal(vb(g["x1"].to(dev), **kw), vb2(g["x1"].to(dev), **kw))
 
 
+@pytest.mark.parametrize("B,N,masked", [(1, 8, False), (3, 63, True), (2, 129, True), (1, 200, False), (5, 257, True), (2, 48, True),
+                                        (4, 112, False)])
+def test_training_step_over_ragged_shapes_vs_oracle(B, N, masked):
+    """Shapes around every tiling boundary of the path (frames + 16 registers = 24 ... 273: below one 32-row block, one short of /
+    one past a 64- and a 128-row tile; batch 1 ... 5; ragged key-padding masks incl. a sample with ONE valid frame): loss and every
+    gradient of a well-conditioned dim-64 / depth-2 model against the fp64 restatement."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=31)
+    state = {k: (v * 0.25 if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma") else v) for k, v in state.items()}
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    vb.load_state_dict(state, strict=False)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    gen = torch.Generator().manual_seed(1000 * B + N)
+    x1, x0 = torch.randn(B, N, 64, generator=gen), torch.randn(B, N, 64, generator=gen)
+    times, frac, rand = torch.rand(B, generator=gen), 0.7 + 0.3 * torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    mask = None
+    if masked:
+        lengths = torch.randint(max(1, N // 3), N + 1, (B,), generator=gen)
+        lengths[0] = N
+        if B > 2:
+            lengths[-1] = 1
+        mask = torch.arange(N)[None, :] < lengths[:, None]
+    with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
+        loss = wrapper(x1.to(dev), mask=mask.to(dev) if masked else None)
+    loss.backward()
+    p = {k: v.double().clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in state.items()}
+    ref = restate.cfm_loss(p, cfg, x1.double(), x0.double(), times.double(), frac, rand, mask=mask)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-3, (float(loss), float(ref))
+    for k, prm in vb.named_parameters():
+        if p[k].grad is not None and float(p[k].grad.norm()) > 0:
+            assert rel(prm.grad, p[k].grad) < 0.04, (k, rel(prm.grad, p[k].grad))
+
+
 def test_attend_module_with_dropout(golden):
     """Attend(dropout=p) (attend.py:38-137): training mode drops attention probabilities with the mask of its last Philox key, eval
     mode does not; gradients flow through the dropped softmax."""
