@@ -1246,21 +1246,34 @@ __device__ __forceinline__ void attn_bwd_dkdv_dma_body(char* smem, int wg_id, co
     }
     {
       f32x4 l4[4];
+#if defined(VBX_ATTN_ABL_DKDV) && (VBX_ATTN_ABL_DKDV & 1)  // timing ablation (diagnostic builds only): no statistics reads
+      for (int g4 = 0; g4 < 4; g4++) l4[g4] = f32x4{scale, scale, scale, scale};
+#else
       D3_READ128(l4[0], sa, SO + QB * 128); D3_READ128(l4[1], sa, SO + QB * 128 + 32);
       D3_READ128(l4[2], sa, SO + QB * 128 + 64); D3_READ128(l4[3], sa, SO + QB * 128 + 96);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) s[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], scale2, -l4[g4][j]));
+        for (int j = 0; j < 4; j++)
+#if defined(VBX_ATTN_ABL_DKDV) && (VBX_ATTN_ABL_DKDV & 2)  // timing ablation: no exponentials
+          s[4 * g4 + j] = fmaf(s[4 * g4 + j], scale2, -l4[g4][j]);
+#else
+          s[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], scale2, -l4[g4][j]));
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     {
       f32x4 d4[4];
+#if defined(VBX_ATTN_ABL_DKDV) && (VBX_ATTN_ABL_DKDV & 1)
+      for (int g4 = 0; g4 < 4; g4++) d4[g4] = f32x4{scale2, scale2, scale2, scale2};
+#else
       D3_READ128(d4[0], sa, SO + QB * 128 + 256); D3_READ128(d4[1], sa, SO + QB * 128 + 288);
       D3_READ128(d4[2], sa, SO + QB * 128 + 320); D3_READ128(d4[3], sa, SO + QB * 128 + 352);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DROP) {
         const unsigned wk = (QB ? wkeep.y : wkeep.x) >> (4 * hi);  // register 4 * g4 + j <-> query 8 * g4 + 4 * hi + j of the block
