@@ -221,7 +221,8 @@ int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, i
 int vbx_stack_input_bwd(const float* dxs, float* dx, float* dreg /* may be NULL */, int B, int N, int R, int D, void* stream);
 int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
                     float* xs, int B, int N, int R, int D, int ksize, void* stream);
-/* backward: de = dxs[:,R:] + conv-transpose(...) ; dw/db partials [chunks][D][ksize+1]; dreg [R,D]. */
+/* ksize: any odd kernel size <= 31 (the reference default is 31, voicebox_pytorch.py:893; one unrolled instantiation per size).
+ * backward: de = dxs[:,R:] + conv-transpose(...) ; dw/db partials [chunks][D][ksize+1]; dreg [R,D]. */
 int vbx_convpos_bwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* dxs,
                     float* dpre_tmp /* fp32 [B,N,D] scratch */, float* de, void* de_bf16,
                     float* wpart /* [chunks][D][64]: k<ksize weight grads, [63] bias grad */, float* dreg, int B, int N,
