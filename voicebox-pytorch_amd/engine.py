@@ -318,7 +318,11 @@ class Engine:
         self.io.dropout = 0
         if self.has_dropout and self.dropout_active:
             self.io.dropout = 1
-            self.io.drop_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # data-parallel ranks seeded alike (torch.manual_seed(s) everywhere) must still drop different entries
+                seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
+            self.io.drop_seed = seed
 
     # -- standalone Transformer.forward / backward (vbx_model.stack_only)
     def forward_stack(self, x, cond=None, attn_mask=None):
