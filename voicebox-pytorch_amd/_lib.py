@@ -118,9 +118,13 @@ def lib():
     if not os.environ.get("VBX_LIB_PATH"):  # a library that was not rebuilt after a source edit must not be mistaken for the product
         from . import build as _build
 
-        if _build.recorded_hash() != _build.source_hash():
-            raise VbxError(f"{LIB_PATH} is stale: csrc/ or include/vbx.h changed since it was built (or it predates the source-hash "
-                           "stamp).  Rebuild with `python voicebox-pytorch_amd/build.py`.")
+        rec = _build.recorded_hash()
+        if rec is None:  # a library without its stamp (copied on its own): cannot tell -- say so, do not refuse
+            import sys
+            print(f"voicebox_pytorch_amd: {LIB_PATH} has no source-hash stamp; cannot check that it matches csrc/", file=sys.stderr)
+        elif rec != _build.source_hash():
+            raise VbxError(f"{LIB_PATH} is stale: csrc/ or include/vbx.h changed since it was built.  "
+                           "Rebuild with `python voicebox-pytorch_amd/build.py`.")
     l = C.CDLL(LIB_PATH)
     l.vbx_last_error.restype = C.c_char_p
     l.vbx_last_error.argtypes = []
