@@ -138,6 +138,7 @@ int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, c
  * kernel runs, because the chain's flags carry a per-launch epoch passed by value). */
 size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
 int vbx_attn_bwd_select(int variant);
+int vbx_attn_bwd_variant(void); /* 1 two-body, 2 one-pass: which kernel the current selection runs (callers size `scratch` by it) */
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
                  const uint8_t* mask, const void* out /* forward output [B,Np,H*64] */, int out_is_f16,
                  const void* dout, const float* lse, float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H,
@@ -414,6 +415,11 @@ typedef struct {
                              arena holds the attention keep bits (per layer when training != 0, for the backward) */
   int Din;                /* dim_in (:884,905): width of x / cond / target / pred and of null_cond; to_embed is Linear(2*Din + E, D)
                              (:938), to_pred Linear(D, Din) (:964-966).  0 = D.  Multiple of 8. */
+  int precise;            /* 1: exact-operand forward (see "precise mode" below): every forward matrix product to fp32 accuracy;
+                             needs wpack3 (vbx_model_precise_wpack_bytes, filled by vbx_model_pack_weights_precise) and pscratch
+                             (vbx_model_precise_scratch_bytes).  The backward entry points are unchanged (bf16 operands). */
+  void* wpack3;           /* precise mode: hi/lo-split fp16 weights, K-concatenated */
+  void* pscratch;         /* precise mode: fp32 intermediates + the K-concatenated activation operand */
 } vbx_model;
 
 typedef struct {
@@ -452,6 +458,39 @@ int vbx_model_backward_embed(const vbx_model* m, const vbx_io* io, void* stream)
 
 /* tests/debug only: device pointer of a named tensor inside the activation arena (NULL if unknown) */
 void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer);
+
+/* ------------------------------------------------------------------ precise mode (exact-operand forward)
+ * The fast path rounds every forward GEMM / attention operand to fp16; at the reference's own initialisation (qk-normed logits of
+ * std ~80, a chaotic 12-layer map) that moves the loss by O(1e-3).  With vbx_model.precise = 1 vbx_model_forward evaluates
+ * the same VoiceBox.forward (voicebox_pytorch.py:987-1115) with every matrix product to fp32 accuracy:
+ *  - nn.Linear (:320,333,345,348,1078,1092): the same vbx_gemm tiles with both operands split into fp16 hi + lo parts and concatenated
+ *    along K -- A' = [A_hi | A_hi | A_lo] (vbx_split3_f16), W' = [W_hi | W_lo | W_hi] (vbx_pack_weight3), K' = 3K, VBX_EPI_F32;
+ *  - MultiheadRMSNorm + rotary (:286-287,193-199, 323-328) and GEGLU (:338-340) as fp32 kernels on the fp32 GEMM results
+ *    (vbx_qknorm_rope_f32, vbx_geglu_f32), which also write the fp16 / bf16 copies the backward entry points read;
+ *  - Attend (attend.py:121-135) as an fp32 FMA flash kernel (vbx_attn_fwd_f32), q / k / v / P never rounded;
+ *  - AdaptiveRMSNorm's to_gamma / to_beta (:273) from the fp32 master weights (vbx_adaln_proj_f32).
+ * Serves the unconditional model (E == 0, no GateLoop, no dropout); other configurations return VBX_EINVAL. */
+/* dst fp16 [rows, 3*Kp] = [hi | hi | lo] of src fp32 [rows, K] (row stride ld floats), columns K..Kp zero; Kp % 8 == 0 */
+int vbx_split3_f16(const float* src, long rows, int K, long ld, void* dst_f16, int Kp, void* stream);
+/* dst fp16 [dst_rows, 3*dst_cols] = [hi | lo | hi] of the weight, rows mapped / padded as vbx_pack_weight does */
+int vbx_pack_weight3(const float* src, int src_rows, int src_cols, void* dst_f16, int dst_rows, int dst_cols, int rowmap, int F,
+                     void* stream);
+/* raw fp32 [B*Np, 3*H*64] (to_qkv output) -> q, k (qk-normed when qk_scale > 0, rotated) and v, head-major [B,H,Np,64]: fp32 plus the
+ * optional fp16 / bf16 copies and 1/max(|.|,1e-12) rows the backward reads (any of q16 .. k_rnorm may be NULL) */
+int vbx_qknorm_rope_f32(const float* raw, int B, int H, int Np, float qk_scale, const float* q_gamma, const float* k_gamma,
+                        const float* rot_cos, const float* rot_sin, float* q32, float* k32, float* v32, void* q16, void* k16,
+                        void* qb, void* kb, void* v_bf16, void* v16, float* q_rnorm, float* k_rnorm, void* stream);
+/* attend.py:121-135 in fp32: q, k, v fp32 [B,H,Np,64] -> out32 fp32 [B,Np,H*64] (+ optional fp16 / bf16 copies, log2-LSE [B,H,Np]) */
+int vbx_attn_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16, void* out_bf16,
+                     float* lse, int B, int H, int Np, float scale, void* stream);
+/* GEGLU (libm erff) on the fp32 pre-activation h1 [M, 2*Fp] in the packed column order (128-column blocks: 64 "x", their 64 "gate"):
+ * g32 [M, Fp] (+ optional fp16 / bf16 copies of g and the bf16 pre-activation the backward reads) */
+int vbx_geglu_f32(const float* h1, float* g32, void* g16, void* g_bf16, void* h1_bf16, long M, int Fp, void* stream);
+/* vbx_adaln_proj_fwd with fp32 weights W [J, Th] */
+int vbx_adaln_proj_f32(const float* temb, const float* w, const float* bias, float* ada, int B, int Th, int J, int group, void* stream);
+size_t vbx_model_precise_wpack_bytes(const vbx_model* m);
+size_t vbx_model_precise_scratch_bytes(const vbx_model* m);
+int vbx_model_pack_weights_precise(const vbx_model* m, void* stream);
 
 /* ------------------------------------------------------------------ in-situ stage timing (measurement only)
  * While enabled, vbx_model_forward / vbx_model_backward_* bracket each MFMA stage of a layer (to_qkv, attention forward, to_out,

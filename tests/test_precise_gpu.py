@@ -1,0 +1,353 @@
+"""GPU tests of the exact-operand ("precise") mode (include/vbx.h "precise mode", csrc/precise.hip).
+
+The fast path rounds every forward GEMM / attention operand to fp16 and holds the north star's "loss within 1e-3 of the reference"
+only where the problem is well conditioned.  In precise mode every forward matrix product is evaluated to fp32
+accuracy -- hi/lo-split fp16 operands K-concatenated through the SAME vbx_gemm tiles, fp32 attention -- and these tests assert the
+north star's 1e-3 AT THE REFERENCE'S OWN INITIALISATION on the headline architectures (config 4: all six reference seeds incl.
+BASELINE's B = 8; config 3), against goldens produced by the unmodified reference (tests/golden/make_golden.py).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restate
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from voicebox_pytorch_amd import _lib
+
+    _lib.lib()
+    _lib.call("vbx_check_device", 0)
+    return _lib
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / ref.norm().clamp(min=1e-30))
+
+
+# ----------------------------------------------------------------------------- op level
+def kconcat_gemm(L, A, W, bias=None, resid=None):
+    M, K = A.shape
+    N = W.shape[0]
+    Kp = (K + 7) // 8 * 8
+    a3 = torch.empty(M, 3 * Kp, dtype=torch.float16, device=dev)
+    w3 = torch.empty(N, 3 * Kp, dtype=torch.float16, device=dev)
+    L.call("vbx_split3_f16", A, M, K, K, a3, Kp, st())
+    L.call("vbx_pack_weight3", W, N, K, w3, N, Kp, 0, 0, st())
+    C = torch.empty(M, N, dtype=torch.float32, device=dev)
+    d = L.GemmDesc()
+    d.mode, d.epilogue, d.M, d.N, d.K = L.VBX_GEMM_NT, L.VBX_EPI_F32, M, N, 3 * Kp
+    d.A, d.B, d.C, d.lda, d.ldb, d.ldc, d.f16 = a3.data_ptr(), w3.data_ptr(), C.data_ptr(), 3 * Kp, 3 * Kp, N, 1
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    assert L.lib().vbx_gemm(d, st()) == 0, L.lib().vbx_last_error()
+    return C, a3, w3
+
+
+@pytest.mark.parametrize("M,N,K", [(8320, 3072, 512), (8192, 512, 1024), (333, 264, 1408), (8320, 512, 1408), (130, 128, 64)])
+def test_kconcat_gemm_is_fp32_accurate(L, M, N, K):
+    """A' = [A_hi | A_hi | A_lo], W' = [W_hi | W_lo | W_hi] through the ordinary fp16 MFMA tiles: the result must be fp32-class
+    (error of the order of an fp32 accumulation, ~1e-6 relative), two orders below the single-fp16 product (2^-11 operands),
+    INCLUDING small weights whose lo parts are fp16 subnormals (nn.Linear init: |w| <= K^-0.5) and a few large activations."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    A[::7] *= 30.0                      # rows of large activations
+    A[:, ::5] *= 1e-3                   # columns of small ones
+    W = (torch.rand(N, K, generator=g) * 2 - 1) * K ** -0.5
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    C, a3, w3 = kconcat_gemm(L, A.to(dev), W.to(dev), bias.to(dev), resid.to(dev))
+    ref = A.double() @ W.double().t() + bias.double() + resid.double()
+    e = rel(C, ref)
+    # what one fp16 rounding of each operand costs, for the record
+    e16 = rel((A.half().double() @ W.half().double().t()) + bias.double() + resid.double(), ref)
+    # operand reconstruction error of the split itself
+    Kp = a3.shape[1] // 3
+    a_rec = a3[:, :Kp].double() + a3[:, 2 * Kp:].double()
+    w_rec = w3[:, :Kp].double() + w3[:, Kp:2 * Kp].double()
+    ea, ew = rel(a_rec[:, :K], A), rel(w_rec[:, :K], W)
+    print(f"K-concat GEMM {M}x{N}x{K}: rel err {e:.2e} (single fp16 operands: {e16:.2e}); split reconstruction A {ea:.1e} W {ew:.1e}")
+    assert torch.equal(a3[:, :Kp], a3[:, Kp:2 * Kp]) and torch.equal(w3[:, :Kp], w3[:, 2 * Kp:])
+    assert ea < 2e-6 and ew < 2e-6, (ea, ew)
+    assert e < 3e-6, e
+    assert e < e16 / 50, (e, e16)
+
+
+def test_qknorm_rope_f32(L, golden):
+    """MultiheadRMSNorm + rotary in fp32 (voicebox_pytorch.py:286-287,193-199,323-328) and its fp16 / bf16 / 1/norm side outputs."""
+    B, H, Np, R = 2, 4, 80, 16
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randn(B * Np, 3 * H * 64, generator=g) * 3.0
+    qg, kg = torch.rand(H, 64, generator=g) + 0.5, torch.rand(H, 64, generator=g) + 0.5
+    from voicebox_pytorch_amd.engine import rotary_tables
+
+    rc, rs = rotary_tables(Np - R, R, 64, 50000.0, dev)
+    hs = (B, H, Np, 64)
+    q32, k32, v32 = (torch.empty(hs, device=dev) for _ in range(3))
+    q16, k16, v16 = (torch.empty(hs, dtype=torch.float16, device=dev) for _ in range(3))
+    qb, kb, vb = (torch.empty(hs, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    qrn, krn = torch.empty(B, H, Np, device=dev), torch.empty(B, H, Np, device=dev)
+    L.call("vbx_qknorm_rope_f32", raw.to(dev), B, H, Np, 8.0, qg.to(dev), kg.to(dev), rc, rs, q32, k32, v32, q16, k16, qb, kb, vb, v16,
+           qrn, krn, st())
+    x = raw.double().view(B, Np, 3, H, 64).permute(2, 0, 3, 1, 4)  # which, b, h, n, d
+    pos = torch.cat((torch.full((R,), -10000, dtype=torch.long), torch.arange(Np - R)))
+    freqs = restate.rotary_freqs(pos, 64, 50000.0).double()
+    for which, (o32, o16, ob, rn, gam) in enumerate(((q32, q16, qb, qrn, qg), (k32, k16, kb, krn, kg))):
+        t = F.normalize(x[which], dim=-1) * 8.0 * gam.double()[None, :, None, :]
+        ref = restate.apply_rotary(freqs, t)
+        assert rel(o32, ref) < 1e-6, (which, rel(o32, ref))
+        assert rel(o16, ref) < 5e-4 and rel(ob, ref) < 4e-3
+        assert rel(rn, 1.0 / x[which].norm(dim=-1)) < 1e-6
+    assert torch.equal(v32.cpu(), x[2].float()) and rel(v16, x[2]) < 5e-4 and rel(vb, x[2]) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,Np,masked", [(2, 2, 1040, False), (2, 2, 1040, True), (1, 2, 300, True), (8, 16, 1040, False)])
+def test_attn_fwd_f32(L, B, H, Np, masked):
+    """attend.py:121-135 with scale 10 on unit-8 q/k (the model's regime: logits of std ~80) in fp32 against fp64."""
+    g = torch.Generator().manual_seed(B * 1000 + Np)
+    q = F.normalize(torch.randn(B, H, Np, 64, generator=g), dim=-1) * 8
+    k = F.normalize(torch.randn(B, H, Np, 64, generator=g), dim=-1) * 8
+    v = torch.randn(B, H, Np, 64, generator=g)
+    mask = None
+    if masked:
+        mask = torch.ones(B, Np, dtype=torch.bool)
+        mask[0, Np - 37:] = False
+        mask[-1, 5:9] = False
+    out32 = torch.empty(B, Np, H * 64, device=dev)
+    out16 = torch.empty(B, Np, H * 64, dtype=torch.float16, device=dev)
+    outb = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, H, Np, device=dev)
+    m8 = mask.to(torch.uint8).to(dev) if masked else None
+    L.call("vbx_attn_fwd_f32", q.to(dev), k.to(dev), v.to(dev), m8, out32, out16, outb, lse, B, H, Np, 10.0, st())
+    torch.cuda.synchronize()
+    if B * H > 16:  # the benchmark grid: check a few heads against fp64
+        sel = [(0, 0), (3, 7), (7, 15)]
+    else:
+        sel = [(b, h) for b in range(B) for h in range(H)]
+    for b, h in sel:
+        ref = restate.attend(q[b:b + 1, h:h + 1].double(), k[b:b + 1, h:h + 1].double(), v[b:b + 1, h:h + 1].double(),
+                             mask=mask[b:b + 1] if masked else None, scale=10.0)[0, 0]
+        got = out32[b, :, h * 64:(h + 1) * 64]
+        e = rel(got, ref)
+        assert e < 2e-5, (b, h, e)  # fp32 logits of magnitude ~80-400: 2^-24 * 400 ~ 2e-5 absolute on a logit
+        assert rel(out16[b, :, h * 64:(h + 1) * 64], ref) < 6e-4 and rel(outb[b, :, h * 64:(h + 1) * 64], ref) < 5e-3
+        sim = torch.einsum("id,jd->ij", q[b, h].double(), k[b, h].double()) * 10.0
+        if masked:
+            sim = sim.masked_fill(~mask[b][None, :], float("-inf"))
+        ref_lse2 = torch.logsumexp(sim, dim=-1) * 1.4426950408889634
+        assert float((lse[b, h].double().cpu() - ref_lse2).abs().max()) < 2e-3
+
+
+def test_geglu_f32(L):
+    M, F_, Fp = 333, 170, 192
+    g = torch.Generator().manual_seed(9)
+    x, gate = torch.randn(M, F_, generator=g) * 2, torch.randn(M, F_, generator=g) * 2
+    h1 = torch.zeros(M, 2 * Fp)
+    for t in range(Fp // 64):
+        n = max(0, min(64, F_ - 64 * t))
+        h1[:, 128 * t:128 * t + n] = x[:, 64 * t:64 * t + n]
+        h1[:, 128 * t + 64:128 * t + 64 + n] = gate[:, 64 * t:64 * t + n]
+    g32 = torch.empty(M, Fp, device=dev)
+    g16 = torch.empty(M, Fp, dtype=torch.float16, device=dev)
+    gb = torch.empty(M, Fp, dtype=torch.bfloat16, device=dev)
+    h1b = torch.empty(M, 2 * Fp, dtype=torch.bfloat16, device=dev)
+    L.call("vbx_geglu_f32", h1.to(dev), g32, g16, gb, h1b, M, Fp, st())
+    ref = F.gelu(gate.double()) * x.double()
+    assert rel(g32[:, :F_], ref) < 5e-7, rel(g32[:, :F_], ref)
+    assert float(g32[:, F_:].abs().max()) == 0.0
+    assert rel(g16[:, :F_], ref) < 5e-4 and rel(gb[:, :F_], ref) < 4e-3
+    assert torch.equal(h1b.cpu(), h1.to(torch.bfloat16))
+
+
+def test_adaln_proj_f32(L):
+    B, Th, D, Lyr = 3, 256, 64, 2
+    g = torch.Generator().manual_seed(11)
+    temb = torch.randn(B, Th, generator=g)
+    W = torch.randn(Lyr * 4 * D, Th, generator=g) * 0.02
+    bias = torch.randn(Lyr * 4 * D, generator=g)
+    ada = torch.empty(Lyr, B, 4 * D, device=dev)
+    L.call("vbx_adaln_proj_f32", temb.to(dev), W.to(dev), bias.to(dev), ada, B, Th, Lyr * 4 * D, 4 * D, st())
+    ref = (temb.double() @ W.double().t() + bias.double()).view(B, Lyr, 4 * D).permute(1, 0, 2)
+    assert rel(ada, ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------- model level
+def build(cfg_dict, state):
+    import voicebox_pytorch_amd as vbx
+
+    vb = vbx.VoiceBox(dim=cfg_dict["dim"], num_cond_tokens=500, depth=cfg_dict["depth"], dim_head=64, heads=cfg_dict["heads"],
+                      condition_on_text=False)
+    missing = vb.load_state_dict(state, strict=False)
+    assert not missing.unexpected_keys and all("inv_freq" in k for k in missing.missing_keys)
+    vb = vb.to(dev)
+    return vbx, vb, vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+
+
+def test_precise_small_golden(golden):
+    """dim-64 golden of the unmodified reference (loss, every gradient, masked batch, eval prediction): the precise forward is at
+    fp32 distance from the reference (the fast path: 7e-4 on this loss); the backward (bf16 operands, unchanged) runs from what the
+    precise forward saved."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    _, vb, wrapper = build(g["cfg"], g["state"])
+    for mask_key, loss_key, grads_key in ((None, "loss", "grads"), ("mask", "loss_masked", "grads_masked")):
+        vb.zero_grad(set_to_none=True)
+        mask = g[mask_key] if mask_key else None
+        with vbx.precise_mode(), rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+            loss = wrapper(g["x1"].to(dev), mask=mask.to(dev) if mask_key else None)
+            dl = abs(float(loss) - float(g[loss_key]))
+            loss.backward()
+        with rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+            fast = wrapper(g["x1"].to(dev), mask=mask.to(dev) if mask_key else None)
+        print(f"small golden ({mask_key}): precise |dloss| {dl:.2e}, fast path {abs(float(fast) - float(g[loss_key])):.2e}")
+        assert dl < 2e-5, dl
+        named = dict(vb.named_parameters())
+        for k in ("to_pred.weight", "transformer.final_norm.gamma", "transformer.layers.1.5.3.weight"):
+            assert rel(named[k].grad, g[grads_key][k]) < 5e-2, (k, rel(named[k].grad, g[grads_key][k]))
+        assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None)
+    vb.eval()
+    with vbx.precise_mode(), torch.no_grad():
+        pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev),
+                  cond_mask=g["cond_mask"].to(dev), cond_drop_prob=0.0)
+    e = rel(pred, g["pred"])
+    print("small golden eval prediction, precise: rel", e)
+    assert e < 2e-3, e  # fast path: ~1-2 %; the random-init dim-64 net amplifies fp32 rounding differences to ~1e-4
+
+
+def test_precise_cfg4_reference_init_all_seeds(golden):
+    """NORTH STAR "loss within 1e-3 of reference" on the headline architecture (dim 512, depth 12, heads 16, N = 1024) AT THE
+    REFERENCE'S OWN INITIALISATION, all six seeds of tests/golden/cfg4_seeds.pt (five at B = 2, one at BASELINE's B = 8), where the
+    fast path measures +1.15, +3.48, -0.42, -1.57, +0.82, +4.04 e-3 (test_model_gpu.py::test_cfg4_depth12_reference_init_loss_distribution)."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg4_seeds")
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    diffs, gtot = {}, {}
+    for s_, rec in sorted(g.items()):
+        state = restate.init_state_dict(cfg, seed=s_)
+        _, vb, wrapper = build(dict(dim=512, depth=12, heads=16), state)
+        b = rec["batch"]
+        x1 = torch.randn(b, 1024, 512, generator=torch.Generator().manual_seed(100 + s_))
+        torch.manual_seed(200 + s_)
+        x0 = torch.randn_like(x1)
+        assert torch.equal(x0[0, 0, :4], rec["x0_check"])
+        with vbx.precise_mode(), rng_override(x0=x0, times=rec["times"], frac_lengths=rec["frac"], rand=rec["rand"]):
+            loss = wrapper(x1.to(dev))
+            loss.backward()
+        tot = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in vb.parameters() if p.grad is not None)))
+        diffs[s_] = float(loss) - float(rec["loss"])
+        gtot[s_] = abs(tot - rec["grad_total"]) / rec["grad_total"]
+        assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None)
+        del vb, wrapper
+        torch.cuda.empty_cache()
+    print("PRECISE cfg4 reference-init loss differences by seed", {k: f"{v:+.2e}" for k, v in diffs.items()})
+    print("PRECISE cfg4 reference-init total-gradient-norm relative differences (bf16-operand backward)", {k: round(v, 3) for k, v in gtot.items()})
+    assert max(abs(v) for v in diffs.values()) < 1e-3, diffs
+
+
+def test_precise_cfg3_reference_init(golden):
+    """BASELINE config 3 (dim 1024, depth 12, heads 16) at B = 2 x 1024, reference initialisation: |dloss| < 1e-3 in precise mode
+    (fast path: 2.7e-3), plus the well-conditioned variant."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("cfg3")
+    cfg = restate.Cfg(dim=1024, depth=12, heads=16, dim_head=64)
+    for name in ("init", "wc"):
+        rec = g[name]
+        state = restate.init_state_dict(cfg, seed=3)
+        if name == "wc":
+            for k in state:
+                if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+                    state[k] = state[k] * 0.25
+        _, vb, wrapper = build(dict(dim=1024, depth=12, heads=16), state)
+        x1 = torch.randn(2, 1024, 1024, generator=torch.Generator().manual_seed(30))
+        torch.manual_seed(31)
+        x0 = torch.randn_like(x1)
+        assert torch.equal(x0[0, 0, :4], rec["x0_check"])
+        with vbx.precise_mode(), rng_override(x0=x0, times=rec["times"], frac_lengths=rec["frac"], rand=rec["rand"]):
+            loss = wrapper(x1.to(dev))
+        dl = abs(float(loss) - float(rec["loss"]))
+        vb.eval()
+        with vbx.precise_mode(), torch.no_grad():
+            pred = vb(x1.to(dev), times=torch.tensor(0.37), cond_token_ids=None, cond=x1.to(dev), cond_drop_prob=0.0)
+        e_rows = rel(pred[:, 500:504, :], rec["pred_rows"])
+        e_norm = abs(float(pred.norm()) - rec["pred_norm"]) / rec["pred_norm"]
+        print(f"PRECISE cfg3 {name}: loss {float(loss):.6f} reference {float(rec['loss']):.6f} |d| {dl:.2e}; pred rows rel {e_rows:.4f} norm rel {e_norm:.2e}")
+        assert dl < 1e-3, (name, dl)
+        if name == "wc":
+            assert e_rows < 2e-3, e_rows  # fast path: 0.52 %
+        del vb, wrapper
+        torch.cuda.empty_cache()
+
+
+def test_precise_cfg4_eval_and_sample(golden):
+    """Depth-12 eval prediction and a 4-interval midpoint sample (hipGraph) in precise mode against the unmodified reference: the
+    well-conditioned weights (cfg4_wc: fast path 0.94 % / 17.9 % on the rows) and the reference initialisation (cfg4: chaotic -- the
+    fp32 restatement on the CPU is itself 36 % away on these rows -- reported)."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    cfg = restate.Cfg(dim=512, depth=12, heads=16, dim_head=64)
+    for name in ("cfg4_wc", "cfg4"):
+        g = golden(name)
+        state = restate.init_state_dict(cfg, seed=4)
+        if name == "cfg4_wc":
+            for k in state:
+                if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+                    state[k] = state[k] * 0.25
+        _, vb, wrapper = build(dict(dim=512, depth=12, heads=16), state)
+        x1 = torch.randn(2, 1024, 512, generator=torch.Generator().manual_seed(40))
+        vb.eval()
+        with vbx.precise_mode(), torch.no_grad():
+            pred = vb(x1.to(dev), times=torch.tensor(0.37), cond_token_ids=None, cond=x1.to(dev), cond_drop_prob=0.0)
+        e_rows = rel(pred[:, 500:504, :], g["pred_rows"])
+        torch.manual_seed(42)
+        y0 = torch.randn_like(x1)
+        with vbx.precise_mode(), rng_override(y0=y0):
+            s = wrapper.sample(cond=x1.to(dev), steps=5)
+        e_s = rel(s[:, 500:504, :], g["sample5_rows"])
+        print(f"PRECISE {name}: eval prediction rows rel {e_rows:.4f}; 4-interval sample rows rel {e_s:.4f}")
+        assert torch.isfinite(s).all()
+        if name == "cfg4_wc":
+            assert e_rows < 1e-3 and e_s < 2e-2, (e_rows, e_s)  # the fp32 restatement on the CPU: 1.2e-3 on the sample rows
+        del vb, wrapper
+        torch.cuda.empty_cache()
+
+
+def test_precise_switch_keeps_the_fast_engines(golden):
+    """Engines are cached per mode: flipping the switch neither disturbs the fast path's results (bit-identical before / after) nor
+    reuses its arenas; a precise training step after a fused-Adam update repacks the split weights."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small")
+    _, vb, wrapper = build(g["cfg"], g["state"])
+
+    def run():
+        with rng_override(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"]):
+            return float(wrapper(g["x1"].to(dev)))
+
+    a = run()
+    with vbx.precise_mode():
+        p = run()
+    b = run()
+    assert a == b and abs(p - float(g["loss"])) < 2e-5 and vbx.precise_enabled() is False
+    with torch.no_grad():
+        for q in vb.parameters():
+            q.mul_(1.01)
+    with vbx.precise_mode():
+        p2 = run()
+    assert p2 != p  # the split weights were repacked from the updated parameters

@@ -61,7 +61,7 @@ static double run(int waves_per_simd, int n) {
   hipDeviceSynchronize();
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
-  g_tflops = (double)blocks * (threads / 64) * n * 65536.0 / (ms * 1e-3) * 1e-12;
+  g_tflops = (double)blocks * (threads / 64) * n * 32768.0 /* 2*32*32*16 FLOP per v_mfma_f32_32x32x16 */ / (ms * 1e-3) * 1e-12;
   std::vector<unsigned long long> h(blocks * 16);
   hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks * 16, hipMemcpyDeviceToHost);
   double tot = 0; int cnt = 0;
@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
     double t[6];
     run<1, false>(w, n); t[0] = g_tflops; run<2, false>(w, n); t[1] = g_tflops; run<4, false>(w, n); t[2] = g_tflops;
     run<1, true>(w, n); t[3] = g_tflops; run<2, true>(w, n); t[4] = g_tflops; run<4, true>(w, n); t[5] = g_tflops;
-    auto ns = [](double tf) { return 65536.0 * 1024.0 / (tf * 1e12) * 1e9; };
+    auto ns = [](double tf) { return 32768.0 * 1024.0 / (tf * 1e12) * 1e9; };
     printf("W=%d  MFMA only: C=1 %.0f (%.1f ns)  C=2 %.0f  C=4 %.0f (%.1f ns) | ds_read_b128 + lgkmcnt(0) before every 4*C MFMAs: C=1 %.0f (%.1f ns)  C=2 %.0f  C=4 %.0f\n",
            w, t[0], ns(t[0]), t[1], t[2], ns(t[2]), t[3], ns(t[3]), t[4], t[5]);
   }

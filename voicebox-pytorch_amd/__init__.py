@@ -11,9 +11,10 @@ try:  # model classes need torch; keep `_lib` importable on its own
     from .model import VoiceBox, ConditionalFlowMatcherWrapper, Transformer, Attend  # noqa: F401
     from .trainer import VoiceBoxTrainer  # noqa: F401
     from .duration import DurationPredictor  # noqa: F401
+    from .engine import precise_mode, set_precise, precise_enabled  # noqa: F401
 
     __all__ += ["VoiceBox", "ConditionalFlowMatcherWrapper", "Transformer", "Attend", "VoiceBoxTrainer", "DurationPredictor", "mask_from_frac_lengths",
-                "mask_from_start_end_indices", "prob_mask_like", "reduce_masks_with_and"]
+                "mask_from_start_end_indices", "prob_mask_like", "reduce_masks_with_and", "precise_mode", "set_precise", "precise_enabled"]
 except ModuleNotFoundError as _e:  # pragma: no cover - only while the package is being bootstrapped
     if "masks" not in str(_e) and "model" not in str(_e):
         raise

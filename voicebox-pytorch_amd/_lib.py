@@ -41,6 +41,7 @@ _PROTOS = {
     "vbx_attn_bwd": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P],
     "vbx_attn_bwd_fused": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P, P],
     "vbx_attn_bwd_select": [I],
+    "vbx_attn_bwd_variant": [],
     "vbx_dropout_bits_words": [I],
     "vbx_attn_dropout_bits": [P, P, I, I, C.c_ulonglong, C.c_uint, F, P],
     "vbx_dropout_rows": [P, P, L, I, I, C.c_ulonglong, C.c_uint, F, P],
@@ -96,6 +97,12 @@ _PROTOS = {
     "vbx_adam_step": [P, P, P, P, L, F, F, F, F, I, P, P],
     "vbx_sumsq": [P, L, P, P, P],
     "vbx_clip_coef": [P, F, F, P, P],
+    "vbx_split3_f16": [P, L, I, L, P, I, P],
+    "vbx_pack_weight3": [P, I, I, P, I, I, I, I, P],
+    "vbx_qknorm_rope_f32": [P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "vbx_attn_fwd_f32": [P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "vbx_geglu_f32": [P, P, P, P, P, L, I, P],
+    "vbx_adaln_proj_f32": [P, P, P, P, I, I, I, I, P],
     "vbx_probe_tr16": [P, P, P, P],
     "vbx_probe_mfma": [I, P, P, P, P],
 }
@@ -118,11 +125,11 @@ def lib():
     if not os.environ.get("VBX_LIB_PATH"):  # a library that was not rebuilt after a source edit must not be mistaken for the product
         from . import build as _build
 
-        rec = _build.recorded_hash()
-        if rec is None:  # a library without its stamp (copied on its own): cannot tell -- say so, do not refuse
+        rec, cur = _build.recorded_hash(), _build.source_hash()
+        if rec is None or cur is None:  # a library without its stamp, or shipped without csrc/: cannot tell -- say so, do not refuse
             import sys
             print(f"voicebox_pytorch_amd: {LIB_PATH} has no source-hash stamp; cannot check that it matches csrc/", file=sys.stderr)
-        elif rec != _build.source_hash():
+        elif rec != cur:
             raise VbxError(f"{LIB_PATH} is stale: csrc/ or include/vbx.h changed since it was built.  "
                            "Rebuild with `python voicebox-pytorch_amd/build.py`.")
     l = C.CDLL(LIB_PATH)

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvbx_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "gemm4.hip", "attn.hip", "norm.hip", "gateloop.hip", "ops.hip", "runtime.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "gemm4.hip", "attn.hip", "norm.hip", "gateloop.hip", "ops.hip", "precise.hip", "runtime.hip"]
 
 
 def _hipcc():
@@ -16,13 +16,23 @@ def _hipcc():
     return "hipcc"
 
 
+def _hashed_files():
+    """What the library is compiled from: the SOURCES, the headers / included bodies beside them, include/vbx.h -- not whatever
+    else sits in csrc/ (editor backups, sub-directories)."""
+    files = [os.path.join(CSRC, f) for f in SOURCES]
+    files += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc")))
+    return [f for f in files if os.path.isfile(f)] + [os.path.join(HERE, "..", "include", "vbx.h")]
+
+
 def source_hash():
-    """sha1 over everything the library is compiled from (csrc/* and include/vbx.h)."""
+    """sha1 over everything the library is compiled from; None when the sources are not there (an installed package that ships
+    the library without csrc/): "cannot verify", not an error."""
     import hashlib
 
+    if not os.path.isdir(CSRC):
+        return None
     h = hashlib.sha1()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "vbx.h")]
-    for f in files:
+    for f in _hashed_files():
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -47,6 +57,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    stamp = source_hash()  # before compiling: an edit made during the build must not be recorded as built
     objs = []
     procs = []
     for s in SOURCES:
@@ -71,7 +82,7 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(HASH_FILE, "w") as fh:
-        fh.write(source_hash() + "\n")
+        fh.write(stamp + "\n")
     return LIB
 
 

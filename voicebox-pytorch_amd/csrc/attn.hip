@@ -1690,6 +1690,7 @@ extern "C" int vbx_attn_bwd_select(int variant) {
   g_attn_bwd_variant = variant;
   return 0;
 }
+extern "C" int vbx_attn_bwd_variant(void) { return g_attn_bwd_variant == 2 ? 2 : 1; }  // the kernel vbx_attn_bwd runs when given scratch
 static inline size_t b1_sync_words(int B, int H, int Np) { return (size_t)B1_SYNC_HDR + (size_t)B * H * cdiv(Np, 64) * 4; }
 static inline size_t b1_acc_floats(int B, int H, int Np) { return (size_t)B * H * cdiv(Np, 64) * 4096; }
 extern "C" size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np) {

@@ -158,3 +158,18 @@ int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st);
 // 0: automatic choice per shape (default), 1: gemm.hip kernels only, 2: gemm3 wherever it can serve, 3: gemm4 wherever it can
 // serve (VBX_GEMM_PATH=<n> presets it; VBX_GEMM3=0 is the same as 1)
 int vbx_gemm_path();
+
+// precise.hip: the exact-operand forward (vbx_model.precise).  runtime.hip hands over the tensors of its own arenas that the
+// precise forward fills for the loss and for the (unchanged) backward; null pointers = not kept (inference).
+struct VbxPreciseLayer {
+  u16 *hn1, *q16, *k16, *qb, *kb, *v, *vh, *oh, *o, *hn2, *gh, *g, *h1;
+  float *qrn, *krn, *lse;
+  const float* b1;  // packed FeedForward[0] bias (wpack arena)
+};
+struct VbxPreciseActs {
+  float *four, *pre, *temb, *ada, *e, *pred, *per_b;
+  float* const* xs;  // 2L + 1 residual snapshots
+  const VbxPreciseLayer* layer;
+  u16 *embed_in_bf16, *embed_in_f16, *hf;
+};
+int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseActs* a, void* stream);

@@ -347,6 +347,11 @@ static int rmsnorm_fwd_launch(const float* x, const float* gamma, const float* b
   VBX_LAUNCH_CHECK();
   return 0;
 }
+// every output at once (precise.hip: fp32 rows for the hi/lo split + the bf16 copy the backward reads)
+int vbx_rmsnorm_fwd_multi(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16, void* y_f16,
+                          float* y_f32, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
+  return rmsnorm_fwd_launch(x, gamma, beta, gb_stride, y_bf16, y_f16, y_f32, B, Np, n0, rows_per_batch, D, stream);
+}
 extern "C" int vbx_rmsnorm_fwd(const float* x, const float* gamma, const float* beta, long gb_stride, void* y_bf16,
                                void* y_f16, int B, int Np, int n0, int rows_per_batch, int D, void* stream) {
   return rmsnorm_fwd_launch(x, gamma, beta, gb_stride, y_bf16, y_f16, nullptr, B, Np, n0, rows_per_batch, D, stream);

@@ -519,6 +519,17 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
   const long* G = m->off;
   const bool tr = m->training != 0;
 
+  if (m->precise) {  // exact-operand forward (precise.hip) into the same arenas: the backward entry points read them as usual
+    std::vector<VbxPreciseLayer> pl(d.L);
+    for (int l = 0; l < d.L; l++) {
+      const ALayer& y = a.layer[l];
+      pl[l] = VbxPreciseLayer{y.hn1, y.q16, y.k16, y.qb, y.kb, y.v, y.vh, y.oh, y.o, y.hn2, y.gh, y.g, tr ? y.h1 : nullptr,
+                              y.qrn, y.krn, y.lse, w.layer[l].b1};
+    }
+    VbxPreciseActs pa{a.four, a.pre, a.temb, a.ada, a.e, a.pred, a.per_b, a.xs.data(), pl.data(), a.embed_in, a.embed_inh, a.hf};
+    return vbx_forward_precise(m, io, &pa, stream);
+  }
+
   if (m->stack_only) {
     // standalone Transformer.forward: registers + x, the caller's condition drives the adaLN projections  (:417-431, :449-451)
     CK(vbx_stack_input(io->x, d.R ? P + G[VBX_P_REG] : nullptr, a.xs[0], d.B, d.N, d.R, d.D, stream));

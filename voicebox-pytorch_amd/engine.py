@@ -20,7 +20,8 @@ class VbxModel(C.Structure):
     _fields_ = [("B", I), ("N", I), ("R", I), ("D", I), ("H", I), ("F", I), ("Th", I), ("L", I), ("ksize", I),
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
-                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I)]
+                ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I),
+                ("precise", I), ("wpack3", P), ("pscratch", P)]
 
 
 class VbxIO(C.Structure):
@@ -32,6 +33,36 @@ class VbxIO(C.Structure):
 class VbxAdamSeg(C.Structure):
     _fields_ = [("off", C.c_long), ("count", C.c_long), ("dst_bf16", P), ("dst_f16", P), ("dst_f32", P),
                 ("cols", I), ("dst_ld", I), ("rowmap", I), ("F", I), ("block0", C.c_long)]
+
+
+# ---- exact-operand ("precise") mode switch (include/vbx.h "precise mode", csrc/precise.hip)
+import contextlib
+import os
+
+_precise = os.environ.get("VBX_PRECISE", "0") not in ("", "0")
+
+
+def precise_enabled():
+    return _precise
+
+
+def set_precise(on):
+    """Process-wide switch of the exact-operand forward: every forward matrix product to fp32 accuracy (hi/lo-split fp16 operands
+    K-concatenated through the same MFMA tiles, fp32 attention) at ~3-4x the forward time.  Engines are cached per mode, so the
+    switch may be flipped between calls.  Default: environment VBX_PRECISE (0)."""
+    global _precise
+    prev = _precise
+    _precise = bool(on)
+    return prev
+
+
+@contextlib.contextmanager
+def precise_mode(on=True):
+    prev = set_precise(on)
+    try:
+        yield
+    finally:
+        set_precise(prev)
 
 
 _runtime_protos_done = False
@@ -50,7 +81,11 @@ def _rt():
         l.vbx_model_adam_segments.restype = I
         l.vbx_adam_step_packed.argtypes = [P, P, P, P, P, I, C.c_long, F, F, F, F, I, P, P]
         l.vbx_adam_step_packed.restype = I
-        for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
+        l.vbx_model_precise_wpack_bytes.argtypes = [MP]
+        l.vbx_model_precise_wpack_bytes.restype = C.c_size_t
+        l.vbx_model_precise_scratch_bytes.argtypes = [MP]
+        l.vbx_model_precise_scratch_bytes.restype = C.c_size_t
+        for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_pack_weights_precise", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
                          ("vbx_model_backward_head", [MP, IP, P, P]), ("vbx_model_backward_layer", [MP, IP, I, P]),
                          ("vbx_model_backward_embed", [MP, IP, P])):
             fn = getattr(l, name)
@@ -153,7 +188,6 @@ class FlatParams:
         write changes neither p._version nor flat._version and the engines (and the hipGraph samplers that hold them) would keep
         serving the previous fp16 / bf16 packed copies.  Public spelling: VoiceBox.mark_weights_dirty()."""
         self.epoch += 1
-        self._key_cache = None
 
     def weights_key(self):
         """Changes whenever any parameter value may have changed.  The nn.Parameters are `p.data = view` tensors with their OWN
@@ -163,16 +197,6 @@ class FlatParams:
         for s in self.order:
             ver += self.slots[s]._version
         return (self.flat.data_ptr(), self.flat._version, self.epoch, ver)
-
-    def weights_key_cached(self, token):
-        """weights_key() is an O(#parameters) Python loop; callers that evaluate it several times with nothing in between that can
-        write a parameter (the slot engines of one sampler call, bind_params right after adam_step_packed) pass the same `token`
-        and get the first evaluation back."""
-        kc = getattr(self, "_key_cache", None)
-        if kc is None or kc[0] is not token:
-            kc = (token, self.weights_key())
-            self._key_cache = kc
-        return kc[1]
 
     def offset_table(self):
         tab = (C.c_long * (NG + self.depth * NL))()
@@ -191,10 +215,12 @@ class Engine:
     """One (batch, frames, training) configuration of a VoiceBox on one GPU: owns the packed-weight and
     activation arenas and issues the native stage calls on the current HIP stream."""
 
-    def __init__(self, cfg, flat: FlatParams, B, N, training, device, wpack_from=None):
+    def __init__(self, cfg, flat: FlatParams, B, N, training, device, wpack_from=None, precise=False):
         """wpack_from: another Engine of the same model whose packed-weight arena this one shares (the arena depends on the
-        architecture only): the concurrent half-batch engines of the sampler keep ONE copy of the operand weights."""
+        architecture only): the concurrent half-batch engines of the sampler keep ONE copy of the operand weights.
+        precise: the exact-operand forward (csrc/precise.hip): two more arenas (split weights, fp32 intermediates)."""
         self.cfg, self.fp, self.B, self.N, self.training, self.device = cfg, flat, B, N, bool(training), device
+        self.precise = bool(precise)
         self.wpack_owner = wpack_from
         _lib.call("vbx_check_device", device.index if device.index is not None else torch.cuda.current_device())
         l = _rt()
@@ -226,6 +252,15 @@ class Engine:
             self.wpack = torch.empty(l.vbx_model_wpack_bytes(C.byref(m)), dtype=torch.uint8, device=device)
         self.act = torch.empty(l.vbx_model_act_bytes(C.byref(m)), dtype=torch.uint8, device=device)
         m.wpack, m.act = self.wpack.data_ptr(), self.act.data_ptr()
+        self.packed3_version = None
+        if self.precise:
+            if wpack_from is not None:
+                assert wpack_from.precise
+                self.wpack3 = wpack_from.wpack3
+            else:
+                self.wpack3 = torch.empty(l.vbx_model_precise_wpack_bytes(C.byref(m)), dtype=torch.uint8, device=device)
+            self.pscratch = torch.empty(l.vbx_model_precise_scratch_bytes(C.byref(m)), dtype=torch.uint8, device=device)
+            m.precise, m.wpack3, m.pscratch = 1, self.wpack3.data_ptr(), self.pscratch.data_ptr()
         self.packed_version = None
         self.io = VbxIO()
         self._keep = None
@@ -243,6 +278,9 @@ class Engine:
         if key != self.packed_version:
             _check(_rt().vbx_model_pack_weights(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights")
             self.packed_version = key
+        if self.precise and key != self.packed3_version:  # the fused Adam refreshes the plain copies only: repack the split ones
+            _check(_rt().vbx_model_pack_weights_precise(C.byref(self.m), _lib.current_stream()), "vbx_model_pack_weights_precise")
+            self.packed3_version = key
 
     # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
     def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale):

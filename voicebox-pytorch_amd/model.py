@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .engine import Engine, FlatParams
+from .engine import Engine, FlatParams, precise_enabled
 from .masks import mask_from_frac_lengths, prob_mask_like, reduce_masks_with_and, take_draw
 
 
@@ -75,7 +75,9 @@ class _AttendFn(torch.autograd.Function):
             _lib.call("vbx_attn_bwd_dropout", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
                       H * 64, B, H, Np, ctx.scale, rm, cm, ctx.drop_p, _lib.current_stream())
         else:
-            scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward
+            scratch = None  # the default two-body kernel needs none; the one-pass chain kernel: flags + running dq sums (~36 MB)
+            if _lib.lib().vbx_attn_bwd_variant() == 2:
+                scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)
             _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
                       H * 64, B, H, Np, ctx.scale, scratch, _lib.current_stream())
         dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
@@ -348,6 +350,7 @@ class _VoiceBoxLossFn(torch.autograd.Function):
     def forward(ctx, vb, eng, x, cond, cond_mask, times, attn_mask, target, loss_mask, text, *params):
         loss = eng.forward(x, cond, cond_mask, times, attn_mask=attn_mask, target=target, loss_mask=loss_mask, text=text)
         ctx.vb, ctx.eng, ctx.gen = vb, eng, eng.generation
+        ctx.wkey = (eng.wpack_owner or eng).packed_version  # the operand copies this forward ran on (shared by the slot engines)
         ctx.token = _InFlight()           # dies with the autograd graph: the arena is free again when nobody can call backward
         eng._in_flight = weakref.ref(ctx.token)
         return loss.clone().reshape(())
@@ -358,6 +361,11 @@ class _VoiceBoxLossFn(torch.autograd.Function):
         if eng.generation != ctx.gen:
             raise RuntimeError("VoiceBox: two later forwards of the same (batch, frames) shape ran before this backward; the two "
                                "activation arenas of a shape hold the two most recent training forwards")
+        if (eng.wpack_owner or eng).packed_version != ctx.wkey:
+            # the reference's autograd raises "modified by an inplace operation" here; with two arenas sharing one set of packed
+            # weights a later forward would otherwise silently hand this backward the NEW bf16 weights beside the OLD activations
+            raise RuntimeError("VoiceBox: parameters were modified (and re-packed by a later forward) between this forward and its "
+                               "backward; run backward before updating the weights")
         gflat = torch.zeros(vb._flat.numel, dtype=torch.float32, device=eng.device)
         gscale = gloss.detach().to(torch.float32).reshape(1).contiguous()
         eng.backward(gflat, gscale=gscale)
@@ -449,7 +457,12 @@ class VoiceBox(nn.Module):
         if dev.type != "cuda":
             raise _lib.VbxError("VoiceBox compute runs only on an MI355X (gfx950) through libvbx_hip.so; "
                                 f"parameters are on '{dev}' and there is no CPU fallback")
-        key = (B, N, bool(training)) if slot == 0 else (B, N, bool(training), slot)
+        precise = precise_enabled()
+        if precise and (self._cfg.get("gateloop") or self._cfg.get("E") or self._cfg["attn_dropout"] > 0. or self._cfg["ff_dropout"] > 0.):
+            raise NotImplementedError("precise mode serves the unconditional VoiceBox (no GateLoop / text conditioning / dropout)")
+        # key[2] carries the mode: 0/1 = inference/training on the fast path, 2/3 = the same in precise mode (own arenas)
+        tkey = int(bool(training)) + (2 if precise else 0)
+        key = (B, N, tkey) if slot == 0 else (B, N, tkey, slot)
         eng = self._engines.get(key)
         if eng is not None and eng.wpack_owner is not wpack_from:
             eng = None
@@ -463,7 +476,7 @@ class VoiceBox(nn.Module):
                 victim = next(k for k in owners if self._engines[k] is not wpack_from)
                 for k in [k for k in self._engines if k[:3] == victim]:
                     self._engines.pop(k)
-            eng = Engine(self._cfg, fp, B, N, training, dev, wpack_from=wpack_from)
+            eng = Engine(self._cfg, fp, B, N, training, dev, wpack_from=wpack_from, precise=precise)
             self._engines[key] = eng
         eng.dropout_active = self.training  # nn.Dropout semantics (attend.py:131, voicebox_pytorch.py:346): the module's mode
         return eng
@@ -645,7 +658,7 @@ class ConditionalFlowMatcherWrapper(nn.Module):
         y0 = torch.randn_like(cond) if y0 is None else y0.to(dev, torch.float32)
         B, N, _ = cond.shape
         T = cond_token_ids.shape[-1] if exists(cond_token_ids) else 0
-        key = (B, N, steps, bool(use_graph), T, float(cond_scale) != 1.)
+        key = (B, N, steps, bool(use_graph), T, float(cond_scale) != 1., precise_enabled())
         fp = self.voicebox.flat_params()
         # a re-flatten (.to(), dtype change) frees the buffer whose addresses the cached hipGraphs captured: drop them
         self._samplers = {k: s for k, s in self._samplers.items() if s.flat_gen == fp.flat_gen and s.eng.fp is fp}

@@ -98,6 +98,7 @@ class MidpointSampler:
 
     def _bind(self, p, x):
         # point the part's engine at the static buffers (x = y or ymid), prediction written to p.f
+        p.eng.dropout_active = False  # sampling is eval (:1268) whatever mode a later forward of the same shape left on the engine
         if not self.tokens:
             p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f)
             return
