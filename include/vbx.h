@@ -464,15 +464,16 @@ void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer);
  * std ~80, a chaotic 12-layer map) that moves the loss by O(1e-3).  With vbx_model.precise = 1 vbx_model_forward evaluates
  * the same VoiceBox.forward (voicebox_pytorch.py:987-1115) with every matrix product to fp32 accuracy:
  *  - nn.Linear (:320,333,345,348,1078,1092): the same vbx_gemm tiles with both operands split into fp16 hi + lo parts and concatenated
- *    along K -- A' = [A_hi | A_hi | A_lo] (vbx_split3_f16), W' = [W_hi | W_lo | W_hi] (vbx_pack_weight3), K' = 3K, VBX_EPI_F32;
+ *    along K -- A' = [A_hi | A_hi 2^-8 | A_lo 2^8] (vbx_split3_f16), W' = [W_hi | W_lo 2^8 | W_hi 2^-8] (vbx_pack_weight3), K' = 3K,
+ *    VBX_EPI_F32 (the powers of two keep the lo parts of small weights out of the fp16 subnormals);
  *  - MultiheadRMSNorm + rotary (:286-287,193-199, 323-328) and GEGLU (:338-340) as fp32 kernels on the fp32 GEMM results
  *    (vbx_qknorm_rope_f32, vbx_geglu_f32), which also write the fp16 / bf16 copies the backward entry points read;
  *  - Attend (attend.py:121-135) as an fp32 FMA flash kernel (vbx_attn_fwd_f32), q / k / v / P never rounded;
  *  - AdaptiveRMSNorm's to_gamma / to_beta (:273) from the fp32 master weights (vbx_adaln_proj_f32).
  * Serves the unconditional model (E == 0, no GateLoop, no dropout); other configurations return VBX_EINVAL. */
-/* dst fp16 [rows, 3*Kp] = [hi | hi | lo] of src fp32 [rows, K] (row stride ld floats), columns K..Kp zero; Kp % 8 == 0 */
+/* dst fp16 [rows, 3*Kp] = [hi | hi 2^-8 | lo 2^8] of src fp32 [rows, K] (row stride ld floats), columns K..Kp zero; Kp % 8 == 0 */
 int vbx_split3_f16(const float* src, long rows, int K, long ld, void* dst_f16, int Kp, void* stream);
-/* dst fp16 [dst_rows, 3*dst_cols] = [hi | lo | hi] of the weight, rows mapped / padded as vbx_pack_weight does */
+/* dst fp16 [dst_rows, 3*dst_cols] = [hi | lo 2^8 | hi 2^-8] of the weight, rows mapped / padded as vbx_pack_weight does */
 int vbx_pack_weight3(const float* src, int src_rows, int src_cols, void* dst_f16, int dst_rows, int dst_cols, int rowmap, int F,
                      void* stream);
 /* raw fp32 [B*Np, 3*H*64] (to_qkv output) -> q, k (qk-normed when qk_scale > 0, rotated) and v, head-major [B,H,Np,64]: fp32 plus the

@@ -778,6 +778,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v3_drop(const u16* __r
 }
 #undef VBX_FWD_DROP
 
+#include "attn_fwd_v4.inc"
+
 // (Round 1 wrote a "ragged tile" role for this kernel -- the 128 workgroups per launch whose query tile holds only the 16
 //  register-token rows split their KEYS over the four waves with private tiles straight from global memory.  Round 2 ran it:
 //  correct (tests/test_ops_gpu.py -k attn_fwd), but the 128-forward sample got SLOWER, 349.8 -> 357.1 ms in the same run, so it
@@ -1640,6 +1642,24 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
+  static const int v4 = getenv("VBX_ATTN_V4") ? atoi(getenv("VBX_ATTN_V4")) : 1;  // 0: A/B against v3 (four single-chain waves per SIMD)
+  if (v4 && !legacy && !abl && !abl2) {  // 256-row tiles, two query blocks per wave, two workgroups per CU
+    const int tiles4 = (Np >> 8) + ((Np & 255) ? 1 : 0);
+#define VBX_FWD4(V)                                                                                                                \
+    {                                                                                                                              \
+      static bool attr4 = false;                                                                                                   \
+      if (!attr4) {                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel_v4<V>), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS); \
+        attr4 = true;                                                                                                              \
+      }                                                                                                                            \
+      hipLaunchKernelGGL(attn_fwd_kernel_v4<V>, dim3(tiles4 * cdiv(BH, 8) * 8), dim3(256), A4_LDS, (hipStream_t)stream, (const u16*)q16, \
+                         (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH);          \
+    }
+    if (v4 == 2) VBX_FWD4(2) else if (v4 == 3) VBX_FWD4(3) else VBX_FWD4(1)
+#undef VBX_FWD4
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   if (v3 && !legacy && !abl && !abl2) {
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);

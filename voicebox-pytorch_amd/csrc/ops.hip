@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void convpos_fwd_kernel(const float* __restric
     if (MODE == 0) {
       // residual uses the UNMASKED e (voicebox_pytorch.py:1080 adds x, conv masks internally)
       const float ev = e[((long)b * N + n) * D + d];
-      out[((long)b * Np + R + n) * D + d] = ev + (m ? gelu_erf(acc) : 0.f);
+      out[((long)b * Np + R + n) * D + d] = ev + (m ? gelu_erf_libm(acc) : 0.f);
     } else {
       const float g = dxs[((long)b * Np + R + n) * D + d];
       out[((long)b * N + n) * D + d] = m ? g * gelu_erf_grad(acc) : 0.f;

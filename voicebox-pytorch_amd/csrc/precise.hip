@@ -7,7 +7,8 @@
 //
 //  * every forward GEMM runs through the SAME vbx_gemm tiles (fp16 MFMA, fp32 accumulate) with both operands split into
 //    fp16 hi + lo parts and concatenated along K:   A' = [A_hi | A_hi | A_lo],  W' = [W_hi | W_lo | W_hi],  K' = 3K, so that
-//    A'.W'^T = A_hi W_hi + A_hi W_lo + A_lo W_hi  (the dropped A_lo W_lo term is 2^-22 relative).  fp16 x fp16 products are exact in
+//    A'.W'^T = A_hi W_hi + A_hi W_lo + A_lo W_hi  (the dropped A_lo W_lo term is 2^-22 relative; the lo segments carry a
+//    factor 2^8 and their partners 2^-8 so that no lo part is an fp16 subnormal, see split_hi_lo).  fp16 x fp16 products are exact in
 //    the MFMA's fp32 accumulator, hence the result carries ~22 operand bits -- fp32-class -- at 3x the MFMA work;
 //  * what the fused QKV / GEGLU epilogues do on fp16 outputs is done here by small fp32 kernels on the fp32 GEMM result
 //    (qk-norm + rotary, erf-GELU gate), which also write the fp16 / bf16 copies the (unchanged, bf16-operand) backward reads;
@@ -33,12 +34,19 @@ inline int grid_for(long n, int cap = 8192) {
   return (int)(b > cap ? cap : b);
 }
 
-VBX_DEV void split_hi_lo(float v, u16& hi, u16& lo) {
+// v = hi + lo with hi = fp16(v) and lo = v - hi (exact in fp32), stored as fp16(lo * 2^8): unscaled, the lo part of an nn.Linear
+// weight (|w| <= K^-0.5: lo ~ 2^-11 w ~ 1e-5) is an fp16 SUBNORMAL and the pair carries 19 bits instead of 22.  The product terms
+// are unchanged because the partner segment carries 2^-8: A' = [A_hi | A_hi 2^-8 | A_lo 2^8], W' = [W_hi | W_lo 2^8 | W_hi 2^-8].
+// (The 2^-8 copies of the hi parts only meet lo parts, so what they lose to underflow is <= 2^-16 * |lo| absolute: nothing.)
+constexpr float P3_UP = 256.0f, P3_DOWN = 1.0f / 256.0f;
+VBX_DEV void split_hi_lo(float v, u16& hi, u16& hi_dn, u16& lo_up) {
   hi = f32_to_f16_sat(v);
-  lo = f32_to_f16_sat(v - f16_to_f32(hi));  // exact difference (Sterbenz), then one rounding: hi + lo carries ~22 bits of v
+  const float h = f16_to_f32(hi);
+  hi_dn = f32_to_f16(h * P3_DOWN);
+  lo_up = f32_to_f16_sat((v - h) * P3_UP);
 }
 
-// dst [rows, 3*Kp] = [hi | hi | lo] of src [rows, K] (row stride ld), columns K..Kp zero
+// dst [rows, 3*Kp] = [hi | hi 2^-8 | lo 2^8] of src [rows, K] (row stride ld), columns K..Kp zero
 __global__ void split3_kernel(const float* __restrict__ src, long rows, int K, long ld, u16* __restrict__ dst, int Kp) {
   const int cpr = Kp / 4;
   const long total = rows * cpr;
@@ -53,19 +61,20 @@ __global__ void split3_kernel(const float* __restrict__ src, long rows, int K, l
       for (int e = 0; e < 4; e++)
         if (c + e < K) v[e] = src[r * ld + c + e];
     }
-    u16 h[4], l[4];
+    u16 h[4], hd[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) split_hi_lo(v[e], h[e], l[e]);
+    for (int e = 0; e < 4; e++) split_hi_lo(v[e], h[e], hd[e], l[e]);
     const uint2 hv = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    const uint2 dv = make_uint2((unsigned)hd[0] | ((unsigned)hd[1] << 16), (unsigned)hd[2] | ((unsigned)hd[3] << 16));
     const uint2 lv = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
     u16* d = dst + r * 3 * (long)Kp + c;
     *reinterpret_cast<uint2*>(d) = hv;
-    *reinterpret_cast<uint2*>(d + Kp) = hv;
+    *reinterpret_cast<uint2*>(d + Kp) = dv;
     *reinterpret_cast<uint2*>(d + 2 * Kp) = lv;
   }
 }
 
-// dst [dst_rows, 3*dst_cols] = [hi | lo | hi] of the (row-mapped, zero-padded) weight, same row map as pack_weight_kernel
+// dst [dst_rows, 3*dst_cols] = [hi | lo 2^8 | hi 2^-8] of the (row-mapped, zero-padded) weight, same row map as pack_weight_kernel
 __global__ void pack_weight3_kernel(const float* __restrict__ src, int src_rows, int src_cols, u16* __restrict__ dst, int dst_rows,
                                     int dst_cols, int rowmap, int F) {
   const long total = (long)dst_rows * dst_cols;
@@ -75,12 +84,12 @@ __global__ void pack_weight3_kernel(const float* __restrict__ src, int src_rows,
     if (rowmap == 1) r = geglu_row_unmap(p, F);
     float v = 0.f;
     if (r >= 0 && r < src_rows && c < src_cols) v = src[(long)r * src_cols + c];
-    u16 hi, lo;
-    split_hi_lo(v, hi, lo);
+    u16 hi, hi_dn, lo_up;
+    split_hi_lo(v, hi, hi_dn, lo_up);
     u16* d = dst + (long)p * 3 * dst_cols + c;
     d[0] = hi;
-    d[dst_cols] = lo;
-    d[2 * dst_cols] = hi;
+    d[dst_cols] = lo_up;
+    d[2 * dst_cols] = hi_dn;
   }
 }
 
