@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="train mode: skip the 64-interval sample leg")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
     ap.add_argument("--bucket-mb", type=int, default=0, help="gradient all-reduce bucket size in MiB (0: the library default)")
+    ap.add_argument("--grad-mode", default="allreduce", choices=["allreduce", "shard"],
+                    help="N > 1: all-reduce + replicated optimizer (DDP semantics) or reduce-scatter + sharded clip / Adam + parameter all-gather")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -285,7 +287,8 @@ def main():
         from voicebox_pytorch_amd.dp import TrainStep
 
         kw = {"bucket_bytes": args.bucket_mb << 20} if args.bucket_mb > 0 else {}
-        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None, **kw)
+        ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None,
+                       grad_mode=args.grad_mode, **kw)
         step = lambda: ts.step(x)
         units_per_step = args.batch * args.frames
         flops_per_step_per_gpu = 3.0 * fwd_flops_per_frame(args.dim, args.depth, args.heads, args.frames, 16) * units_per_step
@@ -353,6 +356,7 @@ def main():
             except Exception as e:  # noqa: BLE001  (diagnostic field only)
                 out["rccl_version"] = f"unavailable ({type(e).__name__})"
             out["grad_comm"] = args.grad_comm
+            out["grad_mode"] = args.grad_mode
             out["bucket_mb"] = args.bucket_mb
         if loss_val is not None:
             out["final_loss"] = round(loss_val, 5)

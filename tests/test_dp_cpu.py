@@ -164,3 +164,83 @@ def test_last_bucket_is_small_and_staging_is_persistent():
     assert v1.dtype == torch.bfloat16 and v1.untyped_storage().data_ptr() == v2.untyped_storage().data_ptr()
     red2 = GradBucketReducer(g, ranges, bucket_bytes=64 << 20, comm_dtype=torch.bfloat16, stage_buf=red1.stage_buf)
     assert red2._stage(*ranges[2]).untyped_storage().data_ptr() == v1.untyped_storage().data_ptr()
+
+
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from voicebox_pytorch_amd.dp import GradBucketReducer
+
+    # a flat buffer in this package's layout (64-float slots), three stages; rank-specific gradients
+    bounds = [0, 64 * 5, 64 * 5 + 64 * 40, 64 * 5 + 64 * 40 + 64 * 7]
+    ranges = [(bounds[i], bounds[i + 1]) for i in range(3)]
+    n = bounds[-1]
+    gen = torch.Generator().manual_seed(100 + rank)
+    g_local = torch.randn(n, generator=gen)
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(7))
+    lr, b1, b2, eps, max_norm = 1e-3, 0.9, 0.99, 1e-8, 0.5
+
+    def adam(p, g, m, v, coef):  # torch.optim.Adam, step 1, gradient pre-multiplied by the clip coefficient
+        gr = g * coef
+        m.mul_(b1).add_(gr, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+        p.sub_(lr / (1 - b1) * m / (v.sqrt() / (1 - b2) ** 0.5 + eps))
+
+    def clip_coef(sumsq):
+        norm = sumsq.sqrt() / world
+        return torch.clamp(max_norm / (norm + 1e-6), max=1.0) / world
+
+    # A: replicated (all-reduce, every rank updates everything)
+    gA = g_local.clone()
+    redA = GradBucketReducer(gA, ranges, bucket_bytes=64 * 30 * 4)
+    for i, rng in enumerate(ranges):
+        redA.stage_done(i, rng)
+    redA.finish()
+    # B: sharded (reduce-scatter, chunk owners update, all-gather)
+    gB = g_local.clone()
+    redB = GradBucketReducer(gB, ranges, bucket_bytes=64 * 30 * 4, shard=True)
+    for i, rng in enumerate(ranges):
+        redB.stage_done(i, rng)
+    redB.finish()
+    assert redB.buckets_launched == redA.buckets_launched and len(redB.owned) == len(redB.buckets_launched)
+    own_ok = all(torch.equal(gB[lo:hi], gA[lo:hi]) for lo, hi in redB.owned)  # the owned chunk holds the all-reduce's sum, bit for bit
+    part = torch.stack([gB[lo:hi].pow(2).sum() for lo, hi in redB.owned]).sum().reshape(1)
+    allp = torch.zeros(world)
+    dist.all_gather_into_tensor(allp, part)
+    coefB = clip_coef(allp.sum())
+    coefA = clip_coef(gA.pow(2).sum())
+    pA, mA, vA = p0.clone(), torch.zeros(n), torch.zeros(n)
+    adam(pA, gA, mA, vA, coefB)  # the same coefficient: the update itself must then be bit-identical
+    pB, mB, vB = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for lo, hi in redB.owned:
+        adam(pB[lo:hi], gB[lo:hi], mB[lo:hi], vB[lo:hi], coefB)
+    redB.all_gather(pB)
+    redB.all_gather(mB)
+    redB.all_gather(vB)
+    covered = sum(hi - lo for lo, hi in redB.owned)
+    if rank == 0:
+        out.put((own_ok, torch.equal(pA, pB), torch.equal(mA, mB) and torch.equal(vA, vB), float(abs(coefA - coefB) / coefA), covered, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_equals_replicated_bit_for_bit():
+    """grad_mode="shard" (reduce-scatter -> owners clip / Adam their 1 / world -> all-gather) against the replicated exchange, gloo
+    world 2, fp32: the owned chunks hold the all-reduce's sums bit for bit, the gathered parameters and moments equal the replicated
+    update bit for bit given the clip coefficient, and the coefficient itself (a sum of chunk partials in rank order instead of one
+    sum) agrees to fp32 rounding."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    own_ok, p_same, mv_same, dcoef, covered, n = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert own_ok and p_same and mv_same
+    assert dcoef < 1e-6, dcoef
+    assert covered * 2 == n  # each rank owns exactly half of the flat buffer

@@ -32,7 +32,7 @@ def _draws(seed, B, N, D):
                 frac_lengths=0.7 + 0.3 * torch.rand(B, generator=g), rand=torch.rand(B, generator=g))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, grad_mode="allreduce"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,7 +48,7 @@ def _worker(rank, world, port, out):
     vb.load_state_dict(state, strict=False)
     vb = vb.to("cuda:0")
     wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
-    ts = TrainStep(wrapper, lr=1e-3, max_grad_norm=0.5, bucket_bytes=1 << 16)  # small buckets: several async all-reduces
+    ts = TrainStep(wrapper, lr=1e-3, max_grad_norm=0.5, bucket_bytes=1 << 16, grad_mode=grad_mode)  # small buckets: several async collectives
     B, N, D = 2, 72, 128
     shards = [_draws(100 + r, B, N, D) for r in range(world)]
     mine = shards[rank]
@@ -58,6 +58,7 @@ def _worker(rank, world, port, out):
     torch.cuda.synchronize()
     g_reduced = ts.gflat.clone() / world
     p_after = ts.fp.flat.clone()
+    owned = list(ts._red.owned) if grad_mode == "shard" else None  # shard mode: only the owned chunks hold the sum
     # parameters must be identical on both ranks after the step
     gathered = [torch.zeros_like(p_after) for _ in range(world)]
     dist.all_gather(gathered, p_after)
@@ -79,9 +80,12 @@ def _worker(rank, world, port, out):
                 o = fp2.offsets[slot]
                 acc[o:o + prm.numel()] += prm.grad.flatten()
         ref = acc / world
-        err = float((g_reduced - ref).abs().max())
+        if owned is None:
+            err = float((g_reduced - ref).abs().max())
+        else:
+            err = max(float((g_reduced[lo:hi] - ref[lo:hi]).abs().max()) for lo, hi in owned)
         scale = float(ref.abs().max())
-        out.put((err, scale, same, float(loss), float((p_after - p_before).abs().max())))
+        out.put((err, scale, same, float(loss), float((p_after - p_before).abs().max()), p_after.cpu()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,7 +163,7 @@ def test_train_step_world2_on_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    err, scale, same, loss, moved = out.get(timeout=600)
+    err, scale, same, loss, moved, _ = out.get(timeout=600)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -167,6 +171,29 @@ def test_train_step_world2_on_one_gpu():
     assert err <= 1e-6 * max(scale, 1e-6) + 1e-9, (err, scale)
     assert moved > 0 and moved < 2e-3  # Adam moved every weight by at most ~lr
     assert 1.0 < loss < 10.0
+
+
+def test_train_step_shard_mode_equals_allreduce_mode_world2_on_one_gpu():
+    """TrainStep(grad_mode="shard"): reduce-scatter of the buckets, clip + Adam on the owned chunks, all-gather of the parameters -- the
+    same step as the all-reduce mode (identical parameters on both ranks, gradients of the owned chunks = the full-batch gradient,
+    updated parameters equal to the all-reduce mode's up to the summation order of the gradient norm)."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for mode in ("allreduce", "shard"):
+        out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out, mode)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[mode] = out.get(timeout=600)
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+    err, scale, same, loss, moved, p_shard = res["shard"]
+    assert same, "ranks diverged in shard mode"
+    assert err <= 1e-6 * max(scale, 1e-6) + 1e-9, (err, scale)
+    d = float((p_shard - res["allreduce"][5]).abs().max())
+    assert d < 2e-7, d  # one Adam step of size ~lr = 1e-3: the clip coefficient differs in the last fp32 bits only
 
 
 def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):

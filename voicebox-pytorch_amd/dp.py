@@ -25,8 +25,14 @@ class GradBucketReducer:
     bound) so buckets are large: whole backward stages are merged until `bucket_bytes` is reached."""
 
     def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None, comm_dtype=None, tail_bytes=16 << 20,
-                 stage_buf=None):
+                 stage_buf=None, shard=False):
+        """shard=True: every bucket is REDUCE-SCATTERED instead of all-reduced -- rank r ends up with the sum of chunk r (1 / world
+        of the bucket, in place) and `owned` lists the flat ranges this rank must clip / Adam before all-gathering the updated
+        parameters (TrainStep(grad_mode="shard")): the optimizer's HBM traffic and arithmetic drop by the world size; the wire
+        carries the same bytes as a ring all-reduce (whose two halves these are)."""
         self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
+        self.shard = bool(shard)
+        self.owned = []
         # The LAST bucket cannot overlap any backward work (nothing is left to run), so it must be small: as soon as what remains
         # to be produced fits `tail_bytes`, the pending stages are flushed instead of being merged with the tail.  With the model's
         # stage order (head, layer L-1 .. 0, embed + time MLP) only the embed stage (a few MB) is exchanged un-overlapped; before,
@@ -41,16 +47,43 @@ class GradBucketReducer:
         # VBX_FORCE_DIST=1: issue the collectives even at world size 1 (exercises the RCCL path -- comm stream, async work,
         # record_stream -- on a single GPU; an all-reduce over one rank is the identity)
         self.active = self.world > 1 or (force_dist() and dist.is_available() and dist.is_initialized())
+        self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         self.comm_stream = comm_stream
         self.pending_lo = None
         self.pending_hi = None
         self.works = []
         self.buckets_launched = []
 
+    def chunk_of(self, lo, hi, r=None):
+        """Rank r's chunk of bucket [lo, hi): equal parts (flat slots and stage boundaries are multiples of 64 floats, so a bucket
+        divides by any world size up to 64; a remainder, if ever, goes to the last rank)."""
+        r = self.rank if r is None else r
+        n = (hi - lo) // self.world
+        return lo + r * n, (hi if r == self.world - 1 else lo + (r + 1) * n)
+
+    def _collective(self, view, lo, hi):
+        if not self.shard:
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        n = (hi - lo) // self.world
+        if n * self.world != hi - lo:  # (never with this package's flat layout) uneven: all-reduce, every rank keeps its chunk
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        out = view[self.rank * n:(self.rank + 1) * n]  # in place: the output is this rank's slice of the input
+        if not GradBucketReducer._no_reduce_scatter:
+            try:
+                return dist.reduce_scatter_tensor(out, view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            except RuntimeError:  # a backend without it for this tensor type (gloo on device tensors): same result, more bytes
+                GradBucketReducer._no_reduce_scatter = True
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    _no_reduce_scatter = False
+    _no_all_gather = False
+
     def _launch(self, lo, hi):
         if hi <= lo:
             return
         self.buckets_launched.append((lo, hi))
+        if self.shard:
+            self.owned.append(self.chunk_of(lo, hi))
         if not self.active:
             return
         view = self.g[lo:hi]
@@ -61,11 +94,11 @@ class GradBucketReducer:
                 self.comm_stream.wait_event(ev)
                 if self.comm_dtype is not None:
                     view = self._stage(lo, hi)
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.works.append(self._collective(view, lo, hi))
         else:
             if self.comm_dtype is not None:
                 view = self._stage(lo, hi)
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.works.append(self._collective(view, lo, hi))
 
     def _stage(self, lo, hi):
         if self.stage_buf is None or self.stage_buf.dtype != self.comm_dtype or self.stage_buf.numel() < self.g.numel():
@@ -98,8 +131,39 @@ class GradBucketReducer:
             w.wait()  # makes the current stream wait for the collective
         self.works = []
         for lo, hi, buf in self.staged:  # decompress the reduced buckets back into the fp32 gradient buffer
-            self.g[lo:hi].copy_(buf)   # (the staging buffer is persistent and owned by the caller: no record_stream needed)
+            if self.shard and self.active:  # only this rank's chunk holds the sum
+                clo, chi = self.chunk_of(lo, hi)
+                self.g[clo:chi].copy_(buf[clo - lo:chi - lo])
+            else:
+                self.g[lo:hi].copy_(buf)   # (the staging buffer is persistent and owned by the caller: no record_stream needed)
         self.staged = []
+
+    def all_gather(self, flat):
+        """shard mode, after the owners updated their chunks of `flat` (the parameters): every bucket's chunks are all-gathered in
+        place (rank r's input is its own slice of the output), on the communication stream when there is one."""
+        if not (self.shard and self.active):
+            return
+        works = []
+        for lo, hi in self.buckets_launched:
+            n = (hi - lo) // self.world
+            view = flat[lo:hi]
+            if n * self.world != hi - lo:
+                for r in range(self.world):  # uneven (never with this layout): broadcast every chunk from its owner
+                    clo, chi = self.chunk_of(lo, hi, r)
+                    works.append(dist.broadcast(flat[clo:chi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                                group=self.group, async_op=True))
+                continue
+            if not GradBucketReducer._no_all_gather:
+                try:
+                    works.append(dist.all_gather_into_tensor(view, view[self.rank * n:(self.rank + 1) * n], group=self.group, async_op=True))
+                    continue
+                except RuntimeError:
+                    GradBucketReducer._no_all_gather = True
+            for r in range(self.world):
+                works.append(dist.broadcast(view[r * n:(r + 1) * n], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                            group=self.group, async_op=True))
+        for w in works:
+            w.wait()
 
 
 class WarmupCosineLR:
@@ -134,7 +198,14 @@ class WarmupCosineLR:
 
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
-                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0., length_bucket=0):
+                 bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0., length_bucket=0,
+                 grad_mode="allreduce"):
+        """grad_mode: "allreduce" (DDP's exchange: every rank holds the summed gradient and runs the whole optimizer) or "shard"
+        (reduce-scatter the buckets, each rank clips / Adams its 1 / world of the flat buffers, all-gather the updated fp32
+        parameters, repack the operand copies in one pass): same results up to the summation order of the gradient norm, the
+        optimizer's 3.3 GB of HBM traffic per step divided by the world size."""
+        assert grad_mode in ("allreduce", "shard"), grad_mode
+        self.grad_mode = grad_mode
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         # wd > 0: AdamW as get_optimizer builds it (optimizer.py:10-35): decoupled decay p *= 1 - lr * wd on the parameters with
@@ -194,7 +265,9 @@ class TrainStep:
 
     def _reducer(self, comm_dtype=None):
         red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
-                                comm_stream=self.comm_stream, comm_dtype=comm_dtype, stage_buf=self._stage_buf)
+                                comm_stream=self.comm_stream, comm_dtype=comm_dtype, stage_buf=self._stage_buf,
+                                shard=self.grad_mode == "shard" and self.exchange)
+        self._red = red
         return red
 
     def accumulate_last_and_apply(self, x1, weight, mask=None, cond_token_ids=None, lr=None):
@@ -287,6 +360,39 @@ class TrainStep:
         self._last_eng = eng
         return loss
 
+    def _clip_adam_sharded(self, eng, lr, red):
+        """grad_mode="shard": this rank holds the summed gradient of its chunks only (red.owned).  Global norm = sum over ranks of
+        the chunk sums of squares (all-gathered and added in rank order: every rank computes the same coefficient), Adam on the
+        owned chunks of (p, m, v), all-gather of the updated parameters, one repack of the operand copies."""
+        st = _lib.current_stream
+        dev = self.gflat.device
+        part = torch.zeros(len(red.owned) + 1, device=dev)
+        for i, (lo, hi) in enumerate(red.owned):
+            _lib.call("vbx_sumsq", self.gflat[lo:hi], hi - lo, part[i:i + 1], self.scratch, st())
+        mine = part[:len(red.owned)].sum().reshape(1)
+        parts = [torch.zeros(1, device=dev) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)  # W scalars; the list form exists on every backend
+        self.sumsq.copy_(torch.cat(parts).sum().reshape(1))  # added in rank order: the same coefficient on every rank
+        _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
+        rate = float(lr if lr is not None else self.lr)
+        if self._wd_params:
+            with torch.no_grad():
+                torch._foreach_mul_(self._wd_params, 1.0 - rate * self.wd)  # replicated (elementwise, identical on every rank)
+        flat = self.fp.flat
+        for lo, hi in red.owned:
+            _lib.call("vbx_adam_step", flat[lo:hi], self.gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, rate,
+                      float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
+        red.all_gather(flat)
+        self._dirty()  # every engine (this one included) repacks its fp16 / bf16 operand copies on its next bind_params
+
+    def gather_optimizer_state(self):
+        """grad_mode="shard": the Adam moments of a chunk live on its owner only; before a checkpoint every rank collects all of them
+        (no-op in all-reduce mode)."""
+        red = getattr(self, "_red", None)
+        if self.grad_mode == "shard" and red is not None:
+            red.all_gather(self.m)
+            red.all_gather(self.v)
+
     def _clip_adam(self, eng, lr):
         # --- clip (global norm of the rank-averaged gradient) + Adam, all on device, no host sync
         st = _lib.current_stream
@@ -294,6 +400,9 @@ class TrainStep:
         if lr is None and self.lr_schedule is not None:
             lr = self.lr_schedule.rate_for_step(self.steps)
         self.steps += 1
+        red = getattr(self, "_red", None)
+        if self.grad_mode == "shard" and red is not None and red.shard and red.active:
+            return self._clip_adam_sharded(eng, lr, red)
         _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
         if self._wd_params:

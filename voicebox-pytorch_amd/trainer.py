@@ -126,6 +126,7 @@ class VoiceBoxTrainer(nn.Module):
 
     def _optim_state_dict(self):
         ts = self.train_step_fn
+        ts.gather_optimizer_state()  # grad_mode="shard": the moments of a chunk live on its owner (a collective: every rank calls save())
         fp = ts.fp
         by_param = {id(fp.slots[s]): s for s in fp.order}
         state = {}
