@@ -104,7 +104,6 @@ VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
 }
 
 VBX_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
 // P^T (or dS^T) accumulator registers 8*t2 .. 8*t2+7 -> fp16 MFMA operand; v_cvt_pkrtz packs two conversions per
 // instruction (round toward zero: a 2^-12 relative bias on softmax weights that sum to 1 -- far below the fp16 noise)
 VBX_DEV f16x8 pack_frag_f16_fast(const f32x16& p, int t2) {
@@ -778,7 +777,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v3_drop(const u16* __r
 }
 #undef VBX_FWD_DROP
 
-#include "attn_fwd_v4.inc"
+// ---- Round-4 experiments on the forward, measured at the benchmark grid (8 x 16 heads x 1040 rows, stand-alone, same box) and removed:
+//  * "v4": 256-row workgroups, a wave owning TWO 32-query blocks whose chains are interleaved in one instruction stream (S of block B
+//    beside the softmax of block A, P.V of A beside the softmax of B; K / V^T fragments read once for both; 3-slot ring with counted
+//    vmcnt; two workgroups per CU = the 512 full tiles in ONE round).  238-244 VGPRs, no spills, correct (all attention tests).
+//    72-76 us against v3's 67-69 us: with two waves per SIMD a 32-MFMA wave-step takes ~3800 cycles -- neither the in-wave interleave
+//    (sched_group_barrier patterns 1 MFMA : 12 VALU + 4 TRANS, 1 : 20, or the compiler's own order) nor the halved LDS traffic buys
+//    back what four independent waves per SIMD hide.
+//  * plain instead of packed f32 VALU in the softmax (v_pk_fma / v_pk_add / v_pk_mul -> scalar, by source and by -fno-slp-vectorize
+//    for the whole file): v3 68.8 vs 69.1 us (no change), the two-body backward 180.7 vs 178.4 us (12 spilled registers), v4 75.9 vs
+//    72.1 us -- packed math is NOT the anti-lever here that it is in a one-wave-per-SIMD stream; instruction count is what counts.
+//  * a compiler trap found on the way (hipcc / ROCm 7.2): op(r[0], r[1]) of r = __builtin_amdgcn_permlane32_swap(x, x, ..) is folded to
+//    r[0] when nothing else uses the pair (the partner half-wave's value silently vanishes); pass both results through an opaque
+//    asm("" : "+v"(r0), "+v"(r1)) before combining them.
 
 // (Round 1 wrote a "ragged tile" role for this kernel -- the 128 workgroups per launch whose query tile holds only the 16
 //  register-token rows split their KEYS over the four waves with private tiles straight from global memory.  Round 2 ran it:
@@ -1642,24 +1653,6 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
-  static const int v4 = getenv("VBX_ATTN_V4") ? atoi(getenv("VBX_ATTN_V4")) : 1;  // 0: A/B against v3 (four single-chain waves per SIMD)
-  if (v4 && !legacy && !abl && !abl2) {  // 256-row tiles, two query blocks per wave, two workgroups per CU
-    const int tiles4 = (Np >> 8) + ((Np & 255) ? 1 : 0);
-#define VBX_FWD4(V)                                                                                                                \
-    {                                                                                                                              \
-      static bool attr4 = false;                                                                                                   \
-      if (!attr4) {                                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel_v4<V>), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS); \
-        attr4 = true;                                                                                                              \
-      }                                                                                                                            \
-      hipLaunchKernelGGL(attn_fwd_kernel_v4<V>, dim3(tiles4 * cdiv(BH, 8) * 8), dim3(256), A4_LDS, (hipStream_t)stream, (const u16*)q16, \
-                         (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH);          \
-    }
-    if (v4 == 2) VBX_FWD4(2) else if (v4 == 3) VBX_FWD4(3) else VBX_FWD4(1)
-#undef VBX_FWD4
-    VBX_LAUNCH_CHECK();
-    return 0;
-  }
   if (v3 && !legacy && !abl && !abl2) {
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
