@@ -284,6 +284,11 @@ int vbx_ode_set_time(float* times, int B, const float* table, const int* counter
 int vbx_axpy_ctr(const float* y, const float* f, const float* table, const int* counter, int slot, float* out, long n,
                  void* stream);
 int vbx_counter_add(int* counter, int inc, void* stream);
+/* Sampling: every batch element of a call shares the ODE time, and the grid is known up front, so the time embedding + the adaLN
+ * projections of ALL time points (voicebox_pytorch.py:1082, :273 -- a 100 MB weight stream per function evaluation at dim 512 / depth
+ * 12) are evaluated once per sample() into table [2 * intervals][L][G] (G = 4 * D: gamma1 | beta1 | gamma2 | beta2 of a layer); this
+ * copies the slice of time point 2 * counter + slot into the runtime's ada [L][B][G] (vbx_io.ada_table makes vbx_model_forward do it). */
+int vbx_ada_select(float* ada, int L, int B, int G, const float* table, const int* counter, int slot, void* stream);
 /* Occupies `stream` with one idle wave for `us` microseconds (0 .. 10000).  The sampler integrates the two halves of a batch as two
  * graphs on two streams and starts the second one ~60 us late, so that different kernels of the two forwards overlap (attention
  * beside GEMMs) instead of the same ones: 16 intervals 81.7 -> 80.1 ms (tools/sample_offset.py). */
@@ -442,6 +447,9 @@ typedef struct {
   float* dcond;                 /* stack_only backward: [B,Th] gradient of the adaptive-norm condition (NULL with plain_norm) */
   int dropout;                  /* 1: apply the model's attn_dropout / ff_dropout in this forward (the module is in train() mode) */
   unsigned long long drop_seed; /* Philox key of this forward's masks (the backward entry points must see the same io) */
+  const float* ada_table;       /* inference only, or NULL: precomputed adaLN projections [2 * intervals][L][4 * D] (vbx_ada_select); */
+  const int* ada_counter;       /* the forward then skips the time embedding and the projection GEMV and takes time point         */
+  int ada_slot;                 /* 2 * ada_counter[0] + ada_slot of the table (`times` is not read)                              */
 } vbx_io;
 
 size_t vbx_model_wpack_bytes(const vbx_model* m);
@@ -450,6 +458,9 @@ int vbx_model_pack_weights(const vbx_model* m, void* stream);
 /* segment table for vbx_adam_step_packed (see there) */
 int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam_seg* out, int max_segs, long* total_blocks);
 int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);
+/* adaLN projections of n <= 16 conditioning rows temb [n, Th] with the model's packed weights -> ada [L][n][4 * D] (what the forward
+ * computes per call; the sampler tabulates it over its time grid, see vbx_ada_select) */
+int vbx_model_adaln_table(const vbx_model* m, const float* temb, int n, float* ada, void* stream);
 /* backward: head (loss, to_pred, final norm) -> layers L-1..0 -> embed (conv, to_embed, time MLP).  Each call
  * finishes the gradients of its own parameters, so the caller can all-reduce them while the next runs. */
 int vbx_model_backward_head(const vbx_model* m, const vbx_io* io, const float* gscale, void* stream);

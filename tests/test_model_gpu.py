@@ -1231,6 +1231,44 @@ def test_sampler_concurrent_halves_equal_single_stream(golden, monkeypatch):
         assert MidpointSampler(vb, B, N, 5).split == 1
 
 
+def test_sampler_adaln_table_is_bit_identical_and_follows_weight_updates(golden, monkeypatch):
+    """The sampler tabulates the time embedding + adaLN projections of the whole ODE grid once per weights version (every batch element
+    of a call shares the time) instead of evaluating them per function evaluation: the sample must be BIT-IDENTICAL to the per-forward
+    path (VBX_SAMPLE_ADA_TABLE=0), eager and captured, one stream and two; and a weight update between two calls of a cached sampler
+    must refresh the table (whose address is baked into the captured graph)."""
+    from voicebox_pytorch_amd.solver import MidpointSampler
+
+    g = golden("small_wc")
+    vbx, vb, wrapper = build(g["cfg"], g["state"])
+    vb.eval()
+    gen = torch.Generator().manual_seed(6)
+    cond = torch.cat([g["cond"], g["cond"].flip(0) * 0.5]).to(dev)
+    y0 = torch.randn(cond.shape, generator=gen).to(dev)
+    B, N, _ = cond.shape
+    with torch.no_grad():
+        monkeypatch.setenv("VBX_SAMPLE_ADA_TABLE", "0")
+        ref_smp = MidpointSampler(vb, B, N, 6, use_graph=False, split=1)
+        assert ref_smp.use_ada_table is False
+        ref = ref_smp.run(y0, cond)
+        monkeypatch.delenv("VBX_SAMPLE_ADA_TABLE")
+        for use_graph in (False, True):
+            for split in (1, 2):
+                smp = MidpointSampler(vb, B, N, 6, use_graph=use_graph, split=split)
+                out = smp.run(y0, cond)
+                assert smp.ada_tab is not None and smp.ada_tab.shape[0] == 2 * 5
+                assert torch.equal(out, ref), (use_graph, split, float((out - ref).abs().max()))
+        # weights change under a cached, captured sampler: the table (and the packed weights) must follow
+        smp = MidpointSampler(vb, B, N, 6, use_graph=True, split=2)
+        a = smp.run(y0, cond)
+        for name, prm in vb.named_parameters():
+            if ".to_gamma." in name or name.startswith("sinu_pos_emb"):
+                prm.mul_(1.05)
+        b = smp.run(y0, cond)
+        monkeypatch.setenv("VBX_SAMPLE_ADA_TABLE", "0")
+        want = MidpointSampler(vb, B, N, 6, use_graph=False, split=1).run(y0, cond)
+        assert torch.equal(a, ref) and not torch.equal(b, a) and torch.equal(b, want)
+
+
 def test_packed_weights_follow_torch_optimizer_and_load_state_dict(golden):
     """the fp16/bf16 operand copies must be refreshed when parameters change through PyTorch
     (torch.optim step, load_state_dict, p.copy_) -- those bump the parameter views' version counters, not the flat buffer's."""

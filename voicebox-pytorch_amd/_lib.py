@@ -91,6 +91,7 @@ _PROTOS = {
     "vbx_ode_set_time": [P, I, P, P, I, P],
     "vbx_axpy_ctr": [P, P, P, P, I, P, L, P],
     "vbx_counter_add": [P, I, P],
+    "vbx_ada_select": [P, I, I, I, P, P, I, P],
     "vbx_stream_delay": [F, P],
     "vbx_pack_weight": [P, I, I, P, P, I, I, I, I, P],
     "vbx_pack_bias": [P, I, P, I, I, I, P],

@@ -1026,6 +1026,19 @@ __global__ void ode_set_time_kernel(float* __restrict__ times, int B, const floa
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) times[b] = table[2 * counter[0] + slot];
 }
+// ada[l][b][:] = table[2 * counter + slot][l][:] for every b: the adaLN projections of one ODE time point, precomputed for the whole
+// grid (every batch element of a sampling call shares the time, so the table has no batch axis); G = floats per layer (4 * D)
+__global__ void ada_select_kernel(float* __restrict__ ada, int L, int B, int G, const float* __restrict__ table,
+                                  const int* __restrict__ counter, int slot) {
+  const long n4 = (long)L * G / 4;
+  const float4* src = reinterpret_cast<const float4*>(table + (long)(2 * counter[0] + slot) * L * G);
+  const int g4 = G / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    const long l = i / g4, c = i - l * g4;
+    for (int b = 0; b < B; b++) reinterpret_cast<float4*>(ada + ((l * B + b) * (long)G))[c] = v;
+  }
+}
 __global__ void axpy_ctr_kernel(const float* __restrict__ y, const float* __restrict__ f, const float* __restrict__ table,
                                 const int* __restrict__ counter, int slot, float* __restrict__ out, long n4) {
   const float a = table[2 * counter[0] + slot];
@@ -1570,6 +1583,12 @@ extern "C" int vbx_axpy_dev(const float* y, const float* f, const float* coef, i
 extern "C" int vbx_ode_set_time(float* times, int B, const float* table, const int* counter, int slot, void* stream) {
   VBX_REQUIRE(times && table && counter && (slot == 0 || slot == 1), "vbx_ode_set_time: bad args");
   hipLaunchKernelGGL(ode_set_time_kernel, dim3(cdiv(B, 64)), dim3(64), 0, ST, times, B, table, counter, slot);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_ada_select(float* ada, int L, int B, int G, const float* table, const int* counter, int slot, void* stream) {
+  VBX_REQUIRE(ada && table && counter && L > 0 && B > 0 && G > 0 && G % 4 == 0 && (slot == 0 || slot == 1), "vbx_ada_select: bad args");
+  hipLaunchKernelGGL(ada_select_kernel, dim3(grid_for((long)L * G / 4, 256)), dim3(256), 0, ST, ada, L, B, G, table, counter, slot);
   VBX_LAUNCH_CHECK();
   return 0;
 }

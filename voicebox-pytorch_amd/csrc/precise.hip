@@ -456,10 +456,14 @@ int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseAc
   };
 #define PCK(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
   // time embedding (fp32 already) + adaLN projections from the fp32 master weights   (:1082, :273)
-  PCK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a->four, a->pre, a->temb, d.B, d.D, d.Th, stream));
-  for (int l = 0; l < d.L; l++) {
-    const long* o = m->off + VBX_NG + (long)l * VBX_NL;
-    PCK(vbx_adaln_proj_f32(a->temb, P + o[VBX_L_G1W], P + o[VBX_L_G1B], a->ada + (size_t)l * d.B * 4 * d.D, d.B, d.Th, 4 * d.D, 4 * d.D, stream));
+  if (io->ada_table) {  // the sampler's precomputed table (vbx_model_adaln_table evaluates it with the fp32 weights in this mode)
+    PCK(vbx_ada_select(a->ada, d.L, d.B, 4 * d.D, io->ada_table, io->ada_counter, io->ada_slot, stream));
+  } else {
+    PCK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a->four, a->pre, a->temb, d.B, d.D, d.Th, stream));
+    for (int l = 0; l < d.L; l++) {
+      const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+      PCK(vbx_adaln_proj_f32(a->temb, P + o[VBX_L_G1W], P + o[VBX_L_G1B], a->ada + (size_t)l * d.B * 4 * d.D, d.B, d.Th, 4 * d.D, 4 * d.D, stream));
+    }
   }
   // to_embed(cat(x, cond * ~cond_mask))   (:1035,1075-1078); the bf16 copy of the input is the backward's wgrad operand
   if (a->embed_in_bf16)

@@ -502,10 +502,29 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
   return 0;
 }
 
+// adaLN projections of n <= 16 conditioning rows temb [n, Th] with the model's packed weights -> ada [L][n][4 * D]: what
+// vbx_model_forward computes per forward, exposed so that the sampler can tabulate it over its whole time grid (vbx_ada_select).
+extern "C" int vbx_model_adaln_table(const vbx_model* m, const float* temb, int n, float* ada, void* stream) {
+  CK(check_model(m));
+  VBX_REQUIRE(temb && ada && n > 0 && n <= 16 && !m->plain_norm, "vbx_model_adaln_table: bad args");
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  if (m->precise) {
+    const float* P = m->params;
+    for (int l = 0; l < d.L; l++) {
+      const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+      CK(vbx_adaln_proj_f32(temb, P + o[VBX_L_G1W], P + o[VBX_L_G1B], ada + (size_t)l * n * 4 * d.D, n, d.Th, 4 * d.D, 4 * d.D, stream));
+    }
+    return 0;
+  }
+  return vbx_adaln_proj_fwd(temb, w.adah, w.bada, ada, n, d.Th, d.J, 4 * d.D, stream);
+}
+
 extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream) {
   CK(check_model(m));
   VBX_REQUIRE(io && io->x, "vbx_model_forward: null io field");
-  VBX_REQUIRE(m->stack_only ? ((m->plain_norm || io->cond) && io->pred && !io->target) : (io->cond && io->times),
+  VBX_REQUIRE(m->stack_only ? ((m->plain_norm || io->cond) && io->pred && !io->target) : (io->cond && (io->times || io->ada_table)),
               "vbx_model_forward: null io field");
   VBX_REQUIRE(!io->target || (io->loss_mask && io->loss), "vbx_model_forward: target needs loss_mask and loss");
   VBX_REQUIRE((io->attn_mask == nullptr) == (io->attn_mask_p == nullptr), "vbx_model_forward: attn_mask and attn_mask_p go together");
@@ -545,9 +564,14 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     }
     tstream = tb.s;
   }
+  if (io->ada_table) {  // sampler: the projections of this time point were evaluated once for the whole grid (vbx_ada_select)
+    VBX_REQUIRE(!tr && io->ada_counter, "vbx_model_forward: ada_table is an inference-only input and needs ada_counter");
+    CK(vbx_ada_select(a.ada, d.L, d.B, 4 * d.D, io->ada_table, io->ada_counter, io->ada_slot, tstream));
+  } else {
   CK(vbx_time_embed_fwd(io->times, P + G[VBX_P_SINW], P + G[VBX_P_T1W], P + G[VBX_P_T1B], a.four, a.pre, a.temb, d.B, d.D,
                         d.Th, tstream));
   CK(vbx_adaln_proj_fwd(a.temb, w.adah, w.bada, a.ada, d.B, d.Th, d.J, 4 * d.D, tstream));
+  }
   if (tb.ok && hipEventRecord(tb.done, tb.s) != hipSuccess) {
     vbx_set_error("vbx_model_forward: event record on the time branch failed");
     return VBX_EINVAL;

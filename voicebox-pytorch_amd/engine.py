@@ -27,7 +27,8 @@ class VbxModel(C.Structure):
 class VbxIO(C.Structure):
     _fields_ = [("x", P), ("cond", P), ("cond_mask", P), ("attn_mask", P), ("attn_mask_p", P), ("loss_mask", P),
                 ("times", P), ("target", P), ("pred", P), ("loss", P), ("cond_ids", P), ("T", I), ("null_id", C.c_long),
-                ("drop_mask", P), ("null_cond", P), ("dx", P), ("dcond", P), ("dropout", I), ("drop_seed", C.c_ulonglong)]
+                ("drop_mask", P), ("null_cond", P), ("dx", P), ("dcond", P), ("dropout", I), ("drop_seed", C.c_ulonglong),
+                ("ada_table", P), ("ada_counter", P), ("ada_slot", I)]
 
 
 class VbxAdamSeg(C.Structure):
@@ -85,6 +86,8 @@ def _rt():
         l.vbx_model_precise_wpack_bytes.restype = C.c_size_t
         l.vbx_model_precise_scratch_bytes.argtypes = [MP]
         l.vbx_model_precise_scratch_bytes.restype = C.c_size_t
+        l.vbx_model_adaln_table.argtypes = [MP, P, I, P, P]
+        l.vbx_model_adaln_table.restype = I
         for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_pack_weights_precise", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
                          ("vbx_model_backward_head", [MP, IP, P, P]), ("vbx_model_backward_layer", [MP, IP, I, P]),
                          ("vbx_model_backward_embed", [MP, IP, P])):
@@ -306,10 +309,11 @@ class Engine:
         self.packed_version = self.fp.weights_key()  # this engine's operand copies were refreshed in the same pass
 
     # -- forward
-    def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None, text=None):
+    def forward(self, x, cond, cond_mask, times, attn_mask=None, target=None, loss_mask=None, pred_out=None, text=None, ada=None):
         """All tensors on self.device, fp32 contiguous / bool.  Returns the loss tensor (1,) if target is given,
         else the prediction (B,N,D).  text (text-conditioned models): (ids int64 (B,T), null_id, drop_mask bool (B,) or None,
-        null_cond fp32 (D,))."""
+        null_cond fp32 (D,)).  ada (inference, the sampler): (table fp32 [2 * intervals, L, 4 * D], counter int32 [1], slot) -- the
+        adaLN projections of every time point of the ODE grid, precomputed; `times` is then not read."""
         self.bind_params()
         B, N, D = self.B, self.N, self.Din
         assert x.shape == (B, N, D) and cond.shape == (B, N, D), (tuple(x.shape), tuple(cond.shape), (B, N, D))
@@ -325,6 +329,12 @@ class Engine:
         io.attn_mask = am.data_ptr() if am is not None else None
         io.attn_mask_p = amp.data_ptr() if amp is not None else None
         io.times = times.data_ptr()
+        if ada is not None:
+            assert target is None and not self.training
+            io.ada_table, io.ada_counter, io.ada_slot = ada[0].data_ptr(), ada[1].data_ptr(), int(ada[2])
+        else:
+            io.ada_table = io.ada_counter = None
+            io.ada_slot = 0
         if target is not None:
             target = target.contiguous()
             lm = _u8(loss_mask)
@@ -344,11 +354,37 @@ class Engine:
             io.drop_mask = drop8.data_ptr() if drop8 is not None else None
             io.null_cond = null_cond.data_ptr()
             text = (ids, drop8, null_cond)
-        self._keep = (x, cond, cm, am, amp, lm, times, target, pred, text)  # keep inputs alive until backward
+        self._keep = (x, cond, cm, am, amp, lm, times, target, pred, text, ada)  # keep inputs alive until backward
         self.generation += 1
         self._draw_dropout_seed()
         _check(_rt().vbx_model_forward(C.byref(self.m), C.byref(io), _lib.current_stream()), "vbx_model_forward")
         return self.loss if target is not None else pred
+
+    def ada_table(self, times):
+        """adaLN projections [len(times), L, 4 * D] of the given time points (fp32, device): the same kernels the forward runs
+        (vbx_time_embed_fwd + vbx_adaln_proj_fwd: every (time, output) pair is an independent dot product, so a row of the table is
+        bit-identical to what a forward at that time computes for each of its batch rows), 16 time points per launch."""
+        self.bind_params()
+        cfg, dev = self.cfg, self.device
+        D, Th, L = cfg["D"], cfg["Th"], cfg["L"]
+        off = self.fp.offsets
+        flat = self.fp.flat
+        self.m.params = flat.data_ptr()
+        times = times.to(dev, torch.float32).contiguous()
+        T = times.numel()
+        out = torch.empty(T, L, 4 * D, dtype=torch.float32, device=dev)
+        st = _lib.current_stream
+        sinw, t1w, t1b = (flat[off[k]:] for k in ("SINW", "T1W", "T1B"))
+        for t0 in range(0, T, 16):
+            n = min(16, T - t0)
+            four = torch.empty(n, D, device=dev)
+            pre = torch.empty(n, Th, device=dev)
+            temb = torch.empty(n, Th, device=dev)
+            _lib.call("vbx_time_embed_fwd", times[t0:t0 + n], sinw, t1w, t1b, four, pre, temb, n, D, Th, st())
+            tmp = torch.empty(L, n, 4 * D, device=dev)
+            _check(_rt().vbx_model_adaln_table(C.byref(self.m), temb.data_ptr(), n, tmp.data_ptr(), st()), "vbx_model_adaln_table")
+            out[t0:t0 + n] = tmp.permute(1, 0, 2)
+        return out
 
     def _draw_dropout_seed(self):
         """One Philox key per training forward, drawn from torch's CPU generator (so torch.manual_seed reproduces a run); the

@@ -92,33 +92,41 @@ class MidpointSampler:
             self.parts.append(p)
         self.side_streams = [torch.cuda.Stream(device=dev) for _ in range(split - 1)]
         self.part_streams = [torch.cuda.Stream(device=dev) for _ in range(split)] if split > 1 else []
+        # adaLN projections of every time point of the grid, evaluated once per weights version instead of once per function
+        # evaluation (a 100 MB weight stream + the time MLP per forward at dim 512 / depth 12): every batch element shares the time.
+        # VBX_SAMPLE_ADA_TABLE=0: A/B (per-forward projections, bit-identical results).
+        self.use_ada_table = os.environ.get("VBX_SAMPLE_ADA_TABLE", "1") != "0"
+        self.ada_tab, self.ada_key = None, None
         self.graph = None       # split == 1: one interval; split > 1: a list, one interval graph per part
         self.use_graph = use_graph
         self.nfe = 2 * (steps - 1) * (2 if self.guided else 1)
 
-    def _bind(self, p, x):
-        # point the part's engine at the static buffers (x = y or ymid), prediction written to p.f
+    def _bind(self, p, x, slot):
+        # point the part's engine at the static buffers (x = y or ymid), prediction written to p.f; slot 0 / 1 = t_i / t_i + dt / 2
         p.eng.dropout_active = False  # sampling is eval (:1268) whatever mode a later forward of the same shape left on the engine
+        ada = (self.ada_tab, p.counter, slot) if self.ada_tab is not None else None
         if not self.tokens:
-            p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f)
+            p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f, ada=ada)
             return
         vb = self.vb
-        p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f, text=(p.ids, vb.null_cond_id, None, vb.null_cond))
+        p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f, text=(p.ids, vb.null_cond_id, None, vb.null_cond), ada=ada)
         if self.guided:
             st, n = _lib.current_stream, p.f.numel()
             p.eng.forward(x, p.cond, p.cmask, p.times, pred_out=p.f_null,
-                          text=(p.ids, vb.null_cond_id, p.drop_all, vb.null_cond))
+                          text=(p.ids, vb.null_cond_id, p.drop_all, vb.null_cond), ada=ada)
             _lib.call("vbx_axpy_dev", p.f, p.f_null, self.g_table, 0, p.f_diff, n, st())   # logits - null
             _lib.call("vbx_axpy_dev", p.f_null, p.f_diff, self.g_table, 1, p.f, n, st())   # null + scale * diff
 
     def _interval_part(self, p):
         st = _lib.current_stream
         n = p.y.numel()
-        _lib.call("vbx_ode_set_time", p.times, p.B, self.t_table, p.counter, 0, st())
-        self._bind(p, p.y)
+        if self.ada_tab is None:
+            _lib.call("vbx_ode_set_time", p.times, p.B, self.t_table, p.counter, 0, st())
+        self._bind(p, p.y, 0)
         _lib.call("vbx_axpy_ctr", p.y, p.f, self.c_table, p.counter, 0, p.ymid, n, st())
-        _lib.call("vbx_ode_set_time", p.times, p.B, self.t_table, p.counter, 1, st())
-        self._bind(p, p.ymid)
+        if self.ada_tab is None:
+            _lib.call("vbx_ode_set_time", p.times, p.B, self.t_table, p.counter, 1, st())
+        self._bind(p, p.ymid, 1)
         _lib.call("vbx_axpy_ctr", p.y, p.f, self.c_table, p.counter, 1, p.y, n, st())
         _lib.call("vbx_counter_add", p.counter, 1, st())
 
@@ -185,6 +193,14 @@ class MidpointSampler:
             self.g_table[1] = float(cond_scale)
         for p in self.parts:
             p.eng.bind_params()  # re-pack weights if they changed since the last call
+        if self.use_ada_table and not self.vb._cfg.get("plain_norm"):
+            key = self.eng.fp.weights_key()
+            if self.ada_tab is None:
+                self.ada_tab = self.eng.ada_table(self.t_table)  # allocated once: its address is baked into the captured graphs
+                self.ada_key = key
+            elif key != self.ada_key:
+                self.ada_tab.copy_(self.eng.ada_table(self.t_table))
+                self.ada_key = key
         if self.use_graph and self.graph is None:
             self._capture()
         self.y.copy_(y0)
