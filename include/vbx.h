@@ -222,6 +222,9 @@ int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, i
 int vbx_stack_input_bwd(const float* dxs, float* dx, float* dreg /* may be NULL */, int B, int N, int R, int D, void* stream);
 int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
                     float* xs, int B, int N, int R, int D, int ksize, void* stream);
+/* vbx_convpos_fwd with libm's erff in the GELU instead of the fast path's Abramowitz-Stegun form (precise mode) */
+int vbx_convpos_fwd_libm(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
+                         float* xs, int B, int N, int R, int D, int ksize, void* stream);
 /* ksize: any odd kernel size <= 31 (the reference default is 31, voicebox_pytorch.py:893; one unrolled instantiation per size).
  * backward: de = dxs[:,R:] + conv-transpose(...) ; dw/db partials [chunks][D][ksize+1]; dreg [R,D]. */
 int vbx_convpos_bwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* dxs,

@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact,attend_mask4d}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -609,6 +609,34 @@ def gen_cfg4_seeds_exact(ref=None):
     torch.save(out, os.path.join(HERE, "cfg4_seeds_exact.pt"))
 
 
+def gen_attend_mask4d(ref):
+    """Attend.forward (attend.py:100-137) from the unmodified reference with a 4-D key-padding mask (b, 1, 1, j) and with the batch-1
+    broadcast form (1, 1, 1, j): outputs and input gradients at the model's logit scale (scale 10 on |q| = |k| = 8)."""
+    import importlib
+
+    attend_mod = importlib.import_module("voicebox_pytorch.attend")
+    att = attend_mod.Attend(scale=10.0)
+    gen = torch.Generator().manual_seed(77)
+    q = torch.randn(2, 2, 90, 64, generator=gen)
+    k = torch.randn(2, 2, 90, 64, generator=gen)
+    q, k = q / q.norm(dim=-1, keepdim=True) * 8, k / k.norm(dim=-1, keepdim=True) * 8
+    v = torch.randn(2, 2, 90, 64, generator=gen)
+    # the goldens are taken on fp16-representable inputs (what the kernels see)
+    q, k, v = q.half().float(), k.half().float(), v.half().float()
+    out = {"q": q, "k": k, "v": v}
+    m2 = torch.ones(2, 90, dtype=torch.bool)
+    m2[1, 60:] = False
+    m2[0, 3:7] = False
+    for name, mask in (("b11j", m2[:, None, None, :]), ("111j", m2[1:2, None, None, :])):
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = att(qr, kr, vr, mask=mask)
+        w = torch.randn(o.shape, generator=torch.Generator().manual_seed(5))
+        (o * w).sum().backward()
+        out[name] = dict(mask=mask.clone(), out=o.detach(), w=w, dq=qr.grad.clone(), dk=kr.grad.clone(), dv=vr.grad.clone())
+    torch.save(out, os.path.join(HERE, "attend_mask4d.pt"))
+    print("attend_mask4d: out norm", float(out["b11j"]["out"].norm()))
+
+
 def gen_cfg3(ref):
     """Round 3: BASELINE config 3 -- dim 1024, heads 16, depth 12 -- at B = 2, N = 1024 from the unmodified
     reference, once at the reference's initialisation and once well-conditioned (qk-norm gammas x 0.25).  Weights by
@@ -664,10 +692,10 @@ def gen_cfg5_wc_b8(ref):
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact", "attend_mask4d"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
          "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
          "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout, "small_dimin": gen_small_dimin,
-         "cfg4_seeds_exact": gen_cfg4_seeds_exact}[w](ref)
+         "cfg4_seeds_exact": gen_cfg4_seeds_exact, "attend_mask4d": gen_attend_mask4d}[w](ref)

@@ -324,6 +324,27 @@ def test_attend_module_matches_reference_math():
     assert qd.grad is not None and kd.grad.shape == k.shape and vd.grad.shape == v.shape
 
 
+def test_attend_4d_key_padding_mask_vs_reference(golden):
+    """attend.py:113-114: a 4-D mask passes through unchanged.  Its key-padding forms (b, 1, 1, j) and (1, 1, 1, j) run on the kernels'
+    key mask, against outputs and input gradients of the unmodified reference (tests/golden/attend_mask4d.pt); per-head / per-query
+    masks raise."""
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("attend_mask4d")
+    att = vbx.Attend(scale=10.0)
+    for name in ("b11j", "111j"):
+        rec = g[name]
+        qd, kd, vd = (g[t].to(dev).requires_grad_(True) for t in ("q", "k", "v"))
+        out = att(qd, kd, vd, mask=rec["mask"].to(dev))
+        assert rel(out, rec["out"]) < 2e-3, (name, rel(out, rec["out"]))  # P rounded to fp16, fp16 output
+        (out * rec["w"].to(dev)).sum().backward()
+        # gradients through a near-one-hot softmax with bf16 operands: direction and size, as test_attn_fwd_bwd
+        for got, want, tol in ((vd.grad, rec["dv"], 2e-2), (qd.grad, rec["dq"], 0.15), (kd.grad, rec["dk"], 0.15)):
+            assert rel(got, want) < tol, (name, rel(got, want))
+    with pytest.raises(NotImplementedError):
+        att(qd, kd, vd, mask=torch.ones(2, 2, 90, 90, dtype=torch.bool, device=dev))
+
+
 def test_dim1024_config3_shape_vs_oracle():
     """BASELINE config 3 architecture (dim 1024, heads 16, ff inner 2730 -> padded 2752) at depth 2 / small batch:
     loss parity with the CPU oracle (the full depth-12 B=8 shape is exercised by bench.py --dim 1024)."""

@@ -59,6 +59,7 @@ _PROTOS = {
     "vbx_stack_input_bwd": [P, P, P, I, I, I, I, P],
     "vbx_rmsnorm_fwd_f32": [P, P, P, L, P, I, I, I, I, I, P],
     "vbx_convpos_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "vbx_convpos_fwd_libm": [P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_bwd_chunks": [I, I],
     "vbx_conv_wgrad_finalize": [P, I, I, I, P, P, P],

@@ -137,8 +137,9 @@ VBX_DEV float erf_as(float x) {
   return copysignf(r, x);
 }
 VBX_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
-// the same with libm's erff (~1 ulp): the conv positional embedding evaluates it once per element of ONE pass per forward, where
-// the A-S form's 6e-7 is ten fp32 ulps at the very input of a 12-layer stack for no measurable time
+// the same with libm's erff (~1 ulp) for the precise mode's conv positional embedding: the A-S form's 6e-7 is ten fp32 ulps at the very
+// input of a 12-layer stack.  (Round 4 measured what that is worth at the reference's chaotic initialisation: switching the FAST path's
+// conv to this form moved the dim-1024 / depth-12 loss from 2.7e-3 to 5.1e-3 off the reference -- rounding-level noise, not accuracy.)
 VBX_DEV float gelu_erf_libm(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 VBX_DEV float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);

@@ -190,7 +190,7 @@ __global__ void cond_emb_bwd_kernel(const u16* __restrict__ demb, int ld, const 
 // ---------------------------------------------------------------- conv positional embedding
 // tile: 64 frames x 64 channels per block; thread (dl = tid&63, ng = tid>>6) computes 16 frames of channel dl.
 constexpr int CT = 64;
-template <int MODE, int KS>  // MODE 0: forward -> xs ; 1: dpre = dxs * m * gelu'(pre) -> out.  KS: compile-time kernel size
+template <int MODE, int KS>  // MODE 0: forward -> xs (2: the same with libm's erff: precise mode) ; 1: dpre = dxs * m * gelu'(pre) -> out.  KS: compile-time kernel size
 __global__ __launch_bounds__(256) void convpos_fwd_kernel(const float* __restrict__ e, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ dxs, float* __restrict__ out, int N,
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) void convpos_fwd_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < ks; k++) acc += wr[k] * tile[(nl + k) * 64 + dl];
     const bool m = !mask || mask[(long)b * N + n];
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
       // residual uses the UNMASKED e (voicebox_pytorch.py:1080 adds x, conv masks internally)
       const float ev = e[((long)b * N + n) * D + d];
-      out[((long)b * Np + R + n) * D + d] = ev + (m ? gelu_erf_libm(acc) : 0.f);
+      out[((long)b * Np + R + n) * D + d] = ev + (m ? (MODE == 2 ? gelu_erf_libm(acc) : gelu_erf(acc)) : 0.f);
     } else {
       const float g = dxs[((long)b * Np + R + n) * D + d];
       out[((long)b * N + n) * D + d] = m ? g * gelu_erf_grad(acc) : 0.f;
@@ -1315,15 +1315,19 @@ extern "C" int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, 
   }
 static inline bool conv_ks_ok(int ks) { return ks >= 1 && ks <= 31 && (ks & 1); }
 
-extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
-                               float* xs, int B, int N, int R, int D, int ksize, void* stream) {
+static int convpos_fwd_impl(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg, float* xs, int B,
+                            int N, int R, int D, int ksize, bool libm, void* stream) {
   VBX_REQUIRE(e && w && bias && xs, "vbx_convpos_fwd: null pointer");
   VBX_REQUIRE(conv_ks_ok(ksize), "vbx_convpos_fwd: conv_pos_embed_kernel_size must be odd and <= 31 (got %d)", ksize);
   VBX_REQUIRE(R == 0 || reg, "vbx_convpos_fwd: register tokens missing");
   dim3 grid(cdiv(N, CT), cdiv(D, 64), B);
-#define VBX_CALL(KS)                                                                                                         \
-  hipLaunchKernelGGL((convpos_fwd_kernel<0, KS>), grid, dim3(256), (CT + KS - 1) * 64 * sizeof(float), ST, e, w, bias, mask, \
-                     (const float*)nullptr, xs, N, R, D)
+#define VBX_CALL(KS)                                                                                                           \
+  if (libm)                                                                                                                    \
+    hipLaunchKernelGGL((convpos_fwd_kernel<2, KS>), grid, dim3(256), (CT + KS - 1) * 64 * sizeof(float), ST, e, w, bias, mask, \
+                       (const float*)nullptr, xs, N, R, D);                                                                    \
+  else                                                                                                                         \
+    hipLaunchKernelGGL((convpos_fwd_kernel<0, KS>), grid, dim3(256), (CT + KS - 1) * 64 * sizeof(float), ST, e, w, bias, mask, \
+                       (const float*)nullptr, xs, N, R, D)
   VBX_CONV_KS_SWITCH(ksize, VBX_CALL)
 #undef VBX_CALL
   VBX_LAUNCH_CHECK();
@@ -1332,6 +1336,16 @@ extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias
     VBX_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
+                               float* xs, int B, int N, int R, int D, int ksize, void* stream) {
+  return convpos_fwd_impl(e, w, bias, mask, reg, xs, B, N, R, D, ksize, false, stream);
+}
+// the same with libm's erff in the GELU (the fast path's A-S form is 6e-7 = ten fp32 ulps off): precise mode
+extern "C" int vbx_convpos_fwd_libm(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
+                                    float* xs, int B, int N, int R, int D, int ksize, void* stream) {
+  return convpos_fwd_impl(e, w, bias, mask, reg, xs, B, N, R, D, ksize, true, stream);
 }
 
 extern "C" int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream) {

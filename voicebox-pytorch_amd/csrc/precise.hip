@@ -471,7 +471,7 @@ int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseAc
   hipLaunchKernelGGL(embed_cat_kernel, dim3(grid_for(d.M0 * 2 * d.Din / 4)), dim3(256), 0, ST, io->x, io->cond, io->cond_mask, s.h32, d.M0, d.Din);
   VBX_LAUNCH_CHECK();
   PCK(gemm3(s.h32, d.M0, d.Ke, d.Ke, w.emb, d.D, a->e, d.D, P + G[VBX_P_EMBB], nullptr));
-  PCK(vbx_convpos_fwd(a->e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a->xs[0], d.B, d.N, d.R, d.D, m->ksize, stream));
+  PCK(vbx_convpos_fwd_libm(a->e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a->xs[0], d.B, d.N, d.R, d.D, m->ksize, stream));
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
     const VbxPreciseLayer& y = a->layer[l];

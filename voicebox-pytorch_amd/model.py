@@ -98,8 +98,15 @@ class Attend(nn.Module):
     def forward(self, q, k, v, mask=None):
         if q.shape[-1] != 64:
             raise NotImplementedError("the HIP attention kernel is built for dim_head == 64")
+        if exists(mask) and mask.ndim == 4:
+            # attend.py:113-114 rearranges a (b, j) key-padding mask to (b, 1, 1, j) and lets a 4-D mask through unchanged; the kernels
+            # take key masks, so a 4-D mask must BE one: size 1 along heads and queries (batch 1 broadcasts)
+            if mask.shape[1] != 1 or mask.shape[2] != 1 or mask.shape[0] not in (1, q.shape[0]) or mask.shape[3] != k.shape[2]:
+                raise NotImplementedError("4-D attention masks are supported in their key-padding form (b | 1, 1, 1, keys) only; "
+                                          f"got {tuple(mask.shape)} (per-head / per-query masks are not built)")
+            mask = mask[:, 0, 0, :].expand(q.shape[0], -1)
         if exists(mask) and mask.ndim != 2:
-            raise NotImplementedError("only (batch, keys) key-padding masks are supported")
+            raise NotImplementedError("only (batch, keys) and (batch, 1, 1, keys) key-padding masks are supported")
         scale = default(self.scale, q.shape[-1] ** -0.5)
         if self.training and self.dropout > 0.:  # one Philox key per call from torch's CPU generator (torch.manual_seed reproduces it)
             self.last_dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
