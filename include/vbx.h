@@ -220,6 +220,12 @@ int vbx_rowdot(const float* x, const float* w, const float* bias, float* out, lo
  * n < R) followed by x [B,N,D]; backward: dx = rows n >= R of dxs, dreg[R,D] = sum over the batch of rows n < R. */
 int vbx_stack_input(const float* x, const float* reg, float* xs, int B, int N, int R, int D, void* stream);
 int vbx_stack_input_bwd(const float* dxs, float* dx, float* dreg /* may be NULL */, int B, int N, int R, int D, void* stream);
+/* u-net skip connection (voicebox_pytorch.py:458-463): cat [rows, 2*D] = (x | scale * skip) as fp16 and / or bf16 (the combiner's GEMM operand);
+ * backward: dcat fp32 [rows, 2*D] = d(cat) -> dx = dcat[:, :D] (+ bf16 copy), dskip = scale * dcat[:, D:]; and the deferred add of a
+ * stored dskip into the gradient of the layer input it was taken from: dx += dskip (+ bf16 copy). */
+int vbx_unet_cat(const float* x, const float* skip, float scale, void* cat_f16, void* cat_bf16, long rows, int D, void* stream);
+int vbx_unet_split(const float* dcat, float scale, float* dx, void* dx_bf16, float* dskip, long rows, int D, void* stream);
+int vbx_unet_addskip(float* dx, void* dx_bf16, const float* dskip, long n, void* stream);
 int vbx_convpos_fwd(const float* e, const float* w, const float* bias, const uint8_t* mask, const float* reg,
                     float* xs, int B, int N, int R, int D, int ksize, void* stream);
 /* vbx_convpos_fwd with libm's erff in the GELU instead of the fast path's Abramowitz-Stegun form (precise mode) */
@@ -396,7 +402,9 @@ enum { VBX_P_SINW = 0, VBX_P_T1W, VBX_P_T1B, VBX_P_EMBW, VBX_P_EMBB, VBX_P_CONVW
  * post-LayerNorm weight and bias (GLLNW, GLLNB).  The four GL* slots are read only when vbx_model.gateloop != 0. */
 enum { VBX_L_G1W = 0, VBX_L_B1W, VBX_L_G2W, VBX_L_B2W, VBX_L_G1B, VBX_L_B1B, VBX_L_G2B, VBX_L_B2B, VBX_L_QG, VBX_L_KG,
        VBX_L_QKVW, VBX_L_OUTW, VBX_L_FF1W, VBX_L_FF1B, VBX_L_FF2W, VBX_L_FF2B, VBX_L_GLG, VBX_L_GLW, VBX_L_GLLNW, VBX_L_GLLNB,
-       VBX_L_N1G, VBX_L_N2G /* plain RMSNorm gammas, read only when vbx_model.plain_norm != 0 */, VBX_NL };
+       VBX_L_N1G, VBX_L_N2G /* plain RMSNorm gammas, read only when vbx_model.plain_norm != 0 */,
+       VBX_L_SKW, VBX_L_SKB /* u-net skip combiner Linear(2 * dim, dim) of the second-half layers, read only when vbx_model.unet != 0 */,
+       VBX_NL };
 
 typedef struct {
   int B, N, R, D, H, F, Th, L, ksize;
@@ -428,6 +436,9 @@ typedef struct {
                              (vbx_model_precise_scratch_bytes).  The backward entry points are unchanged (bf16 operands). */
   void* wpack3;           /* precise mode: hi/lo-split fp16 weights, K-concatenated */
   void* pscratch;         /* precise mode: fp32 intermediates + the K-concatenated activation operand */
+  int unet;               /* use_unet_skip_connection (voicebox_pytorch.py:368-369,391-398,453-463; stack_only models: VoiceBox never
+                             enables it): layer l >= L / 2 starts with x = Linear(2 * dim, dim)(cat(x, skip_scale * input of layer L-1-l)) */
+  float skip_scale;       /* skip_connect_scale (:390), 2^-0.5 by default */
 } vbx_model;
 
 typedef struct {

@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact,attend_mask4d}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact,attend_mask4d,transformer_unet}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -235,6 +235,46 @@ def gen_transformer(ref):
                          grads={k: p.grad.detach().clone() for k, p in tr.named_parameters() if p.grad is not None})
         print("transformer", name, float(y.norm()))
     torch.save(out, os.path.join(HERE, "transformer.pt"))
+
+
+def gen_transformer_unet(ref):
+    """Standalone Transformer with use_unet_skip_connection=True (voicebox_pytorch.py:368-369,391-398,453-463), depth 4 = two skips:
+    adaptive (registers, qk-norm, key-padding mask, skip_connect_scale=0.5), plain (default scale 2^-0.5) and plain + GateLoop
+    layers (the restated third-party layer, see gen_small_gateloop): output + gradients of parameters, input and condition."""
+    out = {}
+    for name, kw, use_mask in (("adaptive", dict(num_register_tokens=4, adaptive_rmsnorm=True, adaptive_rmsnorm_cond_dim_in=32,
+                                                attn_qk_norm=True, skip_connect_scale=0.5), True),
+                               ("plain", dict(num_register_tokens=0, adaptive_rmsnorm=False, attn_qk_norm=False), False),
+                               ("gateloop", dict(num_register_tokens=2, adaptive_rmsnorm=False, attn_qk_norm=True,
+                                                 use_gateloop_layers=True), False)):
+        torch.manual_seed(6)
+        tr = ref.Transformer(dim=64, depth=4, dim_head=64, heads=2, use_unet_skip_connection=True, **kw)
+        g = torch.Generator().manual_seed(12)
+        with torch.no_grad():
+            for n, prm in tr.named_parameters():
+                if ".to_gamma." in n or ".to_beta." in n:
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+                if n.endswith("gamma"):
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+                if "q_norm.gamma" in n or "k_norm.gamma" in n:
+                    prm.mul_(0.25)  # trained-regime logits (std ~5): at depth 4 the random-init softmax is chaotic (DESIGN section 2)
+        state = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+        assert "layers.2.0.weight" in state and "layers.3.0.bias" in state and "layers.1.0.weight" not in state
+        b, n = 2, 40
+        x = torch.randn(b, n, 64, generator=g).requires_grad_(True)
+        cond = torch.randn(b, 32, generator=g).requires_grad_(True) if kw["adaptive_rmsnorm"] else None
+        mask = None
+        if use_mask:
+            mask = torch.ones(b, n, dtype=torch.bool)
+            mask[1, 31:] = False
+        dout = torch.randn(b, n, 64, generator=g)
+        y = tr(x, mask=mask, adaptive_rmsnorm_cond=cond)
+        (y * dout).sum().backward()
+        out[name] = dict(kw=kw, state=state, x=x.detach().clone(), cond=None if cond is None else cond.detach().clone(), mask=mask,
+                         dout=dout, y=y.detach().clone(), dx=x.grad.clone(), dcond=None if cond is None else cond.grad.clone(),
+                         grads={k: p.grad.detach().to(torch.bfloat16) for k, p in tr.named_parameters() if p.grad is not None})  # direction check only
+        print("transformer_unet", name, float(y.norm()))
+    torch.save(out, os.path.join(HERE, "transformer_unet.pt"))
 
 
 def gen_duration(ref):
@@ -692,10 +732,10 @@ def gen_cfg5_wc_b8(ref):
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact", "attend_mask4d"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact", "attend_mask4d", "transformer_unet"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
          "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
          "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout, "small_dimin": gen_small_dimin,
-         "cfg4_seeds_exact": gen_cfg4_seeds_exact, "attend_mask4d": gen_attend_mask4d}[w](ref)
+         "cfg4_seeds_exact": gen_cfg4_seeds_exact, "attend_mask4d": gen_attend_mask4d, "transformer_unet": gen_transformer_unet}[w](ref)

@@ -196,6 +196,23 @@ def test_standalone_transformer_state_dict(golden):
                 tr(c["x"], mask=c["mask"], adaptive_rmsnorm_cond=c["cond"])
 
 
+def test_standalone_transformer_unet_state_dict(golden):
+    """use_unet_skip_connection=True: Linear(2 * dim, dim) at layers[i][0] of the second half, None in the first (:394-398)."""
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("transformer_unet")
+    for name, c in g.items():
+        tr = vbx.Transformer(dim=64, depth=4, dim_head=64, heads=2, use_unet_skip_connection=True, **c["kw"])
+        mine = {k: tuple(v.shape) for k, v in tr.state_dict().items() if "inv_freq" not in k}
+        ref = {k: tuple(v.shape) for k, v in c["state"].items() if "inv_freq" not in k}
+        assert mine == ref, name
+        assert tr.layers[0][0] is None and tr.layers[1][0] is None and tuple(tr.layers[2][0].weight.shape) == (64, 128)
+        assert tr.skip_connect_scale == (c["kw"].get("skip_connect_scale") or 2 ** -0.5)
+        assert not tr.load_state_dict(c["state"], strict=False).unexpected_keys
+        fp = tr.flat_params()
+        assert "L2.SKW" in fp.offsets and "L3.SKB" in fp.offsets and "L1.SKW" not in fp.offsets
+
+
 def test_midpoint_tables_match_oracle_grid():
     """dt_i = t[i+1]-t[i] from the same fp32 linspace as the oracle: linspace(0,1,64) has several distinct dt."""
     t = torch.linspace(0, 1, 64)

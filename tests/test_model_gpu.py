@@ -498,6 +498,53 @@ def test_standalone_transformer_golden(golden):
         assert rel(y2, y) < 1e-6
 
 
+def test_standalone_transformer_unet_golden(golden):
+    """Transformer(use_unet_skip_connection=True) (voicebox_pytorch.py:368-369,391-398,453-463), depth 4 = two skip combiners, through
+    the stack-only runtime: output vs the reference golden; every gradient (the combiners' weight and bias included) vs the
+    emulated-precision oracle and in direction vs the reference; inference call equals the training call."""
+    import voicebox_pytorch_amd as vbx
+
+    g = golden("transformer_unet")
+    for name, c in g.items():
+        kw = c["kw"]
+        tr = vbx.Transformer(dim=64, depth=4, dim_head=64, heads=2, use_unet_skip_connection=True, **kw)
+        assert not tr.load_state_dict(c["state"], strict=False).unexpected_keys
+        tr = tr.to(dev)
+        x = c["x"].to(dev).requires_grad_(True)
+        cond = c["cond"].to(dev).requires_grad_(True) if c["cond"] is not None else None
+        mask = c["mask"].to(dev) if c["mask"] is not None else None
+        y = tr(x, mask=mask, adaptive_rmsnorm_cond=cond)
+        assert y.shape == c["y"].shape
+        assert rel(y, c["y"]) < 2e-2, (name, rel(y, c["y"]))
+        (y * c["dout"].to(dev)).sum().backward()
+        cfg = restate.Cfg(dim=64, depth=4, heads=2, dim_head=64, num_register_tokens=kw["num_register_tokens"],
+                          qk_norm=kw["attn_qk_norm"], use_gateloop=bool(kw.get("use_gateloop_layers")))
+        cfg.skip_connect_scale = kw.get("skip_connect_scale") or 2 ** -0.5
+        p = {k: v.double().clone().requires_grad_(v.is_floating_point()) for k, v in c["state"].items()}
+        xe = c["x"].double().clone().requires_grad_(True)
+        ce = c["cond"].double().clone().requires_grad_(True) if c["cond"] is not None else None
+        with restate.emulate_fp16_operands():
+            ye = restate.transformer(xe, p, cfg, mask=c["mask"], cond=ce, pre="")
+        assert rel(y, ye) < 5e-3, (name, rel(y, ye))
+        (ye * c["dout"].double()).sum().backward()
+        named = dict(tr.named_parameters())
+        errs = {k: rel(named[k].grad, v.grad) for k, v in p.items() if v.grad is not None}
+        errs["x"] = rel(x.grad, xe.grad)
+        if cond is not None:
+            errs["cond"] = rel(cond.grad, ce.grad)
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])
+        print("standalone transformer, u-net", name, [(k, round(v, 4)) for k, v in worst[:6]],
+              {k: round(v, 4) for k, v in errs.items() if ".0.weight" in k or ".0.bias" in k and k.count(".") == 2})
+        assert worst[0][1] < 0.15, (name, worst[:6])
+        for k in ("layers.2.0.weight", "layers.2.0.bias", "layers.3.0.weight", "layers.3.0.bias"):
+            assert errs[k] < 2e-2, (name, k, errs[k])
+        assert flat_cos(named, {k: v.float() for k, v in c["grads"].items()}) > 0.9
+        assert rel(x.grad, c["dx"]) < 0.2
+        with torch.no_grad():
+            y2 = tr(c["x"].to(dev), mask=mask, adaptive_rmsnorm_cond=cond.detach() if cond is not None else None)
+        assert rel(y2, y) < 1e-6
+
+
 def test_text_conditioned_model_golden(golden):
     """condition_on_text=True through the public API (phoneme_ids / semantic_token_ids, classifier-free-guidance drop, guided
     sampling): loss vs the unmodified reference, every gradient (incl. the embedding table) vs the emulated-precision oracle."""
@@ -599,6 +646,12 @@ def test_duration_predictor_golden(golden):
         with pytest.raises(NotImplementedError):
             dp.train()(cond=cond, phoneme_ids=ids)
         dp.eval()
+        # a checkpoint configured with dropout (:631-642) loads and, in eval mode, predicts the same durations bit for bit
+        dpd = vbx.DurationPredictor(num_phoneme_tokens=37, dim_phoneme_emb=32, dim=64, depth=2, dim_head=64, heads=2,
+                                    attn_dropout=0.1, ff_dropout=0.2, **c["kw"])
+        dpd.load_state_dict(c["state"], strict=False)
+        dpd = dpd.to(dev).eval()
+        assert torch.equal(dpd(cond=cond, phoneme_ids=ids, cond_mask=cm), d1), name
 
     # sampler: phoneme ids -> DurationPredictor -> frame-aligned ids == sampling from those ids directly (:1231-1255)
     c = g["short_cond"]

@@ -180,6 +180,28 @@ def test_standalone_transformer(golden):
             assert float((p[k].grad - ref).norm() / ref.norm().clamp(min=1e-20)) < 2e-3, (name, k)
 
 
+def test_standalone_transformer_unet(golden):
+    """restate.transformer with the u-net skip combiners (voicebox_pytorch.py:453-463; depth 4, custom and default
+    skip_connect_scale, with GateLoop layers) vs the reference's Transformer(use_unet_skip_connection=True)."""
+    g = golden("transformer_unet")
+    for name, c in g.items():
+        kw = c["kw"]
+        cfg = restate.Cfg(dim=64, depth=4, heads=2, dim_head=64, num_register_tokens=kw["num_register_tokens"],
+                          qk_norm=kw["attn_qk_norm"], use_gateloop=bool(kw.get("use_gateloop_layers")))
+        cfg.skip_connect_scale = kw.get("skip_connect_scale") or 2 ** -0.5
+        p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in c["state"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        cond = c["cond"].clone().requires_grad_(True) if c["cond"] is not None else None
+        y = restate.transformer(x, p, cfg, mask=c["mask"], cond=cond, pre="")
+        assert float((y - c["y"]).norm() / c["y"].norm()) < 1e-5, name
+        (y * c["dout"]).sum().backward()
+        assert float((x.grad - c["dx"]).norm() / c["dx"].norm()) < 2e-3, name
+        if cond is not None:
+            assert float((cond.grad - c["dcond"]).norm() / c["dcond"].norm()) < 2e-3, name
+        for k, ref in c["grads"].items():  # stored as bf16
+            assert float((p[k].grad - ref.float()).norm() / ref.float().norm().clamp(min=1e-20)) < 1e-2, (name, k)
+
+
 def test_duration_predictor_inference(golden):
     """restate.duration_predictor_* vs the reference's DurationPredictor in eval mode (durations, CFG mix, aligned ids)."""
     g = golden("duration")

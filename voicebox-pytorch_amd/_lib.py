@@ -57,6 +57,9 @@ _PROTOS = {
     "vbx_rowdot": [P, P, P, P, L, I, P],
     "vbx_stack_input": [P, P, P, I, I, I, I, P],
     "vbx_stack_input_bwd": [P, P, P, I, I, I, I, P],
+    "vbx_unet_cat": [P, P, F, P, P, L, I, P],
+    "vbx_unet_split": [P, F, P, P, P, L, I, P],
+    "vbx_unet_addskip": [P, P, P, L, P],
     "vbx_rmsnorm_fwd_f32": [P, P, P, L, P, I, I, I, I, I, P],
     "vbx_convpos_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "vbx_convpos_fwd_libm": [P, P, P, P, P, P, I, I, I, I, I, P],

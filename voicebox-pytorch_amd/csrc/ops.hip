@@ -248,6 +248,48 @@ __global__ void stack_rows_kernel(const float* __restrict__ src, float* __restri
   }
 }
 
+// u-net skip connections of the standalone Transformer (voicebox_pytorch.py:458-463)
+__global__ void unet_cat_kernel(const float* __restrict__ x, const float* __restrict__ skip, float scale, u16* __restrict__ o16,
+                                u16* __restrict__ ob, long rows, int D) {
+  const int cpr = D / 4;
+  const long total = rows * 2 * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / (2 * cpr);
+    const int c = (int)(i - row * 2 * cpr);
+    const bool second = c >= cpr;
+    const int d = (second ? c - cpr : c) * 4;
+    float4 v = *reinterpret_cast<const float4*>((second ? skip : x) + row * D + d);
+    if (second) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+    const long oo = row * 2 * D + (second ? D : 0) + d;
+    if (o16) *reinterpret_cast<uint2*>(o16 + oo) = make_uint2(pack_f16x2_sat(v.x, v.y), pack_f16x2_sat(v.z, v.w));
+    if (ob) *reinterpret_cast<uint2*>(ob + oo) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+}
+__global__ void unet_split_kernel(const float* __restrict__ dcat, float scale, float* __restrict__ dx, u16* __restrict__ dxb,
+                                  float* __restrict__ dskip, long rows, int D) {
+  const int cpr = D / 4;
+  const long total = rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cpr;
+    const int d = (int)(i - row * cpr) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(dcat + row * 2 * D + d);
+    float4 b = *reinterpret_cast<const float4*>(dcat + row * 2 * D + D + d);
+    b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+    *reinterpret_cast<float4*>(dx + row * D + d) = a;
+    if (dxb) *reinterpret_cast<uint2*>(dxb + row * D + d) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+    *reinterpret_cast<float4*>(dskip + row * D + d) = b;
+  }
+}
+__global__ void unet_addskip_kernel(float* __restrict__ dx, u16* __restrict__ dxb, const float* __restrict__ dskip, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(dx)[i];
+    const float4 b = reinterpret_cast<const float4*>(dskip)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(dx)[i] = a;
+    if (dxb) reinterpret_cast<uint2*>(dxb)[i] = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+  }
+}
+
 __global__ void regs_fill_kernel(const float* __restrict__ reg, float* __restrict__ xs, int B, int Np, int R, int D) {
   const long total = (long)B * R * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1356,6 +1398,25 @@ extern "C" int vbx_stack_input(const float* x, const float* reg, float* xs, int 
     hipLaunchKernelGGL(regs_fill_kernel, dim3(grid_for((long)B * R * D)), dim3(256), 0, ST, reg, xs, B, N + R, R, D);
     VBX_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int vbx_unet_cat(const float* x, const float* skip, float scale, void* cat_f16, void* cat_bf16, long rows, int D, void* stream) {
+  VBX_REQUIRE(x && skip && (cat_f16 || cat_bf16) && rows > 0 && D > 0 && D % 4 == 0, "vbx_unet_cat: bad args");
+  hipLaunchKernelGGL(unet_cat_kernel, dim3(grid_for(rows * D / 2)), dim3(256), 0, ST, x, skip, scale, (u16*)cat_f16, (u16*)cat_bf16, rows, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_unet_split(const float* dcat, float scale, float* dx, void* dx_bf16, float* dskip, long rows, int D, void* stream) {
+  VBX_REQUIRE(dcat && dx && dskip && rows > 0 && D > 0 && D % 4 == 0, "vbx_unet_split: bad args");
+  hipLaunchKernelGGL(unet_split_kernel, dim3(grid_for(rows * D / 4)), dim3(256), 0, ST, dcat, scale, dx, (u16*)dx_bf16, dskip, rows, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_unet_addskip(float* dx, void* dx_bf16, const float* dskip, long n, void* stream) {
+  VBX_REQUIRE(dx && dskip && n > 0 && n % 4 == 0, "vbx_unet_addskip: bad args");
+  hipLaunchKernelGGL(unet_addskip_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, dx, (u16*)dx_bf16, dskip, n / 4);
+  VBX_LAUNCH_CHECK();
   return 0;
 }
 

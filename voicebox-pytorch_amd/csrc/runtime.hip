@@ -52,6 +52,7 @@ Dims dims_of(const vbx_model* m) {
 // *h = fp16 copy (forward NT GEMMs), plain = bf16 copy (backward dgrad NN GEMMs)
 struct WLayer {
   u16 *qkv, *qkvh, *out, *outh, *w1, *w1h, *w2, *w2h, *glw, *glwh;
+  u16 *skw = nullptr, *skwh = nullptr;  // u-net skip combiner [D, 2D] of the second-half layers
   float* b1;
 };
 struct WPack {
@@ -82,6 +83,10 @@ void carve_wpack(const vbx_model* m, WPack& w) {
     w.layer[l].w2h = c.take<u16>((size_t)d.D * d.Fp);
     w.layer[l].glw = m->gateloop ? c.take<u16>((size_t)3 * d.D * d.D) : nullptr;
     w.layer[l].glwh = m->gateloop ? c.take<u16>((size_t)3 * d.D * d.D) : nullptr;
+    if (m->unet && l >= d.L / 2) {
+      w.layer[l].skw = c.take<u16>((size_t)2 * d.D * d.D);
+      w.layer[l].skwh = c.take<u16>((size_t)2 * d.D * d.D);
+    }
   }
   w.bytes = al256(c.off);
 }
@@ -98,6 +103,12 @@ struct Acts {
   u16 *embed_in, *embed_inh;
   float *e, *four, *pre, *temb, *ada;
   std::vector<float*> xs;  // residual snapshots
+  // u-net skip connections (vbx_model.unet): xc[l] = combined input of layer l >= L/2, cat16 / catb = the combiner's [M, 2D] operand
+  // (fp16 forward, bf16 recomputed for its weight gradient), dcat = d(cat) fp32, dskip[p] = gradient that reaches the input of
+  // layer p < L/2 through its skip, added when the backward gets there
+  std::vector<float*> xc, dskip;
+  u16 *cat16 = nullptr, *catb = nullptr;
+  float* dcat = nullptr;
   std::vector<ALayer> layer;
   u16 *hf, *hfh;
   float *pred, *per_b;
@@ -185,11 +196,22 @@ void carve_acts(const vbx_model* m, Acts& a) {
   a.temb = c.take<float>((size_t)d.B * d.Th);
   a.ada = c.take<float>((size_t)d.B * d.J);
   const int S = m->gateloop ? 3 : 2;  // residual updates per layer
-  const int nxs = tr ? S * d.L + 1 : 2;
+  const bool keep = tr || m->unet;  // u-net: the first-half layer inputs are read again by the second half, also in inference
+  const int nxs = keep ? S * d.L + 1 : 2;
   a.xs.resize(S * d.L + 1);
   std::vector<float*> bufs(nxs);
   for (int i = 0; i < nxs; i++) bufs[i] = c.take<float>((size_t)d.M * d.D);
-  for (int i = 0; i <= S * d.L; i++) a.xs[i] = bufs[tr ? i : (i & 1)];
+  for (int i = 0; i <= S * d.L; i++) a.xs[i] = bufs[keep ? i : (i & 1)];
+  a.xc.assign(d.L, nullptr);
+  a.dskip.assign(d.L, nullptr);
+  if (m->unet) {
+    float* shared_xc = nullptr;
+    for (int l = d.L / 2; l < d.L; l++) {
+      if (tr || !shared_xc) shared_xc = c.take<float>((size_t)d.M * d.D);
+      a.xc[l] = shared_xc;
+    }
+    a.cat16 = c.take<u16>((size_t)d.M * 2 * d.D);
+  }
   a.layer.resize(d.L);
   const size_t hs = (size_t)d.B * d.H * d.Np * 64;
   ALayer shared{};
@@ -256,6 +278,7 @@ void carve_acts(const vbx_model* m, Acts& a) {
     upd(3 * d.I, d.D, d.M); upd(d.D, d.I, d.M); upd(2 * d.Fp, d.D, d.M); upd(d.D, d.Fp, d.M);
     upd(d.D, d.Ke, d.M0); upd(d.Din, d.D, d.M0);
     if (m->gateloop) upd(3 * d.D, d.D, d.M);
+    if (m->unet) upd(d.D, 2 * d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(4 * sf);  // four regions: the layer's weight-gradient slabs stay live until its batched reduce
     a.npart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // >= the LayerNorm backward's 16-row records
@@ -283,6 +306,11 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.demb = d.E ? c.take<u16>((size_t)d.M0 * d.E) : nullptr;
     a.dxb2 = c.take<u16>((size_t)d.M * d.D);  // always carved: the arena layout must not depend on run-time tuning knobs
     a.attn_scratch = c.take<char>(vbx_attn_bwd_scratch_bytes(d.B, d.H, d.Np));
+    if (m->unet) {
+      a.catb = c.take<u16>((size_t)d.M * 2 * d.D);
+      a.dcat = c.take<float>((size_t)d.M * 2 * d.D);
+      for (int p = 0; p < d.L / 2; p++) a.dskip[p] = c.take<float>((size_t)d.M * d.D);
+    }
   }
   a.bytes = al256(c.off);
 }
@@ -348,7 +376,15 @@ int check_model(const vbx_model* m) {
   VBX_REQUIRE(!m->plain_norm || m->stack_only, "vbx_model: plain_norm is only used by the standalone stack (VoiceBox is adaptive)");
   VBX_REQUIRE(m->Din >= 0 && m->Din % 8 == 0 && (m->Din == 0 || !m->stack_only), "vbx_model: dim_in must be a multiple of 8 (got %d)", m->Din);
   VBX_REQUIRE(m->attn_dropout >= 0.f && m->attn_dropout < 1.f && m->ff_dropout >= 0.f && m->ff_dropout < 1.f, "vbx_model: dropout must be in [0, 1)");
+  VBX_REQUIRE(!m->unet || (m->stack_only && m->L % 2 == 0 && !m->precise),
+              "vbx_model: u-net skip connections belong to the standalone stack (even depth); VoiceBox never enables them");
   return 0;
+}
+
+// input of layer l as its blocks see it: the u-net combiner's output in the second half, else the previous layer's output
+float* layer_input(const vbx_model* m, const Acts& a, int l) {
+  const int S = m->gateloop ? 3 : 2;
+  return (m->unet && l >= m->L / 2) ? a.xc[l] : a.xs[S * l];
 }
 
 // forward GEMMs: fp16 operands
@@ -498,6 +534,7 @@ extern "C" int vbx_model_pack_weights(const vbx_model* m, void* stream) {
     CK(vbx_pack_bias(P + o[VBX_L_FF1B], 2 * d.F, w.layer[l].b1, 2 * d.Fp, 1, d.F, stream));
     CK(vbx_pack_weight(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, w.layer[l].w2h, d.D, d.Fp, 0, 0, stream));
     if (m->gateloop) CK(vbx_pack_weight(P + o[VBX_L_GLW], 3 * d.D, d.D, w.layer[l].glw, w.layer[l].glwh, 3 * d.D, d.D, 0, 0, stream));
+    if (w.layer[l].skw) CK(vbx_pack_weight(P + o[VBX_L_SKW], d.D, 2 * d.D, w.layer[l].skw, w.layer[l].skwh, d.D, 2 * d.D, 0, 0, stream));
   }
   return 0;
 }
@@ -600,12 +637,18 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     const ALayer& y = a.layer[l];
     const float* ada_l = a.ada + (size_t)l * d.B * 4 * d.D;  // [B][g1|b1|g2|b2]
     const int S = m->gateloop ? 3 : 2;
-    float* x_in = a.xs[S * l + S - 2];
+    float* x0 = layer_input(m, a, l);
+    float* x_in = m->gateloop ? a.xs[S * l + 1] : x0;
     float* x_mid = a.xs[S * l + S - 1];
     float* x_out = a.xs[S * l + S];
+    if (m->unet && l >= d.L / 2) {
+      // x = skip_combiner(cat(x, skip * skip_connect_scale))   (:458-463); the skip is the input of layer L-1-l
+      CK(vbx_unet_cat(a.xs[S * l], a.xs[S * (d.L - 1 - l)], m->skip_scale, a.cat16, nullptr, d.M, d.D, stream));
+      CK(gemm_nt(a.cat16, 2 * d.D, w.layer[l].skwh, 2 * d.D, (int)d.M, d.D, 2 * d.D, VBX_EPI_F32, x0, d.D, P + o[VBX_L_SKB], nullptr,
+                 nullptr, nullptr, st));
+    }
     if (m->gateloop) {
       // x = GateLoop(x) + x   (:465-466): RMSNorm -> to_qkva -> gated scan -> post LayerNorm + residual
-      float* x0 = a.xs[S * l];
       CK(vbx_rmsnorm_fwd(x0, P + o[VBX_L_GLG], nullptr, 0, y.hg, y.hgh, d.B, d.Np, 0, d.Np, d.D, stream));
       CK(gemm_nt(y.hgh, d.D, w.layer[l].glwh, d.D, (int)d.M, 3 * d.D, d.D, VBX_EPI_F32, y.glp, 3 * d.D, nullptr, nullptr, nullptr,
                  nullptr, st));
@@ -711,7 +754,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const int chunks = vbx_rmsnorm_bwd_chunks(d.Np), ln_chunks = (d.Np + 15) / 16;
   const int M = (int)d.M;
   const int S = m->gateloop ? 3 : 2;
-  const float* x_in = a.xs[S * l + S - 2];   // input of the attention block
+  const float* x_in = m->gateloop ? a.xs[S * l + 1] : layer_input(m, a, l);   // input of the attention block
   const float* x_mid = a.xs[S * l + S - 1];  // input of the feed-forward block
 
   static const bool batched = !(getenv("VBX_BATCH_REDUCE") && atoi(getenv("VBX_BATCH_REDUCE")) == 0);  // 0: one launch per reduction (A/B)
@@ -833,9 +876,25 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_gateloop_scan_bwd(y.glp, y.glh, a.gl_ds, a.gl_dp, d.B, d.Np, d.D, stream));
     CK(gemm_nn_bf16(a.gl_dp, 3 * d.D, w.layer[l].glw, d.D, M, d.D, 3 * d.D, a.dhn, d.D, st));
     CK(wgrad(a.gl_dp, 3 * d.D, y.hg, d.D, 3 * d.D, d.D, d.M, a.slabs, Gd + o[VBX_L_GLW], 3 * d.D, d.D, 0, 0, st));
-    CK(vbx_rmsnorm_bwd(a.xs[S * l], P + o[VBX_L_GLG], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_rmsnorm_bwd(layer_input(m, a, l), P + o[VBX_L_GLG], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
     CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
     CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_GLG], d.D, 0, stream));
+  }
+  if (m->unet && l >= d.L / 2) {
+    // ---- skip combiner: a.dx = d(combined input).  d(bias), dW = dx^T . cat, d(cat) = dx . W -> d(x) | d(skip)   (:458-463)
+    const int p = d.L - 1 - l;
+    CK(vbx_colsum_f32(a.dx, M, d.D, d.D, Gd + o[VBX_L_SKB], a.cs_scratch, stream));
+    CK(vbx_unet_cat(a.xs[S * l], a.xs[S * p], m->skip_scale, nullptr, a.catb, d.M, d.D, stream));
+    CK(wgrad(a.dxb, d.D, a.catb, 2 * d.D, d.D, 2 * d.D, d.M, a.slabs, Gd + o[VBX_L_SKW], d.D, 2 * d.D, 0, 0, st));
+    vbx_gemm_desc g{};
+    g.mode = VBX_GEMM_NN; g.epilogue = VBX_EPI_F32; g.M = M; g.N = 2 * d.D; g.K = d.D; g.lda = d.D; g.ldb = 2 * d.D; g.ldc = 2 * d.D;
+    g.A = a.dxb; g.B = w.layer[l].skw; g.C = a.dcat;
+    CK(vbx_gemm(&g, stream));
+    CK(wgrad_join(st));  // the combiner's wgrad reads a.dxb, rewritten next
+    CK(vbx_unet_split(a.dcat, m->skip_scale, a.dx, a.dxb, a.dskip[p], d.M, d.D, stream));
+  } else if (m->unet) {
+    // the input of a first-half layer also fed the combiner of layer L-1-l
+    CK(vbx_unet_addskip(a.dx, a.dxb, a.dskip[l], d.M * d.D, stream));
   }
   if (m->plain_norm) return 0;
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
@@ -937,6 +996,7 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
     add(o[VBX_L_FF1B], 2 * d.F, 1, nullptr, nullptr, w.layer[l].b1, 1, 1, d.F);
     add(o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, w.layer[l].w2h, nullptr, d.Fp, 0, 0);
     if (m->gateloop) add(o[VBX_L_GLW], 3 * d.D, d.D, w.layer[l].glw, w.layer[l].glwh, nullptr, d.D, 0, 0);
+    if (w.layer[l].skw) add(o[VBX_L_SKW], d.D, 2 * d.D, w.layer[l].skw, w.layer[l].skwh, nullptr, 2 * d.D, 0, 0);
   }
   std::sort(ps.begin(), ps.end(), [](const vbx_adam_seg& a, const vbx_adam_seg& b) { return a.off < b.off; });
   std::vector<vbx_adam_seg> all;

@@ -47,8 +47,8 @@ class DurationPredictor(nn.Module):
             raise NotImplementedError("the espeak phoneme Tokenizer is third-party: pass num_phoneme_tokens and call with phoneme_ids")
         if dim_phoneme_emb % 8 != 0:
             raise NotImplementedError("dim_phoneme_emb must be a multiple of 8 (vectorised embedding gather)")
-        if ff_dropout or attn_dropout:
-            raise NotImplementedError("dropout is not built into the fused kernels (the reference default is 0)")
+        # ff_dropout / attn_dropout go to the Transformer as in the reference (:631-642); this module only runs in eval mode (forward
+        # raises while .training), where nn.Dropout is the identity, so they never change a result here
         self.audio_enc_dec = None
         self.proj_in = nn.Identity()
         self.tokenizer = None

@@ -12,7 +12,7 @@ from ._lib import P, I, F
 # enum mirrors of include/vbx.h
 G_NAMES = ["SINW", "T1W", "T1B", "EMBW", "EMBB", "CONVW", "CONVB", "REG", "FNG", "PREDW", "CEMB"]
 L_NAMES = ["G1W", "B1W", "G2W", "B2W", "G1B", "B1B", "G2B", "B2B", "QG", "KG", "QKVW", "OUTW", "FF1W", "FF1B", "FF2W", "FF2B",
-           "GLG", "GLW", "GLLNW", "GLLNB", "N1G", "N2G"]
+           "GLG", "GLW", "GLLNW", "GLLNB", "N1G", "N2G", "SKW", "SKB"]
 NG, NL = len(G_NAMES), len(L_NAMES)
 
 
@@ -21,7 +21,7 @@ class VbxModel(C.Structure):
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
                 ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I),
-                ("precise", I), ("wpack3", P), ("pscratch", P)]
+                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F)]
 
 
 class VbxIO(C.Structure):
@@ -240,6 +240,8 @@ class Engine:
         m.attn_dropout = float(cfg.get("attn_dropout", 0.))
         m.ff_dropout = float(cfg.get("ff_dropout", 0.))
         m.Din = int(cfg.get("Din", 0) or 0)  # data width (dim_in); 0 = D
+        m.unet = 1 if cfg.get("unet") else 0
+        m.skip_scale = float(cfg.get("skip_scale", 2 ** -0.5))
         self.Din = m.Din or cfg["D"]
         self.has_dropout = m.attn_dropout > 0. or m.ff_dropout > 0.
         self.dropout_active = False  # nn.Dropout semantics: the owning module sets this to its .training flag before a forward

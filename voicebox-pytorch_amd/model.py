@@ -236,8 +236,6 @@ class Transformer(nn.Module):
                  gateloop_use_jax=False):
         super().__init__()
         assert depth % 2 == 0
-        if use_unet_skip_connection:
-            raise NotImplementedError("u-net skip connections are never enabled by VoiceBox (voicebox_pytorch.py:948-962)")
         self.layers = nn.ModuleList([])
         self.rotary_emb = RotaryEmbedding(dim=dim_head)
         self.num_register_tokens = int(num_register_tokens)
@@ -254,14 +252,17 @@ class Transformer(nn.Module):
                          R=int(num_register_tokens), ksize=31, qk_norm=bool(attn_qk_norm),
                          attn_scale=10.0 if attn_qk_norm else dim_head ** -0.5, theta=50000.0,
                          gateloop=bool(use_gateloop_layers), stack_only=True, plain_norm=not adaptive_rmsnorm,
-                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout))
+                         attn_dropout=float(attn_dropout), ff_dropout=float(ff_dropout),
+                         unet=bool(use_unet_skip_connection), skip_scale=float(default(skip_connect_scale, 2 ** -0.5)))
         self._flat = None
         self._engines = {}
         norm = (lambda: AdaptiveRMSNorm(dim, cond_dim=adaptive_rmsnorm_cond_dim_in)) if adaptive_rmsnorm else (lambda: RMSNorm(dim))
         self.skip_connect_scale = default(skip_connect_scale, 2 ** -0.5)
-        for _ in range(depth):
+        for ind in range(depth):
+            has_skip = use_unet_skip_connection and (ind + 1) > (depth // 2)  # :394-398: the second half combines with the first half's inputs
             self.layers.append(nn.ModuleList([
-                None, GateLoop(dim=dim, use_jax_associative_scan=gateloop_use_jax) if use_gateloop_layers else None, norm(),
+                nn.Linear(dim * 2, dim) if has_skip else None,
+                GateLoop(dim=dim, use_jax_associative_scan=gateloop_use_jax) if use_gateloop_layers else None, norm(),
                 Attention(dim=dim, dim_head=dim_head, heads=heads, dropout=attn_dropout, flash=attn_flash, qk_norm=attn_qk_norm),
                 norm(), FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout)]))
         self.final_norm = RMSNorm(dim)
@@ -273,8 +274,10 @@ class Transformer(nn.Module):
     # ---- native plumbing of the standalone call (VoiceBox owns its own flat buffer over the same parameters)
     def _layer_slots(self, s):
         for l, layer in enumerate(self.layers):
-            _, gl, n1, attn, n2, ff = layer
+            skip, gl, n1, attn, n2, ff = layer
             p = f"L{l}."
+            if skip is not None:
+                s[p + "SKW"], s[p + "SKB"] = skip.weight, skip.bias
             if gl is not None:
                 s[p + "GLG"], s[p + "GLW"] = gl.norm.gamma, gl.to_qkva[0].weight
                 s[p + "GLLNW"], s[p + "GLLNB"] = gl.maybe_post_ln.weight, gl.maybe_post_ln.bias
