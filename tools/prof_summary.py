@@ -21,7 +21,19 @@ rows = from_db(sys.argv[1]) if sys.argv[1].endswith(".db") else from_csv(sys.arg
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 rows.sort(key=lambda r: -r[2])
 tot = sum(r[2] for r in rows)
+# a kernel whose call count is not a multiple of the step count ran in the one-time setup (parameter flattening: one copy per
+# nn.Parameter; weight packing; random-init fills), not in the steps
+isteps = int(steps)
+per_step = [r for r in rows if isteps > 0 and r[1] % isteps == 0]
+setup = [r for r in rows if r not in per_step]
+mfma = lambda n: re.search(r"gemm|attn_(fwd|bwd)", n) is not None
 print(f"total kernel time {tot/1e3:.2f} ms over {steps:g} steps = {tot/1e3/steps:.3f} ms/step")
+if isteps > 1:
+    ps_t, ps_c = sum(r[2] for r in per_step), sum(r[1] for r in per_step)
+    mf_t, mf_c = sum(r[2] for r in per_step if mfma(r[0])), sum(r[1] for r in per_step if mfma(r[0]))
+    print(f"per-step kernels: {ps_c/steps:.0f} launches, {ps_t/1e3/steps:.3f} ms per step (MFMA kernels {mf_c/steps:.0f} launches, "
+          f"{mf_t/1e3/steps:.3f} ms; others {(ps_c-mf_c)/steps:.0f} launches, {(ps_t-mf_t)/1e3/steps:.3f} ms); one-time setup: "
+          f"{sum(r[1] for r in setup)} launches, {sum(r[2] for r in setup)/1e3:.2f} ms in total")
 print(f"{'kernel':92s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} {'%':>6s}")
 for n, c, t, a in rows[:45]:
-    print(f"{short(n):92s} {c:6d} {t:10.1f} {a:9.2f} {100*t/tot:6.2f}")
+    print(f"{short(n):92s} {c:6d} {t:10.1f} {a:9.2f} {100*t/tot:6.2f}" + ("" if (n, c, t, a) in per_step or isteps <= 1 else "  (setup)"))
