@@ -21,10 +21,10 @@ rows = from_db(sys.argv[1]) if sys.argv[1].endswith(".db") else from_csv(sys.arg
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 rows.sort(key=lambda r: -r[2])
 tot = sum(r[2] for r in rows)
-# a kernel whose call count is not a multiple of the step count ran in the one-time setup (parameter flattening: one copy per
-# nn.Parameter; weight packing; random-init fills), not in the steps
+# one-time setup, not part of a step: parameter flattening (one device copy per nn.Parameter) and the first weight packing
 isteps = int(steps)
-per_step = [r for r in rows if isteps > 0 and r[1] % isteps == 0]
+SETUP = re.compile(r"copyBuffer|pack_weight_kernel|pack_bias_kernel")  # (their call counts are not multiples of the step count)
+per_step = [r for r in rows if not (SETUP.search(r[0]) and isteps > 0 and r[1] % isteps != 0)]
 setup = [r for r in rows if r not in per_step]
 mfma = lambda n: re.search(r"gemm|attn_(fwd|bwd)", n) is not None
 print(f"total kernel time {tot/1e3:.2f} ms over {steps:g} steps = {tot/1e3/steps:.3f} ms/step")
