@@ -32,3 +32,4 @@ python tools/prof_summary.py $(find $O/prof_sample -name "*.db" | head -1) 18 > 
 python tools/pmc_summary.py $O/${T}_train_pmc.json $O/pmc_fetch $O/pmc_write $O/pmc_mfma > $O/${T}_train_pmc.txt 2>&1
 rm -rf $O/prof_train $O/prof_sample $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 head -24 $O/${T}_train_step_kernel_stats.txt
+bash tools/precise_report.sh $T > /dev/null 2>&1; tail -12 $O/r04_precise_parity.txt
