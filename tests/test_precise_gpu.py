@@ -216,16 +216,19 @@ def test_precise_small_golden(golden):
         for k in ("to_pred.weight", "transformer.final_norm.gamma", "transformer.layers.1.5.3.weight"):
             assert rel(named[k].grad, g[grads_key][k]) < 5e-2, (k, rel(named[k].grad, g[grads_key][k]))
         assert all(torch.isfinite(p.grad).all() for p in vb.parameters() if p.grad is not None)
-        # every gradient vs the unmodified reference, by the number of softmaxes between tensor and loss (test_model_gpu.py): the
-        # backward still multiplies bf16 operands and recomputes P from the fp16 q / k, so the classes keep the fast path's bounds
-        from test_model_gpu import REF_GRAD_CLASS0, REF_GRAD_CLASS1, softmaxes_downstream, flat_cos
+        # every gradient vs the UNMODIFIED REFERENCE, by the number of softmaxes between tensor and loss (test_model_gpu.py).  With
+        # exact saved activations only the bf16 backward operands (and P recomputed from the fp16 q / k) remain: measured 0.5 % / 4.2 % /
+        # 6.8 % for 0 / 1 / 2 softmaxes downstream, where the fast path has 2.3 % / 20-43 % / ~150 % -- so here EVERY tensor is asserted
+        from test_model_gpu import softmaxes_downstream, flat_cos
+        REF_GRAD_CLASS0, REF_GRAD_CLASS1, REF_GRAD_CLASS2 = 0.02, 0.10, 0.15
         worst = {0: 0.0, 1: 0.0, 2: 0.0}
         for k, ref in g[grads_key].items():
             c = min(softmaxes_downstream(k, g["cfg"]["depth"]), 2)
             worst[c] = max(worst[c], rel(named[k].grad, ref))
         print(f"small golden ({mask_key}), precise forward + bf16 backward: worst gradient error by class {worst}, "
               f"cosine {flat_cos(named, g[grads_key]):.4f}")
-        assert worst[0] < REF_GRAD_CLASS0 and worst[1] < REF_GRAD_CLASS1, worst
+        assert worst[0] < REF_GRAD_CLASS0 and worst[1] < REF_GRAD_CLASS1 and worst[2] < REF_GRAD_CLASS2, worst
+        assert flat_cos(named, g[grads_key]) > 0.999
     vb.eval()
     with vbx.precise_mode(), torch.no_grad():
         pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["cond"].to(dev),
