@@ -323,7 +323,7 @@ def test_precise_cfg3_reference_init(golden):
         else:
             e = golden("cfg4_seeds_exact")["cfg3_init"]
             print(f"   cfg3 init: exact(fp64) - reference {e['exact'] - e['golden']:+.2e}, fp32 restatement - reference {e['fp32_restatement'] - e['golden']:+.2e}")
-            assert dl < 2e-3, dl          # measured 9.3e-4; the exact value is 7.5e-4 from the reference (fast path: 2.7e-3)
+            assert dl < 2e-3, dl          # measured 1.8e-4 .. 9.3e-4; the exact value is 7.5e-4 from the reference (fast path: 2.7e-3)
         del vb, wrapper
         torch.cuda.empty_cache()
 
