@@ -281,6 +281,7 @@ def test_precise_cfg4_reference_init_all_seeds(golden):
         assert abs(e["golden"] - float(g[s_]["loss"])) < 1e-7
         print(f"  {s_}: {diffs[s_]:+.2e} | {e['exact'] - e['golden']:+.2e} | {e['fp32_restatement'] - e['golden']:+.2e} | {losses[s_] - e['exact']:+.2e}")
     print("PRECISE cfg4 reference-init total-gradient-norm relative differences (bf16-operand backward)", {k: round(v, 3) for k, v in gtot.items()})
+    assert max(gtot.values()) < 0.15, gtot  # measured 1.5 - 9.8 % (the fast path: 5 - 17 %)
     mean_abs = sum(abs(v) for v in diffs.values()) / len(diffs)
     assert max(abs(v) for v in diffs.values()) < 3e-3 and mean_abs < 1.5e-3, (diffs, mean_abs)
     assert max(abs(losses[s_] - ex[f"cfg4_seed{s_}"]["exact"]) for s_ in losses) < 3e-3
