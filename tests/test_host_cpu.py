@@ -213,6 +213,57 @@ def test_standalone_transformer_unet_state_dict(golden):
         assert "L2.SKW" in fp.offsets and "L3.SKB" in fp.offsets and "L1.SKW" not in fp.offsets
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The structs that cross the C ABI by pointer (vbx_model, vbx_io, vbx_gemm_desc, vbx_adam_seg) are declared twice -- include/vbx.h
+    and the ctypes mirrors of the host side.  gcc compiles the header and prints sizeof / offsetof of every mirrored field; a
+    field added on one side only (or in another place) fails here instead of as silent garbage on the GPU box."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    from voicebox_pytorch_amd import _lib, engine
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("vbx_model", engine.VbxModel), ("vbx_io", engine.VbxIO), ("vbx_adam_seg", engine.VbxAdamSeg), ("vbx_gemm_desc", _lib.GemmDesc)]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "vbx.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_ctypes_prototypes_match_the_header_argument_counts():
+    """Every entry point bound in _lib._PROTOS takes as many arguments as include/vbx.h declares for it (ctypes would happily pass too
+    few or too many)."""
+    import re
+
+    from voicebox_pytorch_amd import _lib
+
+    h = open(os.path.join(ROOT, "include", "vbx.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//[^\n]*", "", h)
+    declared = {}
+    for m in re.finditer(r"\b(?:int|size_t|void\*|const char\*|unsigned|long)\s+(vbx_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+        args = m.group(2).strip()
+        declared[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    assert len(declared) > 90
+    missing = [k for k in _lib._PROTOS if k not in declared]
+    assert not missing, missing
+    bad = [(k, declared[k], len(v)) for k, v in _lib._PROTOS.items() if declared[k] != len(v)]
+    assert not bad, bad
+
+
 def test_midpoint_tables_match_oracle_grid():
     """dt_i = t[i+1]-t[i] from the same fp32 linspace as the oracle: linspace(0,1,64) has several distinct dt."""
     t = torch.linspace(0, 1, 64)
