@@ -535,7 +535,7 @@ def test_standalone_transformer_unet_golden(golden):
         worst = sorted(errs.items(), key=lambda kv: -kv[1])
         print("standalone transformer, u-net", name, [(k, round(v, 4)) for k, v in worst[:6]],
               {k: round(v, 4) for k, v in errs.items() if ".0.weight" in k or ".0.bias" in k and k.count(".") == 2})
-        assert worst[0][1] < 0.15, (name, worst[:6])
+        assert worst[0][1] < 0.05, (name, worst[:6])  # measured <= 1.5 % (well-conditioned logits)
         for k in ("layers.2.0.weight", "layers.2.0.bias", "layers.3.0.weight", "layers.3.0.bias"):
             assert errs[k] < 2e-2, (name, k, errs[k])
         assert flat_cos(named, {k: v.float() for k, v in c["grads"].items()}) > 0.9
@@ -543,6 +543,49 @@ def test_standalone_transformer_unet_golden(golden):
         with torch.no_grad():
             y2 = tr(c["x"].to(dev), mask=mask, adaptive_rmsnorm_cond=cond.detach() if cond is not None else None)
         assert rel(y2, y) < 1e-6
+
+
+def test_standalone_transformer_unet_ragged_shape_vs_oracle():
+    """u-net skips at a shape that is no multiple of any tile (dim 128, 2 x 301 frames + 16 registers = 634 rows, key-padding mask,
+    depth 6 = three nested skips): output and every gradient vs the emulated-precision fp64 oracle on the same seeded weights."""
+    import voicebox_pytorch_amd as vbx
+
+    torch.manual_seed(21)
+    kw = dict(num_register_tokens=16, adaptive_rmsnorm=True, adaptive_rmsnorm_cond_dim_in=64, attn_qk_norm=True)
+    tr = vbx.Transformer(dim=128, depth=6, dim_head=64, heads=2, use_unet_skip_connection=True, **kw)
+    with torch.no_grad():
+        for n, prm in tr.named_parameters():
+            if ".to_gamma." in n or ".to_beta." in n:
+                prm.add_(torch.randn_like(prm) * 0.05)
+            if "q_norm.gamma" in n or "k_norm.gamma" in n:
+                prm.mul_(0.25)
+    state = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    tr = tr.to(dev)
+    b, n = 2, 301
+    x0 = torch.randn(b, n, 128)
+    c0 = torch.randn(b, 64)
+    mask = torch.ones(b, n, dtype=torch.bool)
+    mask[1, 250:] = False
+    dout = torch.randn(b, n, 128)
+    x = x0.to(dev).requires_grad_(True)
+    cond = c0.to(dev).requires_grad_(True)
+    y = tr(x, mask=mask.to(dev), adaptive_rmsnorm_cond=cond)
+    (y * dout.to(dev)).sum().backward()
+    cfg = restate.Cfg(dim=128, depth=6, heads=2, dim_head=64, num_register_tokens=16, qk_norm=True)
+    p = {k: v.double().clone().requires_grad_(v.is_floating_point()) for k, v in state.items()}
+    xe, ce = x0.double().requires_grad_(True), c0.double().requires_grad_(True)
+    with restate.emulate_fp16_operands():
+        ye = restate.transformer(xe, p, cfg, mask=mask, cond=ce, pre="")
+    assert rel(y, ye) < 5e-3, rel(y, ye)
+    (ye * dout.double()).sum().backward()
+    named = dict(tr.named_parameters())
+    errs = {k: rel(named[k].grad, v.grad) for k, v in p.items() if v.grad is not None}
+    errs["x"], errs["cond"] = rel(x.grad, xe.grad), rel(cond.grad, ce.grad)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])
+    print("u-net, ragged shape:", [(k, round(v, 4)) for k, v in worst[:5]])
+    assert worst[0][1] < 0.05, worst[:5]  # measured 1.5 %
+    for l in (3, 4, 5):
+        assert errs[f"layers.{l}.0.weight"] < 3e-2 and errs[f"layers.{l}.0.bias"] < 3e-2, (l, errs[f"layers.{l}.0.weight"])
 
 
 def test_text_conditioned_model_golden(golden):
