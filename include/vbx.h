@@ -81,6 +81,8 @@ typedef struct {
                              * C as fp16. */
   void* v16;                /* EPI_QKV: fp16 copy of v [B,H,Np,64] (forward P.V operand); v (bf16) may then be NULL */
   void* C3;                 /* EPI_GEGLU: optional bf16 copy of C [M,ldc] (wgrad operand) */
+  float q_prescale;         /* EPI_QKV: q16 is written as q-hat * q_prescale (vbx_attn_q_prescale(scale): the attention kernels'
+                             * contract); <= 0 means 1.  qb / k16 / kb are never scaled. */
 } vbx_gemm_desc;
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
@@ -123,7 +125,13 @@ int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_stride, const vo
 /* ------------------------------------------------------------------ attention */
 /* Attend.forward math path (attend.py:121-135): softmax(scale * q k^T + key-pad mask) v, fused
  * flash-style (scores never materialised).  q16,k16,v16 fp16 are [B,H,Np,64]; mask uint8
- * [B,Np] or NULL; lse fp32 [B,H,Np] in log2 units (m + log2 l). */
+ * [B,Np] or NULL; lse fp32 [B,H,Np] in log2 units (m + log2 l).
+ * CONTRACT (round 5, every vbx_attn_* entry point): q16 holds q PRE-MULTIPLIED by scale * log2(e) (vbx_attn_q_prescale(scale)),
+ * so that q16 . k16 is directly the exponent of exp2 -- the kernels fold the softmax statistics into the MFMA accumulator
+ * (csrc/attn_bwd_fold.inc) and have no per-element scale multiply left.  The to_qkv epilogue writes it that way
+ * (vbx_gemm_desc.q_prescale); a caller with plain fp32 q multiplies before rounding to fp16.  qb (the bf16 backward operand)
+ * stays UNSCALED; `scale` remains the multiplier of dq / dk, which are gradients w.r.t. the unscaled q / k. */
+float vbx_attn_q_prescale(float scale);
 int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, const uint8_t* mask,
                  void* out16 /* fp16 [B,Np,H*64] */, void* out_bf16 /* optional bf16 copy (backward operand) */,
                  float* lse, int B, int H, int Np, float scale, void* stream);
@@ -190,7 +198,7 @@ int vbx_attn_bwd_fused_dropout(const void* q16, const void* k16, const void* qb,
 int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
                         const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
                         const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H, int Np,
-                        void* stream);
+                        float q16_scale /* the factor q16 carries: vbx_attn_q_prescale(scale) */, void* stream);
 
 /* ------------------------------------------------------------------ small / memory-bound ops */
 /* x_cat bf16 [B*N, 2*D] = (x, cond * ~cond_mask)   (voicebox_pytorch.py:1035,1075-1076) */
@@ -505,7 +513,9 @@ int vbx_pack_weight3(const float* src, int src_rows, int src_cols, void* dst_f16
  * optional fp16 / bf16 copies and 1/max(|.|,1e-12) rows the backward reads (any of q16 .. k_rnorm may be NULL) */
 int vbx_qknorm_rope_f32(const float* raw, int B, int H, int Np, float qk_scale, const float* q_gamma, const float* k_gamma,
                         const float* rot_cos, const float* rot_sin, float* q32, float* k32, float* v32, void* q16, void* k16,
-                        void* qb, void* kb, void* v_bf16, void* v16, float* q_rnorm, float* k_rnorm, void* stream);
+                        void* qb, void* kb, void* v_bf16, void* v16, float* q_rnorm, float* k_rnorm,
+                        float q16_scale /* q16 = q * q16_scale: vbx_attn_q_prescale(scale), the attention kernels' contract */,
+                        void* stream);
 /* attend.py:121-135 in fp32: q, k, v fp32 [B,H,Np,64] -> out32 fp32 [B,Np,H*64] (+ optional fp16 / bf16 copies, log2-LSE [B,H,Np]) */
 int vbx_attn_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16, void* out_bf16,
                      float* lse, int B, int H, int Np, float scale, void* stream);

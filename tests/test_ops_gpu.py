@@ -204,7 +204,7 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     krn = torch.empty_like(qrn)
     gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_QKV, x, W, M, 3 * I, D, Np=Np, H=H, qk_scale=8.0 if qknorm else 0.0,
          q_gamma=qg, k_gamma=kg, rot_cos=rc.to(dev), rot_sin=rs.to(dev), q16=q16, k16=k16, qb=qb, kb=kb, v=v,
-         q_rnorm=qrn, k_rnorm=krn, f16=1, v16=v16)
+         q_rnorm=qrn, k_rnorm=krn, f16=1, v16=v16, q_prescale=L.lib().vbx_attn_q_prescale(10.0))
     qkv = (x.double().cpu() @ W.double().cpu().t()).view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
     q, k, vv = qkv[0], qkv[1], qkv[2]
     if qknorm:
@@ -212,7 +212,8 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
         q = restate.l2norm_scale(q, 64) * qg.double().cpu()[:, None, :]
         k = restate.l2norm_scale(k, 64) * kg.double().cpu()[:, None, :]
     q, k = restate.apply_rotary(fr.double(), q), restate.apply_rotary(fr.double(), k)
-    assert rel_err(q16, q) < 6e-4 and rel_err(k16, k) < 6e-4  # fp16 storage: 2^-11
+    # fp16 storage: 2^-11; q16 carries the attention kernels' scale * log2(e) (include/vbx.h), qb / k16 / kb do not
+    assert rel_err(q16, q * L.lib().vbx_attn_q_prescale(10.0)) < 6e-4 and rel_err(k16, k) < 6e-4
     assert rel_err(qb, q) < 4e-3 and rel_err(kb, k) < 4e-3
     assert rel_err(v, vv) < 4e-3 and rel_err(v16, vv) < 6e-4
 
@@ -319,6 +320,14 @@ def bwd_variant(request, L):
     L.lib().vbx_attn_bwd_select(0)
 
 
+def qpre(L, q16, scale):
+    """The kernels' q operand and the q the exact reference must see (include/vbx.h, attention contract since round 5): q16 carries
+    scale * log2(e), i.e. the kernel computes with fp16(q * c) -- the reference with that value divided by c in fp64."""
+    c = L.lib().vbx_attn_q_prescale(scale)
+    qs = (q16.float() * c).half()
+    return qs, qs.double() / c
+
+
 def attn_inputs(Bsz, H, Np, seed, qnorm=8.0):
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(Bsz, H, Np, 64, generator=g)
@@ -346,10 +355,11 @@ def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked, bwd_variant):
     out16 = torch.empty(Bsz, Np, H * 64, dtype=torch.float16, device=dev)
     out = torch.empty(Bsz, Np, H * 64, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(Bsz, H, Np, device=dev)
-    qd, kd, vd = q16.to(dev), k16.to(dev), v.to(dev)
+    qs, q_eff = qpre(L, q16, scale)
+    qd, kd, vd = qs.to(dev), k16.to(dev), v.to(dev)
     md = mask.to(dev) if masked else None
     L.call("vbx_attn_fwd", qd, kd, vd, md, out16, out, lse, Bsz, H, Np, scale, st())
-    qr, kr, vr = (t.double().requires_grad_(True) for t in (q16, k16, v))
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q_eff, k16, v))
     ref = restate.attend(qr, kr, vr, mask=mask, scale=scale)  # (b,h,n,d)
     ref_t = ref.permute(0, 2, 1, 3).reshape(Bsz, Np, H * 64)
     # P is rounded to fp16 before P.V (rel 2^-11 per weight); outputs stored in fp16 (+ bf16 copy)
@@ -473,10 +483,11 @@ def test_attn_dropout_fwd_bwd(L, Bsz, H, Np, scale, masked, p):
     out16 = torch.empty(Bsz, Np, H * 64, dtype=torch.float16, device=dev)
     out = torch.empty(Bsz, Np, H * 64, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(Bsz, H, Np, device=dev)
-    qd, kd, vd = q16.to(dev), k16.to(dev), v.to(dev)
+    qs, q_eff = qpre(L, q16, scale)
+    qd, kd, vd = qs.to(dev), k16.to(dev), v.to(dev)
     md = mask.to(dev) if masked else None
     L.call("vbx_attn_fwd_dropout", qd, kd, vd, md, out16, out, lse, Bsz, H, Np, scale, rm, p, st())
-    qr, kr, vr = (t.double().requires_grad_(True) for t in (q16, k16, v))
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q_eff, k16, v))
     ref = restate.attend(qr, kr, vr, mask=mask, scale=scale, drop=mult)
     ref_t = ref.permute(0, 2, 1, 3).reshape(Bsz, Np, H * 64)
     assert rel_err(out16, ref_t) < 1.5e-3, rel_err(out16, ref_t)
@@ -532,7 +543,7 @@ def test_qknorm_rope_bwd(L, qknorm):
     L.call("vbx_qknorm_rope_bwd", up[0].to(dev), up[1].to(dev), outs[0].detach().half().to(dev),
            outs[1].detach().half().to(dev), rn[0].to(dev), rn[1].to(dev), gam[0].detach().float().to(dev),
            gam[1].detach().float().to(dev), rc.to(dev), rs.to(dev), 8.0 if qknorm else 0.0, dqkv, 3 * H * 64, gpart,
-           Bsz, H, Np, st())
+           Bsz, H, Np, 1.0, st())  # q16 passed unscaled here: q16_scale = 1
     got = dqkv.float().cpu().view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
     for w in range(2):
         assert rel_err(got[w], t.grad[w]) < 5e-3, (w, rel_err(got[w], t.grad[w]))
@@ -554,7 +565,7 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked, bwd_varia
         y = restate.l2norm_scale(pre[w], 64) * gam[w][:, None, :] if qknorm else pre[w]
         hats.append(restate.apply_rotary(fr, y))
     rn = (1 / pre.norm(dim=-1)).float()
-    q16, k16 = hats[0].half().to(dev), hats[1].half().to(dev)
+    q16, k16 = qpre(L, hats[0].half(), scale)[0].to(dev), hats[1].half().to(dev)  # q16 in the kernels' exp2 domain
     v = torch.randn(Bsz, H, Np, 64, generator=g).half().to(dev)
     mask = None
     if masked:
@@ -565,7 +576,7 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked, bwd_varia
     lse = torch.empty(Bsz, H, Np, device=dev)
     L.call("vbx_attn_fwd", q16, k16, v, mask, out16, None, lse, Bsz, H, Np, scale, st())
     dout = bf(torch.randn(Bsz, Np, H * 64, generator=g) * 1e-3).to(dev)
-    qb, kb, vb = bf(q16.float()), bf(k16.float()), bf(v.float())
+    qb, kb, vb = bf(hats[0].half().float()).to(dev), bf(k16.float()), bf(v.float())
     I = H * 64
     # two-pass
     delta = torch.empty(Bsz, H, Np, device=dev)
@@ -577,7 +588,7 @@ def test_attn_bwd_fused_equals_two_pass(L, Bsz, H, Np, qknorm, masked, bwd_varia
     gp1 = torch.zeros(2, rows1, H, 64, device=dev)
     gq, gk = gam[0].float().to(dev), gam[1].float().to(dev)
     L.call("vbx_qknorm_rope_bwd", dq, dk, q16, k16, rn[0].to(dev), rn[1].to(dev), gq, gk, rc.to(dev), rs.to(dev),
-           8.0 if qknorm else 0.0, d1, 3 * I, gp1, Bsz, H, Np, st())
+           8.0 if qknorm else 0.0, d1, 3 * I, gp1, Bsz, H, Np, L.lib().vbx_attn_q_prescale(scale), st())
     # fused
     d2 = torch.zeros(Bsz * Np, 3 * I, dtype=torch.bfloat16, device=dev)
     rows2 = Bsz * L.lib().vbx_attn_bwd_fused_tiles(Np)
@@ -601,7 +612,8 @@ def _bwd_case(L, Bsz, H, Np, seed, masked=False):
     fr, rc, rs = rot_tables(Np, 16 if Np > 16 else 0)
     hats = [restate.apply_rotary(fr, restate.l2norm_scale(pre[w], 64) * gam[w][:, None, :]) for w in range(2)]
     rn = (1 / pre.norm(dim=-1)).float()
-    c = dict(Bsz=Bsz, H=H, Np=Np, q16=hats[0].half().to(dev), k16=hats[1].half().to(dev),
+    c = dict(Bsz=Bsz, H=H, Np=Np, q16=qpre(L, hats[0].half(), 10.0)[0].to(dev), qb=bf(hats[0].half().float()).to(dev),
+             k16=hats[1].half().to(dev),
              v=torch.randn(Bsz, H, Np, 64, generator=g).half().to(dev), rn=rn.to(dev), gam=gam.float().to(dev), rc=rc.to(dev),
              rs=rs.to(dev), mask=None)
     if masked:
@@ -625,7 +637,7 @@ def _bwd_fused(L, c, variant, scratch=None):
         gp = torch.zeros(2, Bsz * L.lib().vbx_attn_bwd_fused_tiles(Np), H, 64, device=dev)
         delta = torch.empty(Bsz, H, Np, device=dev)
         scratch = attn_scratch(L, Bsz, H, Np) if scratch is None else scratch
-        L.call("vbx_attn_bwd_fused", c["q16"], c["k16"], bf(c["q16"].float()), bf(c["k16"].float()), bf(c["v"].float()), c["mask"],
+        L.call("vbx_attn_bwd_fused", c["q16"], c["k16"], c["qb"], bf(c["k16"].float()), bf(c["v"].float()), c["mask"],
                c["out16"], 1, c["dout"], c["lse"], delta, c["rn"][0], c["rn"][1], c["gam"][0], c["gam"][1], c["rc"], c["rs"], 8.0, d,
                3 * I, gp, Bsz, H, Np, 10.0, scratch, st())
         torch.cuda.synchronize()

@@ -5,7 +5,7 @@ import torch
 from tools.gemm_bench import timeit, L, st, dev
 B, H = 8, 16
 for Np in (896, 1024, 1040, 1056, 1152):
-    q = torch.randn(B, H, Np, 64, device=dev); q = (q / q.norm(dim=-1, keepdim=True) * 8).half()
+    q = torch.randn(B, H, Np, 64, device=dev); q = (q / q.norm(dim=-1, keepdim=True) * 8 * L.lib().vbx_attn_q_prescale(10.0)).half()  # q16 contract: include/vbx.h
     k = torch.randn(B, H, Np, 64, device=dev); k = (k / k.norm(dim=-1, keepdim=True) * 8).half()
     v = torch.randn(B, H, Np, 64, device=dev).half()
     out = torch.empty(B, Np, H * 64, device=dev, dtype=torch.float16)

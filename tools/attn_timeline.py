@@ -13,7 +13,7 @@ B, H, Np = 8, 16, int(os.environ.get("NP", 1040))
 g = torch.Generator().manual_seed(0)
 q = torch.randn(B, H, Np, 64, generator=g); k = torch.randn(B, H, Np, 64, generator=g); v = torch.randn(B, H, Np, 64, generator=g)
 q = q / q.norm(dim=-1, keepdim=True) * 8; k = k / k.norm(dim=-1, keepdim=True) * 8
-qd, kd, vd = q.half().to(dev), k.half().to(dev), v.half().to(dev)
+qd, kd, vd = (q * L.lib().vbx_attn_q_prescale(10.0)).half().to(dev), k.half().to(dev), v.half().to(dev)  # q16 contract: include/vbx.h
 qb, kb, vb = q.bfloat16().to(dev), k.bfloat16().to(dev), v.bfloat16().to(dev)
 out16 = torch.empty(B, Np, H * 64, dtype=torch.float16, device=dev); out = torch.empty(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
 lse = torch.empty(B, H, Np, device=dev)

@@ -71,7 +71,7 @@ if __name__ == "__main__":
         gemm(L.VBX_GEMM_TN, L.VBX_EPI_SPLITK, 512, 1408, M, splits=16, name="TN (dW2)")
     if which in ("all", "attn"):
         B, H, Np = 8, 16, 1040
-        q = torch.randn(B, H, Np, 64, device=dev); q = (q / q.norm(dim=-1, keepdim=True) * 8).half()
+        q = torch.randn(B, H, Np, 64, device=dev); q = (q / q.norm(dim=-1, keepdim=True) * 8 * L.lib().vbx_attn_q_prescale(10.0)).half()  # q16 contract: include/vbx.h
         k = torch.randn(B, H, Np, 64, device=dev); k = (k / k.norm(dim=-1, keepdim=True) * 8).half()
         v = torch.randn(B, H, Np, 64, device=dev).half()
         out = torch.empty(B, Np, H * 64, device=dev, dtype=torch.float16)

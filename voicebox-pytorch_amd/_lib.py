@@ -22,6 +22,7 @@ class GemmDesc(C.Structure):
         ("A", P), ("B", P), ("C", P), ("bias", P), ("resid", P), ("C2", P), ("splits", I),
         ("Np", I), ("H", I), ("qk_scale", F), ("q_gamma", P), ("k_gamma", P), ("rot_cos", P), ("rot_sin", P),
         ("q16", P), ("k16", P), ("qb", P), ("kb", P), ("v", P), ("q_rnorm", P), ("k_rnorm", P), ("f16", I), ("v16", P), ("C3", P),
+        ("q_prescale", F),
     ]
 
 
@@ -48,7 +49,7 @@ _PROTOS = {
     "vbx_attn_fwd_dropout": [P, P, P, P, P, P, P, I, I, I, F, P, F, P],
     "vbx_attn_bwd_dropout": [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P, F, P],
     "vbx_attn_bwd_fused_tiles": [I],
-    "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, P],
+    "vbx_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, F, P, I, P, I, I, I, F, P],
     "vbx_qknorm_rope_bwd_gpart_rows": [I],
     "vbx_pack_embed_input": [P, P, P, P, P, I, I, I, P],
     "vbx_pack_embed_input_text": [P, P, P, P, P, P, I, P, I, L, P, P, I, I, I, P],
@@ -104,7 +105,7 @@ _PROTOS = {
     "vbx_clip_coef": [P, F, F, P, P],
     "vbx_split3_f16": [P, L, I, L, P, I, P],
     "vbx_pack_weight3": [P, I, I, P, I, I, I, I, P],
-    "vbx_qknorm_rope_f32": [P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "vbx_qknorm_rope_f32": [P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, P],
     "vbx_attn_fwd_f32": [P, P, P, P, P, P, P, P, I, I, I, F, P],
     "vbx_geglu_f32": [P, P, P, P, P, L, I, P],
     "vbx_adaln_proj_f32": [P, P, P, P, I, I, I, I, P],
@@ -148,12 +149,14 @@ def lib():
     l.vbx_attn_bwd_scratch_bytes.restype = C.c_size_t
     l.vbx_dropout_keep_scale.argtypes = [F]
     l.vbx_dropout_keep_scale.restype = F
+    l.vbx_attn_q_prescale.argtypes = [F]
+    l.vbx_attn_q_prescale.restype = F
     _lib = l
     return l
 
 
 def exported_symbols():
-    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes", "vbx_dropout_keep_scale"]  # + the stage-level entries bound in engine.py
+    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes", "vbx_dropout_keep_scale", "vbx_attn_q_prescale"]  # + the stage-level entries bound in engine.py
 
 
 def ptr(t):

@@ -160,6 +160,7 @@ struct QKBwd {
   u16* dqkv;            // bf16 [B*Np, ld]
   int ld, col0;         // column offset of this tensor's block inside a dqkv row (0 for q, H*64 for k)
   float* gpart;         // [B][tiles][H][64] partial gamma gradients of this tensor (qk-norm only)
+  float xh_inv;         // 1 / (the factor xh carries): 1 / (scale * log2 e) for the pre-scaled q16, 1 for k16
 };
 VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratch */, const f32x16 (&acc)[2], float scale,
                                const QKBwd& f, bool active, int b, int h, int H, int tile, int ntiles, int row0, int Np, int lane,
@@ -217,7 +218,7 @@ VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratc
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         dy[i] = g[i] * cp[i] + sgn * gp[i] * sp[i];
-        yv[i] = qh[i] * cp[i] + sgn * qp[i] * sp[i];
+        yv[i] = (qh[i] * cp[i] + sgn * qp[i] * sp[i]) * f.xh_inv;
       }
       if (f.qk_scale > 0.f) {
         const float rinv = f.rn[bh * Np + nc];
@@ -1617,6 +1618,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs 
 }
 
 #include "attn_bwd1.inc"
+#include "attn_bwd_fold.inc"
 
 }  // namespace
 
@@ -1630,6 +1632,9 @@ extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf 
 #endif
 
 static const float LOG2E = 1.4426950408889634f;
+// Round 5 contract (include/vbx.h): q16 arrives PRE-MULTIPLIED by scale * log2(e), so q . k is already the exponent of exp2 and the
+// kernels that still carry a `scale2` factor get 1; `scale` itself is only the multiplier of dq / dk.
+static const float QK_UNIT = 1.0f;
 
 extern "C" float vbx_dropout_keep_scale(float p);
 extern "C" int vbx_dropout_bits_words(int Np);
@@ -1644,7 +1649,7 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   if (drop_bits_rm) {  // training-time attention dropout (attend.py:131): the 4-per-CU body with the keep-bit selects
     VBX_REQUIRE(drop_p > 0.f && drop_p < 1.f, "vbx_attn_fwd_dropout: p must be in (0, 1)");
     hipLaunchKernelGGL(attn_fwd_kernel_v3_drop, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16,
-                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap,
+                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap,
                        (const unsigned*)drop_bits_rm, vbx_dropout_bits_words(Np), vbx_dropout_keep_scale(drop_p));
     VBX_LAUNCH_CHECK();
     return 0;
@@ -1655,18 +1660,18 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
   if (v3 && !legacy && !abl && !abl2) {
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap);
+                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);
     VBX_LAUNCH_CHECK();
     return 0;
   }
   if (legacy || abl)
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, abl, BH, xmap);
+                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, abl, BH, xmap);
   else
   {
 #define VBX_FWD2(A)                                                                                                   \
   hipLaunchKernelGGL(attn_fwd_kernel_v2<A>, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,     \
-                     (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, scale * LOG2E, BH, xmap)
+                     (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap)
     switch (abl2) {  // timing ablations are separate instantiations: the production kernel carries no switches
       case 0: VBX_FWD2(0); break;
       case 1: VBX_FWD2(1); break;
@@ -1683,6 +1688,7 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   VBX_LAUNCH_CHECK();
   return 0;
 }
+extern "C" float vbx_attn_q_prescale(float scale) { return scale * LOG2E; }
 extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
                             float* lse, int B, int H, int Np, float scale, void* stream) {
   return attn_fwd_impl(q16, k16, v, mask, out, out_bf16, lse, B, H, Np, scale, nullptr, 0.f, stream);
@@ -1749,6 +1755,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_fold), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     attr = true;
   }
   const long chunks = (long)B * Np * H * 8;
@@ -1767,7 +1774,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     g.dqacc = (float*)((char*)scratch + ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255));
         static unsigned launch_epoch = 0;
     g.epoch = (++launch_epoch) & 0xFFFFFFu;
-    g.dv_ld = dv_ld; g.H = H; g.Np = Np; g.BH = B * H; g.nx = attn_xcds(); g.scale2 = scale * LOG2E; g.scale = scale; g.fq = fq; g.fk = fk;
+    g.dv_ld = dv_ld; g.H = H; g.Np = Np; g.BH = B * H; g.nx = attn_xcds(); g.scale2 = QK_UNIT; g.scale = scale; g.fq = fq; g.fk = fk;
     // 512 persistent workgroups = two per CU: each pulls (head, key block) items from the queue of the XCD it runs on
     hipLaunchKernelGGL(attn_bwd1_kernel, dim3(512), dim3(256), B1_LDS, st, g);
     VBX_LAUNCH_CHECK();
@@ -1784,10 +1791,13 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   a.bits_rm = drop.rm; a.bits_cm = drop.cm; a.W2 = vbx_dropout_bits_words(Np); a.rkeep = dropout ? vbx_dropout_keep_scale(drop.p) : 1.f;
   a.q16 = (const u16*)q16; a.k16 = (const u16*)k16; a.qb16 = (const u16*)qb; a.kb16 = (const u16*)kb; a.vv = (const u16*)v;
   a.dout = (const u16*)dout; a.mask = mask; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = (u16*)dv; a.dv_ld = dv_ld;
-  a.H = H; a.Np = Np; a.BH = BH; a.xmap = xmap; a.grid_one = (int)grid.x; a.scale2 = scale * LOG2E; a.scale = scale; a.fq = fq; a.fk = fk;
+  a.H = H; a.Np = Np; a.BH = BH; a.xmap = xmap; a.grid_one = (int)grid.x; a.scale2 = QK_UNIT; a.scale = scale; a.fq = fq; a.fk = fk;
   if (bwd_dma == 4) {
     a.role = 0;
+    // VBX_ATTN_BWD_FOLD=0: A/B against round 3's bodies (statistics subtracted by VALU instead of folded into the MFMA accumulator)
+    static const bool fold = !(getenv("VBX_ATTN_BWD_FOLD") && atoi(getenv("VBX_ATTN_BWD_FOLD")) == 0);
     if (dropout) hipLaunchKernelGGL(attn_bwd_kernel_dma<true>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+    else if (fold) hipLaunchKernelGGL(attn_bwd_kernel_fold, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
     else hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
     VBX_LAUNCH_CHECK();
     return 0;
@@ -1797,7 +1807,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, grid, dim3(256), BWD_DMA_LDS, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
-                       (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, scale * LOG2E, scale, BH, xmap, fq);
+                       (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, QK_UNIT, scale, BH, xmap, fq);
   }
   VBX_LAUNCH_CHECK();
   if (bwd_dma & 2) {
@@ -1806,7 +1816,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
                        (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
-                       scale * LOG2E, scale, BH, xmap, fk);
+                       QK_UNIT, scale, BH, xmap, fk);
   }
   VBX_LAUNCH_CHECK();
   return 0;
@@ -1853,9 +1863,9 @@ extern "C" int vbx_attn_bwd_fused_dropout(const void* q16, const void* k16, cons
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && ld % 8 == 0 && ld >= 3 * H * 64, "vbx_attn_bwd_fused: bad dims");
   VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma && gpart), "vbx_attn_bwd_fused: qk-norm needs norms, gammas, gpart");
   const int I = H * 64, tiles = cdiv(Np, 128);
-  QKBwd fq{(const u16*)q16, q_rnorm, q_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, 0, gpart};
+  QKBwd fq{(const u16*)q16, q_rnorm, q_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, 0, gpart, 1.0f / (scale * LOG2E)};
   QKBwd fk{(const u16*)k16, k_rnorm, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, I,
-           gpart ? gpart + (size_t)B * tiles * H * 64 : nullptr};
+           gpart ? gpart + (size_t)B * tiles * H * 64 : nullptr, 1.0f};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, nullptr, nullptr, (u16*)dqkv + 2 * I, ld, B, H, Np,
                        scale, fq, fk, scratch, AttnDrop{(const unsigned*)bits_rm, (const unsigned*)bits_cm, p}, stream);
 }

@@ -935,6 +935,7 @@ struct EpiQKV {
   float qk_scale;
   const float* qg; const float* kg; const float* rc; const float* rs;
   u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn; u16* v16;
+  float qps;  // q16 = q-hat * qps (the attention kernels' contract: scale * log2 e, include/vbx.h); qb, k16, kb unscaled
   VBX_DEV void operator()(const float* Cs, int m0, int n0, int tid, int, int M, int N, int rows) const {
     const int I = H * 64;
     const int which = n0 / I;
@@ -1007,13 +1008,17 @@ struct EpiQKV {
       if (valid) {
         const long o = (((long)b * H + head) * Np + n) * 64 + d0;
         u16* dst = (which == 0 ? q16 : k16);
-        *reinterpret_cast<uint4*>(dst + o) = pack8_f16(olo);
-        *reinterpret_cast<uint4*>(dst + o + 32) = pack8_f16(ohi);
         u16* bcopy = (which == 0 ? qb : kb);
         if (bcopy) {
           *reinterpret_cast<uint4*>(bcopy + o) = pack8_bf16(olo);
           *reinterpret_cast<uint4*>(bcopy + o + 32) = pack8_bf16(ohi);
         }
+        if (which == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) { olo[i] *= qps; ohi[i] *= qps; }
+        }
+        *reinterpret_cast<uint4*>(dst + o) = pack8_f16(olo);
+        *reinterpret_cast<uint4*>(dst + o + 32) = pack8_f16(ohi);
         float* rn = (which == 0 ? qrn : krn);
         if (rn && j == 0) rn[((long)b * H + head) * Np + n] = rinv;
       }
@@ -1281,7 +1286,8 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
       VBX_REQUIRE(d->q16 && d->k16 && (d->v || d->v16) && d->rot_cos && d->rot_sin, "vbx_gemm QKV: null output/table");
       VBX_REQUIRE(d->qk_scale <= 0.f || (d->q_gamma && d->k_gamma), "vbx_gemm QKV: qk-norm needs gammas");
       EpiQKV e{d->Np, d->H, d->qk_scale, d->q_gamma, d->k_gamma, d->rot_cos, d->rot_sin,
-               (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm, (u16*)d->v16};
+               (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm, (u16*)d->v16,
+               d->q_prescale > 0.f ? d->q_prescale : 1.0f};
       if (d->f16) return launch<0, 0, true>(p, e, 1, st);
       return launch<0, 0>(p, e, 1, st);
     }

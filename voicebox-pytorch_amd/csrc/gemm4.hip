@@ -245,7 +245,8 @@ int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st) {
       if (!d->q16 || !d->k16 || !(d->v || d->v16) || !d->rot_cos || !d->rot_sin) return VBX_EUNSUPPORTED;
       if (d->qk_scale > 0.f && !(d->q_gamma && d->k_gamma)) return VBX_EUNSUPPORTED;
       Epi3QKV e{d->Np, d->H, d->qk_scale, d->q_gamma, d->k_gamma, d->rot_cos, d->rot_sin,
-                (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm, (u16*)d->v16};
+                (u16*)d->q16, (u16*)d->k16, (u16*)d->qb, (u16*)d->kb, (u16*)d->v, d->q_rnorm, d->k_rnorm, (u16*)d->v16,
+                d->q_prescale > 0.f ? d->q_prescale : 1.0f};
       if (d->f16) return launch4<0, 0, true>(p, e, st);
       return launch4<0, 0>(p, e, st);
     }

@@ -227,6 +227,7 @@ struct Epi3QKV {
   float qk_scale;
   const float* qg; const float* kg; const float* rc; const float* rs;
   u16* q16; u16* k16; u16* qb; u16* kb; u16* v; float* qrn; float* krn; u16* v16;
+  float qps;  // q16 = q-hat * qps (the attention kernels' contract, include/vbx.h); qb, k16, kb unscaled
   // (batch, token) of global row gr, given those of the pass's first row (a pass is 32 consecutive rows)
   VBX_DEV void split_row(int gr, int rbase, int b0, int n0, int& b, int& n) const {
     if (Np >= 32) {
@@ -304,8 +305,9 @@ struct Epi3QKV {
           }
 #pragma unroll
           for (int jj = 0; jj < 4; jj++) {
-            RowStage<8>::put(b16, il, hh * 4 + jj, lane, as_u32x2(pack4_f16(o4[jj])));
             if (dstb) RowStage<8>::put(bbf, il, hh * 4 + jj, lane, as_u32x2(pack4_bf16(o4[jj])));
+            if (which == 0) o4[jj] *= qps;
+            RowStage<8>::put(b16, il, hh * 4 + jj, lane, as_u32x2(pack4_f16(o4[jj])));
           }
           float* rn = (which == 0 ? qrn : krn);
           if (valid && rn && g == 0) rn[((long)b * H + head) * Np + n] = rinv;

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __res
                                                               const float* __restrict__ qg, const float* __restrict__ kg,
                                                               const float* __restrict__ rc, const float* __restrict__ rs,
                                                               float qk_scale, u16* __restrict__ dqkv, int ld,
-                                                              float* __restrict__ gpart, int B, int H, int Np) {
+                                                              float* __restrict__ gpart, int B, int H, int Np, float q16_inv) {
   __shared__ float red[32][64];
   const int h = blockIdx.x, b = blockIdx.y;
   const int which = blockIdx.z / NSPLIT, split = blockIdx.z % NSPLIT;
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __res
   const u16* hsrc = which == 0 ? q16 : k16;
   const float* rn = which == 0 ? qrn : krn;
   const float* gam = (which == 0 ? qg : kg);
+  const float xh_inv = which == 0 ? q16_inv : 1.0f;  // q16 carries scale * log2(e) (include/vbx.h, attention section)
   const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;  // 32 row slots
   const int d0 = sub * 8;
   const bool lowhalf = d0 < 32;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const float* __res
       const float gp = __shfl_xor(g[i], 4, 64);
       const float qp = __shfl_xor(qh[i], 4, 64);
       dy[i] = g[i] * cp[i] + sgn * gp * sp[i];
-      yv[i] = qh[i] * cp[i] + sgn * qp * sp[i];
+      yv[i] = (qh[i] * cp[i] + sgn * qp * sp[i]) * xh_inv;
     }
     float out[8];
     if (qk_scale > 0.f) {
@@ -437,14 +438,14 @@ extern "C" int vbx_qknorm_rope_bwd_gpart_rows(int B) { return B * NSPLIT; }
 extern "C" int vbx_qknorm_rope_bwd(const float* dq, const float* dk, const void* q16, const void* k16, const float* q_rnorm,
                                    const float* k_rnorm, const float* q_gamma, const float* k_gamma, const float* rot_cos,
                                    const float* rot_sin, float qk_scale, void* dqkv, int ld, float* gpart, int B, int H,
-                                   int Np, void* stream) {
+                                   int Np, float q16_scale, void* stream) {
   VBX_REQUIRE(dq && dk && q16 && k16 && rot_cos && rot_sin && dqkv && gpart, "vbx_qknorm_rope_bwd: null pointer");
   VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma), "vbx_qknorm_rope_bwd: qk-norm needs stats");
-  VBX_REQUIRE(ld % 8 == 0, "vbx_qknorm_rope_bwd: ld must be a multiple of 8");
+  VBX_REQUIRE(ld % 8 == 0 && q16_scale > 0.f, "vbx_qknorm_rope_bwd: ld must be a multiple of 8, q16_scale > 0");
   dim3 grid(H, B, 2 * NSPLIT);
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dq, dk, (const u16*)q16,
                      (const u16*)k16, q_rnorm, k_rnorm, q_gamma, k_gamma, rot_cos, rot_sin, qk_scale, (u16*)dqkv, ld, gpart,
-                     B, H, Np);
+                     B, H, Np, 1.0f / q16_scale);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_f32_kernel(const float* __res
                                                               float* __restrict__ q32, float* __restrict__ k32, float* __restrict__ v32,
                                                               u16* __restrict__ q16, u16* __restrict__ k16, u16* __restrict__ qb,
                                                               u16* __restrict__ kb, u16* __restrict__ vb, u16* __restrict__ v16,
-                                                              float* __restrict__ qrn, float* __restrict__ krn) {
+                                                              float* __restrict__ qrn, float* __restrict__ krn, float q16_scale) {
   const int lane = threadIdx.x & 63;
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= M * H) return;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_f32_kernel(const float* __res
     const float out = lane < 32 ? t * c - p * s : t * c + p * s;
     (which == 0 ? q32 : k32)[o] = out;
     u16* d16 = which == 0 ? q16 : k16;
-    if (d16) d16[o] = f32_to_f16(out);
+    if (d16) d16[o] = f32_to_f16(which == 0 ? out * q16_scale : out);  // q16 carries scale * log2 e (include/vbx.h, attention)
     u16* db = which == 0 ? qb : kb;
     if (db) db[o] = f32_to_bf16(out);
     float* rn = which == 0 ? qrn : krn;
@@ -296,12 +296,14 @@ extern "C" int vbx_pack_weight3(const float* src, int src_rows, int src_cols, vo
 }
 extern "C" int vbx_qknorm_rope_f32(const float* raw, int B, int H, int Np, float qk_scale, const float* q_gamma, const float* k_gamma,
                                    const float* rot_cos, const float* rot_sin, float* q32, float* k32, float* v32, void* q16, void* k16,
-                                   void* qb, void* kb, void* v_bf16, void* v16, float* q_rnorm, float* k_rnorm, void* stream) {
+                                   void* qb, void* kb, void* v_bf16, void* v16, float* q_rnorm, float* k_rnorm, float q16_scale,
+                                   void* stream) {
   VBX_REQUIRE(raw && rot_cos && rot_sin && q32 && k32 && v32 && B > 0 && H > 0 && Np > 0, "vbx_qknorm_rope_f32: bad args");
   VBX_REQUIRE(qk_scale <= 0.f || (q_gamma && k_gamma), "vbx_qknorm_rope_f32: qk-norm needs gammas");
   const long M = (long)B * Np;
   hipLaunchKernelGGL(qknorm_rope_f32_kernel, dim3(cdiv(M * H, 4)), dim3(256), 0, ST, raw, Np, H, M, qk_scale, q_gamma, k_gamma, rot_cos,
-                     rot_sin, q32, k32, v32, (u16*)q16, (u16*)k16, (u16*)qb, (u16*)kb, (u16*)v_bf16, (u16*)v16, q_rnorm, k_rnorm);
+                     rot_sin, q32, k32, v32, (u16*)q16, (u16*)k16, (u16*)qb, (u16*)kb, (u16*)v_bf16, (u16*)v16, q_rnorm, k_rnorm,
+                     q16_scale > 0.f ? q16_scale : 1.0f);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -483,7 +485,7 @@ int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseAc
     PCK(gemm3(s.h32, d.M, d.D, d.D, w.layer[l].qkv, 3 * d.I, s.raw, 3 * d.I, nullptr, nullptr));
     PCK(vbx_qknorm_rope_f32(s.raw, d.B, d.H, d.Np, m->qk_norm ? 8.0f : 0.0f, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                             m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, s.q32, s.k32, s.v32, y.q16, y.k16, y.qb, y.kb,
-                            y.v, y.vh, y.qrn, y.krn, stream));
+                            y.v, y.vh, y.qrn, y.krn, vbx_attn_q_prescale(m->attn_scale), stream));
     PCK(vbx_attn_fwd_f32(s.q32, s.k32, s.v32, io->attn_mask_p, s.o32, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
     PCK(gemm3(s.o32, d.M, d.I, d.I, w.layer[l].out, d.D, x_mid, d.D, nullptr, x_in));
     PCK(vbx_rmsnorm_fwd_multi(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, nullptr, s.h32, d.B, d.Np, 0, d.Np, d.D, stream));

@@ -665,6 +665,7 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     g.k_gamma = m->qk_norm ? P + o[VBX_L_KG] : nullptr;
     g.rot_cos = m->rot_cos; g.rot_sin = m->rot_sin;
     g.q16 = y.q16; g.k16 = y.k16; g.qb = y.qb; g.kb = y.kb; g.v = y.v; g.v16 = y.vh; g.q_rnorm = y.qrn; g.k_rnorm = y.krn;
+    g.q_prescale = vbx_attn_q_prescale(m->attn_scale);  // q16 in the exp2 domain: the attention kernels' contract (include/vbx.h)
     { ProfScope ps("fwd to_qkv", st); CK(vbx_gemm(&g, stream)); }
     const bool drop_on = io->dropout != 0;
     if (y.dbr && drop_on) {  // attend.py:131: keep bits of this layer, kept in the arena for the backward
@@ -820,7 +821,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
                       a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                            m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
-                           3 * d.I, a.gpart, d.B, d.H, d.Np, stream));
+                           3 * d.I, a.gpart, d.B, d.H, d.Np, vbx_attn_q_prescale(m->attn_scale), stream));
     if (m->qk_norm) {
       const int rows = vbx_qknorm_rope_bwd_gpart_rows(d.B);
       CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));

@@ -42,7 +42,10 @@ class _AttendFn(torch.autograd.Function):
     def forward(ctx, q, k, v, mask, scale, drop_p=0., drop_seed=0):
         B, H, Np, dh = q.shape
         dev = q.device
-        q16, k16 = q.to(torch.float16).contiguous(), k.to(torch.float16).contiguous()
+        # kernel contract (include/vbx.h): q16 carries scale * log2(e), so q16 . k16 is the exponent of exp2; qb stays unscaled
+        q16 = (q.float() * _lib.lib().vbx_attn_q_prescale(float(scale))).to(torch.float16).contiguous()
+        k16 = k.to(torch.float16).contiguous()
+        qb = q.to(torch.float16).to(torch.bfloat16).contiguous()
         v16 = v.to(torch.float16).contiguous()
         vb = v.to(torch.bfloat16).contiguous()
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
@@ -56,17 +59,17 @@ class _AttendFn(torch.autograd.Function):
                       _lib.current_stream())
         else:
             _lib.call("vbx_attn_fwd", q16, k16, v16, m8, out16, None, lse, B, H, Np, float(scale), _lib.current_stream())
-        ctx.save_for_backward(q16, k16, vb, out16, lse, m8 if m8 is not None else none, rm, cm)
+        ctx.save_for_backward(q16, k16, vb, out16, lse, m8 if m8 is not None else none, rm, cm, qb)
         ctx.has_mask, ctx.scale, ctx.in_dtype, ctx.drop_p = m8 is not None, float(scale), q.dtype, float(drop_p)
         return out16.view(B, Np, H, 64).permute(0, 2, 1, 3).to(q.dtype)
 
     @staticmethod
     def backward(ctx, dout):
-        q16, k16, vb, out, lse, m8, rm, cm = ctx.saved_tensors
+        q16, k16, vb, out, lse, m8, rm, cm, qb = ctx.saved_tensors
         B, H, Np, _ = q16.shape
         dev = q16.device
         do = dout.permute(0, 2, 1, 3).reshape(B, Np, H * 64).to(torch.bfloat16).contiguous()
-        qb, kb = q16.to(torch.bfloat16), k16.to(torch.bfloat16)
+        kb = k16.to(torch.bfloat16)
         delta = torch.empty(B, H, Np, dtype=torch.float32, device=dev)
         dq = torch.empty(B, H, Np, 64, dtype=torch.float32, device=dev)
         dk = torch.empty_like(dq)
