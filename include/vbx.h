@@ -143,7 +143,10 @@ int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, c
  * on MI355X so far, kept selectable.
  * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL (two-body only).
  * vbx_attn_bwd_select: 0 automatic (= two-body), 1 two-body, 2 one-pass (error without scratch; under stream capture the two-body
- * kernel runs, because the chain's flags carry a per-launch epoch passed by value). */
+ * kernel runs, because the chain's flags carry a per-launch epoch passed by value), 3 two-body WITHOUT round 5's fold of the softmax
+ * statistics into the MFMA accumulator (csrc/attn_bwd_fold.inc; round 3's bodies: results bit-identical to the one-pass kernel's,
+ * ~25 % slower; also VBX_ATTN_BWD_FOLD=0).  The folded bodies evaluate P = exp2(-(L - q.k)) with L added inside the matrix pipe;
+ * they differ from 3 by fp32 rounding of the exponent only. */
 size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
 int vbx_attn_bwd_select(int variant);
 int vbx_attn_bwd_variant(void); /* 1 two-body, 2 one-pass: which kernel the current selection runs (callers size `scratch` by it) */

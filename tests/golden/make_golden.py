@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact,attend_mask4d,transformer_unet}.pt
+Outputs (committed): tests/golden/{masks,rotary,small,small_gateloop,small_text,transformer,duration,cfg1,cfg4,small_wc,cfg4_wc,cfg5_wc,cfg4_wc_train,cfg4_seeds,cfg3,cfg5_wc_b8,small_dropout,small_dimin,cfg4_seeds_exact,attend_mask4d,transformer_unet,init_stats}.pt
 
 RNG protocol: the reference draws, from the global CPU generator,
 randn_like(x1) -> rand(B) -> uniform_(0.7,1)(B) -> uniform_(0,1)(B) per training
@@ -729,13 +729,40 @@ def gen_cfg5_wc_b8(ref):
     print("cfg5_wc_b8: sample norms", s65.flatten(1).norm(dim=1).tolist())
 
 
+def gen_init_stats(ref):
+    """Round 5: the reference-initialisation parity statement as a STATISTIC over many seeds instead of bounds fitted
+    to six realisations.  Forward only.  config 4 architecture (dim 512, depth 12, heads 16, N = 1024): 16 seeds at B = 2 (weights seed
+    s, data seed 100 + s, draws seed 200 + s for s = 20..35) ; config 3 (dim 1024): 6 seeds at B = 2 (s = 40..45).  Per seed: the
+    unmodified reference's fp32 loss, the exact (fp64 restatement) loss and the fp32 restatement's loss (= what another correct fp32
+    implementation gets), plus the draws.  tests/test_model_gpu.py asserts mean |difference| and RMS over the seeds."""
+    out = {}
+    for tag, cfg, seeds in (("cfg4", restate.Cfg(dim=512, depth=12, heads=16, dim_head=64), range(20, 36)),
+                            ("cfg3", restate.Cfg(dim=1024, depth=12, heads=16, dim_head=64), range(40, 46))):
+        for s in seeds:
+            state = restate.init_state_dict(cfg, seed=s)
+            vb, wrapper = build_reference(ref, cfg, state=state)
+            x1 = torch.randn(2, 1024, cfg.dim, generator=torch.Generator().manual_seed(100 + s))
+            x0, times, frac, rand = replay_draws(x1, seed=200 + s)
+            torch.manual_seed(200 + s)
+            with torch.no_grad():
+                gold = float(wrapper(x1))
+                l32 = float(restate.cfm_loss(state, cfg, x1, x0, times, frac, rand))
+                p64 = {k: v.double() for k, v in state.items()}
+                l64 = float(restate.cfm_loss(p64, cfg, x1.double(), x0.double(), times.double(), frac, rand))
+            out[(tag, s)] = dict(loss=gold, exact=l64, fp32_restatement=l32, x0_check=x0[0, 0, :4].clone(), times=times, frac=frac, rand=rand)
+            print(f"init_stats {tag} seed {s}: reference {gold:.7f}  exact {l64:.7f} ({l64 - gold:+.2e})  fp32 restatement {l32:.7f} ({l32 - gold:+.2e})", flush=True)
+            del vb, wrapper, state, p64
+    torch.save(out, os.path.join(HERE, "init_stats.pt"))
+
+
 if __name__ == "__main__":
     ref = ref_loader.load_reference()
     which = sys.argv[1:] or ["masks", "rotary", "small", "small_gateloop", "small_text", "transformer", "duration", "cfg1", "cfg4",
-                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact", "attend_mask4d", "transformer_unet"]
+                             "small_wc", "cfg4_wc", "cfg5_wc", "cfg4_wc_train", "cfg4_seeds", "cfg3", "cfg5_wc_b8", "small_dropout", "small_dimin", "cfg4_seeds_exact", "attend_mask4d", "transformer_unet", "init_stats"]
     for w in which:
         {"masks": gen_masks, "rotary": gen_rotary, "small": gen_small, "small_gateloop": gen_small_gateloop, "small_text": gen_small_text,
          "transformer": gen_transformer, "duration": gen_duration, "cfg1": gen_cfg1, "cfg4": gen_cfg4, "small_wc": gen_small_wc, "cfg4_wc": gen_cfg4_wc,
          "cfg5_wc": gen_cfg5_wc, "cfg4_wc_train": gen_cfg4_wc_train, "cfg4_seeds": gen_cfg4_seeds, "cfg3": gen_cfg3,
          "cfg5_wc_b8": gen_cfg5_wc_b8, "small_dropout": gen_small_dropout, "small_dimin": gen_small_dimin,
-         "cfg4_seeds_exact": gen_cfg4_seeds_exact, "attend_mask4d": gen_attend_mask4d, "transformer_unet": gen_transformer_unet}[w](ref)
+         "cfg4_seeds_exact": gen_cfg4_seeds_exact, "attend_mask4d": gen_attend_mask4d, "transformer_unet": gen_transformer_unet,
+         "init_stats": gen_init_stats}[w](ref)

@@ -664,7 +664,7 @@ def test_attn_bwd_onepass_equals_two_body(L, Bsz, H, Np, masked):
     items on 512 persistent workgroups).  dv / dk come out of the same arithmetic in the same order: bit-identical.  dq sums the same
     bf16-rounded dS blocks in a different association: equal up to the bf16 rounding of the output."""
     c = _bwd_case(L, Bsz, H, Np, seed=Np + Bsz, masked=masked)
-    d1, g1, _ = _bwd_fused(L, c, 1)
+    d1, g1, _ = _bwd_fused(L, c, 3)  # 3 = the two-body kernel WITHOUT round 5's fold (same exponent arithmetic as the one-pass kernel)
     d2, g2, scratch = _bwd_fused(L, c, 2)
     I = H * 64
     _chain_bookkeeping_ok(scratch, Bsz, H, Np)
@@ -676,6 +676,26 @@ def test_attn_bwd_onepass_equals_two_body(L, Bsz, H, Np, masked):
     assert rel_err(g2[0].sum(0), g1[0].sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("Bsz,H,Np,masked", [(8, 16, 1040, False), (2, 4, 1040, True), (3, 5, 520, False), (1, 2, 130, True), (1, 2, 24, False)])
+def test_attn_bwd_folded_statistics_equal_the_unfolded_bodies(L, Bsz, H, Np, masked):
+    """Round 5's default backward (csrc/attn_bwd_fold.inc: L and delta enter as the C operand of the S / dP MFMA chains, negated
+    stationary fragments, P = exp2(-(L - q.k))) against round 3's bodies (select 3: P = exp2(fma(s, 1, -L)), dP - delta by VALU) on the
+    same inputs, incl. the benchmark grid.  The two differ only in where the fp32 rounding of the exponent / of dP - delta happens, then
+    share the bf16 rounding of P and dS: every output within bf16 noise of the other, gamma partials likewise, and the folded kernel is
+    deterministic."""
+    c = _bwd_case(L, Bsz, H, Np, seed=7 * Np + Bsz, masked=masked)
+    d3, g3, _ = _bwd_fused(L, c, 3)
+    d1, g1, _ = _bwd_fused(L, c, 1)
+    d1b, g1b, _ = _bwd_fused(L, c, 1)
+    assert torch.equal(d1, d1b) and torch.equal(g1, g1b)
+    I = H * 64
+    assert torch.isfinite(d1.float()).all()
+    for blk, name in ((0, "dq"), (1, "dk"), (2, "dv")):
+        e = rel_err(d1[:, blk * I:(blk + 1) * I].float(), d3[:, blk * I:(blk + 1) * I].float())
+        assert e < 6e-3, (name, e)
+    assert rel_err(g1.sum(1), g3.sum(1)) < 2e-3
+
+
 @pytest.mark.parametrize("Np", [130, 200])
 def test_attn_bwd_onepass_early_consumer_over_repeated_launches(L, Np):
     """Regression for a hand-off race found on hardware (round 3): with two key blocks per head the chain's last member has 2 / 72 keys
@@ -684,7 +704,7 @@ def test_attn_bwd_onepass_early_consumer_over_repeated_launches(L, Np):
     that was not there yet (22 of 32 launches wrong).  Flags now carry a per-launch epoch.  32 launches on one re-poisoned scratch
     buffer: every result must be finite, equal to the two-body kernel's, and identical from launch to launch."""
     c = _bwd_case(L, 1, 2, Np, seed=Np)
-    d1, g1, _ = _bwd_fused(L, c, 1)
+    d1, g1, _ = _bwd_fused(L, c, 3)  # the unfolded two-body kernel: bit-identical dk / dv
     I = 2 * 64
     scratch = attn_scratch(L, 1, 2, Np)
     first = None

@@ -1705,7 +1705,7 @@ extern "C" int vbx_attn_fwd_dropout(const void* q16, const void* k16, const void
 // VBX_ATTN_BWD_ONEPASS=1 presets 2 (A/B); vbx_attn_bwd_select() switches at run time (tests, tools).
 static int g_attn_bwd_variant = (getenv("VBX_ATTN_BWD_ONEPASS") && atoi(getenv("VBX_ATTN_BWD_ONEPASS")) != 0) ? 2 : 0;
 extern "C" int vbx_attn_bwd_select(int variant) {
-  VBX_REQUIRE(variant >= 0 && variant <= 2, "vbx_attn_bwd_select: 0 auto, 1 two-body, 2 one-pass");
+  VBX_REQUIRE(variant >= 0 && variant <= 3, "vbx_attn_bwd_select: 0 auto, 1 two-body, 2 one-pass, 3 two-body without the MFMA fold");
   g_attn_bwd_variant = variant;
   return 0;
 }
@@ -1795,7 +1795,8 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   if (bwd_dma == 4) {
     a.role = 0;
     // VBX_ATTN_BWD_FOLD=0: A/B against round 3's bodies (statistics subtracted by VALU instead of folded into the MFMA accumulator)
-    static const bool fold = !(getenv("VBX_ATTN_BWD_FOLD") && atoi(getenv("VBX_ATTN_BWD_FOLD")) == 0);
+    static const bool fold_env = !(getenv("VBX_ATTN_BWD_FOLD") && atoi(getenv("VBX_ATTN_BWD_FOLD")) == 0);
+    const bool fold = fold_env && g_attn_bwd_variant != 3;  // vbx_attn_bwd_select(3): round 3's bodies (bit-identical to the one-pass kernel)
     if (dropout) hipLaunchKernelGGL(attn_bwd_kernel_dma<true>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
     else if (fold) hipLaunchKernelGGL(attn_bwd_kernel_fold, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
     else hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
