@@ -83,6 +83,12 @@ typedef struct {
   void* C3;                 /* EPI_GEGLU: optional bf16 copy of C [M,ldc] (wgrad operand) */
   float q_prescale;         /* EPI_QKV: q16 is written as q-hat * q_prescale (vbx_attn_q_prescale(scale): the attention kernels'
                              * contract); <= 0 means 1.  qb / k16 / kb are never scaled. */
+  /* EPI_BF16, NN mode, optional (round 5): this GEMM is the dgrad of Attention.to_out (C = dO bf16 [B*Np, H*64]) and the attention
+   * backward's delta[b,h,n] = sum_d dO[b,n,h*64+d] * O[b,n,h*64+d] is written as a by-product (then pass out = NULL to vbx_attn_bwd*).
+   * delta_o: the forward output O, fp16, same [M, ldc] layout as C; needs Np, H with N = H*64.  VBX_EUNSUPPORTED when the tile that
+   * would serve this shape has no such epilogue (call again without, and let vbx_attn_bwd* run its own pass). */
+  const void* delta_o;
+  float* delta;
 } vbx_gemm_desc;
 
 int vbx_gemm(const vbx_gemm_desc* d, void* stream);
@@ -151,7 +157,8 @@ size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
 int vbx_attn_bwd_select(int variant);
 int vbx_attn_bwd_variant(void); /* 1 two-body, 2 one-pass: which kernel the current selection runs (callers size `scratch` by it) */
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
-                 const uint8_t* mask, const void* out /* forward output [B,Np,H*64] */, int out_is_f16,
+                 const uint8_t* mask, const void* out /* forward output [B,Np,H*64]; NULL: `delta` already holds rowsum(dO * O)
+                                                         (vbx_gemm_desc.delta) and the pass that computes it is skipped */, int out_is_f16,
                  const void* dout, const float* lse, float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H,
                  int Np, float scale, void* scratch, void* stream);
 /* backward of MultiheadRMSNorm + rotary (voicebox_pytorch.py:286-287,199): consumes dq/dk fp32

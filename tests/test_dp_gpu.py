@@ -225,6 +225,7 @@ def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
     opt = get_optimizer(w_r.parameters())
     vb, w = make()
     ts = TrainStep(w, lr=lr, max_grad_norm=0.5, wd=wd)
+    ref = dict(vb_r.named_parameters())
     for step in range(2):
         with rng_override(**draws):
             w_r(g["x1"].to(dev)).backward()
@@ -232,12 +233,17 @@ def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
         opt.step(); opt.zero_grad()
         with rng_override(**draws):
             ts.step(g["x1"].to(dev))
-    ref = dict(vb_r.named_parameters())
-    for k, p in vb.named_parameters():
-        if p.requires_grad:
-            upd, upd_r = p.detach() - g["state"][k].to(dev), ref[k].detach() - g["state"][k].to(dev)
-            e = float((upd - upd_r).norm() / upd_r.norm().clamp(min=1e-20))
-            assert e < 3e-2, (k, e)
+        # Step 1: both paths start from the same weights, run the same kernels and get the same gradients -- the updates may differ by
+        # the fp32 operation order of the two Adam implementations only.  Step 2 starts from weights that differ in their last bits, and
+        # at this (reference-init, near-one-hot softmax) point the gradient of a tensor below both attentions is a chaotic function of
+        # them: the update of transformer.register_tokens differed by 3.0 - 4.3 % over three builds of the kernels (rounds 4 / 5) -- a
+        # noise figure, so the second step is held to 10 % and the exactness claim rests on the first.
+        tol = 2e-4 if step == 0 else 1e-1
+        for k, p in vb.named_parameters():
+            if p.requires_grad:
+                upd, upd_r = p.detach() - g["state"][k].to(dev), ref[k].detach() - g["state"][k].to(dev)
+                e = float((upd - upd_r).norm() / upd_r.norm().clamp(min=1e-20))
+                assert e < tol, (step, k, e)
     # the decay really acted: a 2-D weight moved differently from an undecayed run
     vb0, w0 = make()
     ts0 = TrainStep(w0, lr=lr, max_grad_norm=0.5)

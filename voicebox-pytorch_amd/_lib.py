@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("A", P), ("B", P), ("C", P), ("bias", P), ("resid", P), ("C2", P), ("splits", I),
         ("Np", I), ("H", I), ("qk_scale", F), ("q_gamma", P), ("k_gamma", P), ("rot_cos", P), ("rot_sin", P),
         ("q16", P), ("k16", P), ("qb", P), ("kb", P), ("v", P), ("q_rnorm", P), ("k_rnorm", P), ("f16", I), ("v16", P), ("C3", P),
-        ("q_prescale", F),
+        ("q_prescale", F), ("delta_o", P), ("delta", P),
     ]
 
 

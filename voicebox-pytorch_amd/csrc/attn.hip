@@ -1742,6 +1742,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   VBX_REQUIRE(!dropout || (drop.cm && drop.p > 0.f && drop.p < 1.f), "vbx_attn_bwd_dropout: needs both keep-bit arrays and p in (0, 1)");
   bool onepass = scratch && g_attn_bwd_variant == 2 && !dropout;  // dropout runs on the two-body kernel
   VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch || dropout, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
+  if (!out) onepass = false;  // the delta pass also resets the one-pass kernel's queue heads: without it the two-body kernel runs
   if (onepass) {  // its flags carry a per-launch epoch passed by value: a captured launch would replay a stale one
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) onepass = false;
@@ -1759,7 +1760,9 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     attr = true;
   }
   const long chunks = (long)B * Np * H * 8;
-  if (out_is_f16)
+  if (!out) {
+    // delta was written by the to_out dgrad's epilogue (vbx_gemm_desc.delta): no pass of its own
+  } else if (out_is_f16)
     hipLaunchKernelGGL(attn_delta_kernel<true>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
                        delta, H, Np, chunks, sync, nsync);
   else
@@ -1827,7 +1830,7 @@ extern "C" int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, co
                             const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
                             float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
                             void* scratch, void* stream) {
-  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && dout && lse && delta && dq && dk && dv, "vbx_attn_bwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd: bad dims (dv_ld must be a multiple of 8)");
   const QKBwd none{};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
@@ -1837,7 +1840,7 @@ extern "C" int vbx_attn_bwd_dropout(const void* q16, const void* k16, const void
                                     const uint8_t* mask, const void* out, int out_is_f16, const void* dout, const float* lse,
                                     float* delta, float* dq, float* dk, void* dv, int dv_ld, int B, int H, int Np, float scale,
                                     const void* bits_rm, const void* bits_cm, float p, void* stream) {
-  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dq && dk && dv && bits_rm && bits_cm, "vbx_attn_bwd_dropout: null pointer");
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && dout && lse && delta && dq && dk && dv && bits_rm && bits_cm, "vbx_attn_bwd_dropout: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && dv_ld % 8 == 0, "vbx_attn_bwd_dropout: bad dims (dv_ld must be a multiple of 8)");
   const QKBwd none{};
   return attn_bwd_impl(q16, k16, qb, kb, v, mask, out, out_is_f16, dout, lse, delta, dq, dk, dv, dv_ld, B, H, Np, scale, none, none,
@@ -1860,7 +1863,7 @@ extern "C" int vbx_attn_bwd_fused_dropout(const void* q16, const void* k16, cons
                                           const float* k_gamma, const float* rot_cos, const float* rot_sin, float qk_scale,
                                           void* dqkv, int ld, float* gpart, int B, int H, int Np, float scale, void* scratch,
                                           const void* bits_rm, const void* bits_cm, float p, void* stream) {
-  VBX_REQUIRE(q16 && k16 && qb && kb && v && out && dout && lse && delta && dqkv && rot_cos && rot_sin, "vbx_attn_bwd_fused: null pointer");
+  VBX_REQUIRE(q16 && k16 && qb && kb && v && dout && lse && delta && dqkv && rot_cos && rot_sin, "vbx_attn_bwd_fused: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f && ld % 8 == 0 && ld >= 3 * H * 64, "vbx_attn_bwd_fused: bad dims");
   VBX_REQUIRE(qk_scale <= 0.f || (q_rnorm && k_rnorm && q_gamma && k_gamma && gpart), "vbx_attn_bwd_fused: qk-norm needs norms, gammas, gpart");
   const int I = H * 64, tiles = cdiv(Np, 128);

@@ -1248,6 +1248,10 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "vbx_gemm: leading dims must be multiples of 8 (16-byte rows)");
   VBX_REQUIRE(d->N % 8 == 0, "vbx_gemm: N must be a multiple of 8");
   const int tile = gemm_tile_for(d);
+  if (d->delta) {  // only the 128 x 256 tile's row-staged epilogue produces the attention delta (gemm_epi3.hpp): serve it there or say no
+    if (tile != 4) return VBX_EUNSUPPORTED;
+    return vbx_gemm4(d, st);
+  }
   if (tile == 3 || tile == 4) {
     const int rc = tile == 3 ? vbx_gemm3(d, st) : vbx_gemm4(d, st);
     if (rc != VBX_EUNSUPPORTED) return rc;

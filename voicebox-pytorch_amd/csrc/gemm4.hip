@@ -227,6 +227,12 @@ int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st) {
   switch (d->epilogue) {
     case VBX_EPI_BF16: {
       if (!d->C || d->ldc % 8) return VBX_EUNSUPPORTED;
+      if (d->delta) {  // dgrad of to_out with the attention backward's delta as a by-product (gemm_epi3.hpp::Epi3BF16Delta)
+        if (d->mode != VBX_GEMM_NN || d->bias || !d->delta_o || d->H <= 0 || d->Np <= 0 || d->N != d->H * 64 || d->M % d->Np)
+          return VBX_EUNSUPPORTED;
+        Epi3BF16Delta e{(u16*)d->C, d->ldc, (const u16*)d->delta_o, d->delta, d->H, d->Np};
+        return launch4<0, 1>(p, e, st);
+      }
       Epi3BF16 e{(u16*)d->C, d->ldc, d->bias};
       if (d->mode == VBX_GEMM_NT && !d->f16) return launch4<0, 0>(p, e, st);
       if (d->mode == VBX_GEMM_NN) return launch4<0, 1>(p, e, st);

@@ -117,6 +117,65 @@ struct Epi3BF16 {
   }
 };
 
+// The dgrad of Attention.to_out (dO = dX . W_out, bf16) with the attention backward's delta = rowsum_d(dO * O) per (token, head)
+// taken on the way out (round 5): the row stage hands every lane 8 consecutive bf16 dO values of one (row, head) -- the lane loads the
+// matching 16 bytes of the forward output O (fp16, the same [M, ldc] token-major layout), multiplies, and the 8 lanes of a head's 64
+// columns add up by three lane exchanges.  Replaces attn_delta_kernel's separate 34 MB pass (8.9 us per layer) with one 16-byte load
+// per store of this epilogue.  The products use the bf16-ROUNDED dO, as the stand-alone kernel (and the dP of the backward) do.
+struct Epi3BF16Delta {
+  u16* C; long ldc; const u16* O; float* delta; int H, Np;
+  VBX_DEV void operator()(const Acc& acc, int row0, int col0, int lane, int, int M, int N, int hstep, unsigned stage) const {
+    typedef RowStage<8> RS;
+#pragma unroll
+    for (int ih = 0; ih < 2; ih++) {
+      const unsigned buf = stage + ih * RS::BYTES;
+#pragma unroll
+      for (int il = 0; il < 2; il++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) RS::put(buf, il, j, lane, as_u32x2(pack4_bf16(acc[2 * ih + il][j])));
+      const int rbase = row0 + ih * hstep;
+      const int c = RS::chunk_of(lane);
+      const int gc = col0 + c * 8;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {  // two groups of ITS / 2 read-backs: bounds the live registers (4 x (dO + O) chunks)
+        constexpr int NI = RS::ITS / 2;
+        u32x4 v[NI];
+        uint4 ov[NI];
+#pragma unroll
+        for (int u = 0; u < NI; u++) v[u] = RS::get(buf, half * NI + u, lane);
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int gr = rbase + RS::row_of(half * NI + u, lane);
+          const bool ok = gr < M && gc < N;
+          ov[u] = ok ? *reinterpret_cast<const uint4*>(O + (long)gr * ldc + gc) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int gr = rbase + RS::row_of(half * NI + u, lane);
+          const bool ok = gr < M && gc < N;
+          if (ok) *reinterpret_cast<uint4*>(C + (long)gr * ldc + gc) = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+          const unsigned ow[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+          float sdot = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sdot += f16_to_f32((u16)(ow[e] & 0xffff)) * bf16_to_f32((u16)(v[u][e] & 0xffff));
+            sdot += f16_to_f32((u16)(ow[e] >> 16)) * bf16_to_f32((u16)(v[u][e] >> 16));
+          }
+          sdot += __shfl_xor(sdot, 1, 64);
+          sdot += __shfl_xor(sdot, 2, 64);
+          sdot += __shfl_xor(sdot, 4, 64);
+          if (ok && (c & 7) == 0) {
+            const int b = gr / Np, n = gr - b * Np;
+            delta[((long)b * H + (gc >> 6)) * Np + n] = sdot;
+          }
+        }
+      }
+    }
+  }
+};
+
 struct Epi3F32 {
   float* C; long ldc; const float* bias; const float* resid; u16* C2;
   VBX_DEV void operator()(const Acc& acc, int row0, int col0, int lane, int, int M, int N, int hstep, unsigned) const {

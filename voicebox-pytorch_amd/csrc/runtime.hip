@@ -798,12 +798,36 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   }
   if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
-  { ProfScope ps("dgrad to_out", st); CK(gemm_nn_bf16(dxb_attn, d.D, w.layer[l].out, d.I, M, d.I, d.D, a.dO, d.I, st)); }
+  // delta = rowsum(dO * O) of the attention backward rides in this GEMM's epilogue when the tile serving it has one (128 x 256 tile:
+  // gemm_epi3.hpp::Epi3BF16Delta); otherwise the attention entry point runs its own pass over O and dO.
+  // MEASURED (round 5, same box, in situ): the GEMM 21.4 -> 33.4 us per launch against 5 us saved in the attention stage -- the row
+  // stage's 16 read-backs per wave each gain a dependent 16-byte load, three lane exchanges and a division on the critical path of a
+  // tile that has only two workgroups per CU to hide them.  A loser by 7 us per layer: OFF by default, VBX_DELTA_FUSED=1 re-enables it.
+  static const bool delta_fused = getenv("VBX_DELTA_FUSED") && atoi(getenv("VBX_DELTA_FUSED")) != 0;
+  bool have_delta = false;
+  {
+    ProfScope ps("dgrad to_out", st);
+    vbx_gemm_desc g{};
+    g.mode = VBX_GEMM_NN; g.epilogue = VBX_EPI_BF16; g.M = M; g.N = d.I; g.K = d.D; g.lda = d.D; g.ldb = d.I; g.ldc = d.I;
+    g.A = dxb_attn; g.B = w.layer[l].out; g.C = a.dO;
+    int rc = VBX_EUNSUPPORTED;
+    if (delta_fused && vbx_attn_bwd_variant() != 2) {
+      g.delta_o = y.oh; g.delta = a.delta; g.H = d.H; g.Np = d.Np;
+      rc = vbx_gemm(&g, st);
+      have_delta = rc == 0;
+    }
+    if (rc == VBX_EUNSUPPORTED) {
+      g.delta_o = nullptr; g.delta = nullptr;
+      rc = vbx_gemm(&g, st);
+    }
+    CK(rc);
+  }
+  const u16* attn_out = have_delta ? nullptr : y.oh;  // NULL: a.delta is already there
   CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp, gs));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     ProfScope ps("bwd attention", st);
-    CK(vbx_attn_bwd_fused_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, y.qrn,
+    CK(vbx_attn_bwd_fused_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, attn_out, 1, a.dO, y.lse, a.delta, y.qrn,
                                   y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos,
                                   m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale,
                                   a.attn_scratch, drop_on ? y.dbr : nullptr, y.dbc, m->attn_dropout, stream));
@@ -814,10 +838,10 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   } else {
     if (y.dbr && drop_on)
-      CK(vbx_attn_bwd_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
+      CK(vbx_attn_bwd_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, attn_out, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
                               a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, y.dbr, y.dbc, m->attn_dropout, stream));
     else
-      CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, y.oh, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
+      CK(vbx_attn_bwd(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, attn_out, 1, a.dO, y.lse, a.delta, a.dq, a.dk,
                       a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                            m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
