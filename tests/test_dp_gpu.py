@@ -376,6 +376,20 @@ def _nccl_world1_worker(port, out):
         torch.cuda.synchronize()
         res[forced] = dict(loss=float(loss), flat=ts.fp.flat.detach().cpu().clone(), g=ts.gflat.detach().cpu().clone(),
                            exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None)
+    # shard mode over RCCL: the in-place reduce_scatter_tensor / all_gather_into_tensor path must be the one that runs (ADVICE r4:
+    # the gloo tests only ever see the all-reduce fallback)
+    os.environ["VBX_FORCE_DIST"] = "1"
+    vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    vb.load_state_dict(state, strict=False)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to("cuda:0"))
+    ts = TrainStep(wrapper, lr=1e-3, max_grad_norm=0.5, bucket_bytes=1 << 16, grad_mode="shard")
+    d = _draws(100, 2, 72, 128)
+    for _ in range(3):
+        with rng_override(**{k: v for k, v in d.items() if k != "x1"}):
+            loss = ts.step(d["x1"].cuda())
+    torch.cuda.synchronize()
+    res["shard"] = dict(loss=float(loss), flat=ts.fp.flat.detach().cpu().clone(), used_reduce_scatter=bool(ts._red.used_reduce_scatter),
+                        native=bool(ts._red.native_shard_collectives))
     dist.destroy_process_group()
     torch.save(res, out)
 
@@ -393,4 +407,6 @@ def test_rccl_path_executes_at_world_size_1(tmp_path):
     res = torch.load(out)
     assert res["1"]["exchange"] and res["1"]["comm_stream"] and not res["0"]["exchange"]
     assert res["1"]["loss"] == res["0"]["loss"]
+    assert res["shard"]["native"] and res["shard"]["used_reduce_scatter"], res["shard"]
+    assert float((res["shard"]["flat"] - res["0"]["flat"]).abs().max()) < 2e-6  # same update up to the last bits of the clip coefficient
     assert torch.equal(res["1"]["g"], res["0"]["g"]) and torch.equal(res["1"]["flat"], res["0"]["flat"])

@@ -96,44 +96,29 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
   float4 ag[NC], ab[NC], ac[NC];
 #pragma unroll
   for (int i = 0; i < NC; i++) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0); }
-  // Round 5: every global load of the wave's rows (x, dy AND the incoming dx) is requested before the first reduction -- the old
-  // order (x, dy -> two wave reductions -> dx_in -> store, row after row) exposed three dependent memory round trips per row to a
-  // wave that has only two rows of work (16.8 us per launch at 68 MB = 4 TB/s).
-  constexpr int RPW = RB_ROWS / NB_WAVES;
-  float4 xv[RPW][NC], dv[RPW][NC], av[RPW][NC];
-  bool rowok[RPW];
-#pragma unroll
-  for (int k = 0; k < RPW; k++) {
+  // (Round 5 tried requesting every global load of the wave's rows -- x, dy AND the incoming dx of both rows -- before the first
+  //  reduction, to take two dependent memory round trips per row off the wave's chain: 94 VGPRs instead of 60-odd, and the kernel
+  //  went from 16.8 to 19.7 us per launch in the train-step profile.  The row-after-row order below stays.)
+  for (int k = 0; k < RB_ROWS / NB_WAVES; k++) {
     const int j = chunk * RB_ROWS + wave + NB_WAVES * k;
-    rowok[k] = j < rpb;
-    const int jc = rowok[k] ? j : (rpb - 1);
-    const long xrow = ((long)b * Np + n0 + jc) * D;
-    const long drow = ((long)b * rpb + jc) * D;
+    if (j >= rpb) break;
+    const long xrow = ((long)b * Np + n0 + j) * D;
+    const long drow = ((long)b * rpb + j) * D;
     const float4* xr = reinterpret_cast<const float4*>(x + xrow);
     const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow);
-    const float4* din = dx_in ? reinterpret_cast<const float4*>(dx_in + xrow) : nullptr;
+    float4 xv[NC], dv[NC];
+    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
-      xv[k][i] = make_float4(0, 0, 0, 0); dv[k][i] = make_float4(0, 0, 0, 0); av[k][i] = make_float4(0, 0, 0, 0);
       if (c < D4) {
-        xv[k][i] = xr[c];
+        xv[i] = xr[c];
         const uint2 p = dyr[c];
-        dv[k][i] = make_float4(bf16_to_f32((u16)(p.x & 0xffff)), bf16_to_f32((u16)(p.x >> 16)),
-                               bf16_to_f32((u16)(p.y & 0xffff)), bf16_to_f32((u16)(p.y >> 16)));
-        if (din) av[k][i] = din[c];
+        dv[i] = make_float4(bf16_to_f32((u16)(p.x & 0xffff)), bf16_to_f32((u16)(p.x >> 16)),
+                            bf16_to_f32((u16)(p.y & 0xffff)), bf16_to_f32((u16)(p.y >> 16)));
+        ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
       }
     }
-  }
-#pragma unroll
-  for (int k = 0; k < RPW; k++) {
-    if (!rowok[k]) break;  // wave-uniform
-    const int j = chunk * RB_ROWS + wave + NB_WAVES * k;
-    const long xrow = ((long)b * Np + n0 + j) * D;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; i++)
-      ss += xv[k][i].x * xv[k][i].x + xv[k][i].y * xv[k][i].y + xv[k][i].z * xv[k][i].z + xv[k][i].w * xv[k][i].w;  // columns past D4 hold zeros
     ss = wave_sum(ss);
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
     float dot = 0.f;
@@ -142,28 +127,28 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
       const int c = lane + 64 * i;
       if (c < D4) {
         const float4 g = g4[c];
-        float4& X = xv[k][i];
-        float4& Dv = dv[k][i];
         // u
-        X.x *= inv; X.y *= inv; X.z *= inv; X.w *= inv;
-        ag[i].x += sqrtD * X.x * Dv.x; ag[i].y += sqrtD * X.y * Dv.y;
-        ag[i].z += sqrtD * X.z * Dv.z; ag[i].w += sqrtD * X.w * Dv.w;
-        ab[i].x += Dv.x; ab[i].y += Dv.y; ab[i].z += Dv.z; ab[i].w += Dv.w;
+        xv[i].x *= inv; xv[i].y *= inv; xv[i].z *= inv; xv[i].w *= inv;
+        ag[i].x += sqrtD * xv[i].x * dv[i].x; ag[i].y += sqrtD * xv[i].y * dv[i].y;
+        ag[i].z += sqrtD * xv[i].z * dv[i].z; ag[i].w += sqrtD * xv[i].w * dv[i].w;
+        ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
         // du
-        Dv.x *= sqrtD * g.x; Dv.y *= sqrtD * g.y; Dv.z *= sqrtD * g.z; Dv.w *= sqrtD * g.w;
-        dot += X.x * Dv.x + X.y * Dv.y + X.z * Dv.z + X.w * Dv.w;
+        dv[i].x *= sqrtD * g.x; dv[i].y *= sqrtD * g.y; dv[i].z *= sqrtD * g.z; dv[i].w *= sqrtD * g.w;
+        dot += xv[i].x * dv[i].x + xv[i].y * dv[i].y + xv[i].z * dv[i].z + xv[i].w * dv[i].w;
       }
     }
     dot = wave_sum(dot);
+    const float4* din = dx_in ? reinterpret_cast<const float4*>(dx_in + xrow) : nullptr;
     float4* dout = reinterpret_cast<float4*>(dx_out + xrow);
     uint2* dbo = dxb ? reinterpret_cast<uint2*>(dxb + xrow) : nullptr;
 #pragma unroll
     for (int i = 0; i < NC; i++) {
       const int c = lane + 64 * i;
       if (c < D4) {
-        const float4 X = xv[k][i], Dv = dv[k][i], a = av[k][i];
-        float4 o = make_float4((Dv.x - X.x * dot) * inv, (Dv.y - X.y * dot) * inv, (Dv.z - X.z * dot) * inv, (Dv.w - X.w * dot) * inv);
-        if (dx_in) {
+        float4 o = make_float4((dv[i].x - xv[i].x * dot) * inv, (dv[i].y - xv[i].y * dot) * inv,
+                               (dv[i].z - xv[i].z * dot) * inv, (dv[i].w - xv[i].w * dot) * inv);
+        if (din) {
+          const float4 a = din[c];
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
           ac[i].x += a.x; ac[i].y += a.y; ac[i].z += a.z; ac[i].w += a.w;
         }

@@ -48,6 +48,12 @@ class GradBucketReducer:
         # record_stream -- on a single GPU; an all-reduce over one rank is the identity)
         self.active = self.world > 1 or (force_dist() and dist.is_available() and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        # Which collectives the shard mode uses is decided HERE, per reducer, from the backend and the device of the buffer (ADVICE r4:
+        # a try / except fallback flipped a process-global flag on any RuntimeError -- a real RCCL error was hidden, and a failure on
+        # one rank made the ranks issue different collectives).  RCCL (backend "nccl") has in-place reduce_scatter_tensor /
+        # all_gather_into_tensor on device tensors; gloo gets the all-reduce / per-chunk broadcast forms.  Errors propagate.
+        self.native_shard_collectives = bool(self.active and gflat.is_cuda and dist.get_backend(group) == "nccl")
+        self.uneven_logged = False
         self.comm_stream = comm_stream
         self.pending_lo = None
         self.pending_hi = None
@@ -55,8 +61,9 @@ class GradBucketReducer:
         self.buckets_launched = []
 
     def chunk_of(self, lo, hi, r=None):
-        """Rank r's chunk of bucket [lo, hi): equal parts (flat slots and stage boundaries are multiples of 64 floats, so a bucket
-        divides by any world size up to 64; a remainder, if ever, goes to the last rank)."""
+        """Rank r's chunk of bucket [lo, hi): equal parts.  Flat slots and stage boundaries are multiples of 64 floats, so a bucket
+        divides evenly by every POWER-OF-TWO world size up to 64; for other world sizes (3, 6, 7 ...) the remainder goes to the last
+        rank and the exchange falls back to all-reduce + per-chunk broadcasts (no traffic saved; logged once)."""
         r = self.rank if r is None else r
         n = (hi - lo) // self.world
         return lo + r * n, (hi if r == self.world - 1 else lo + (r + 1) * n)
@@ -65,18 +72,19 @@ class GradBucketReducer:
         if not self.shard:
             return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         n = (hi - lo) // self.world
-        if n * self.world != hi - lo:  # (never with this package's flat layout) uneven: all-reduce, every rank keeps its chunk
+        if n * self.world != hi - lo:  # world size not a power of two: all-reduce, every rank keeps its chunk
+            if not self.uneven_logged and self.rank == 0:
+                print(f"voicebox_pytorch_amd.dp: bucket of {hi - lo} floats does not divide by world size {self.world}: "
+                      "shard mode exchanges it by all-reduce + broadcasts (no wire traffic saved)", flush=True)
+            self.uneven_logged = True
             return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        out = view[self.rank * n:(self.rank + 1) * n]  # in place: the output is this rank's slice of the input
-        if not GradBucketReducer._no_reduce_scatter:
-            try:
-                return dist.reduce_scatter_tensor(out, view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            except RuntimeError:  # a backend without it for this tensor type (gloo on device tensors): same result, more bytes
-                GradBucketReducer._no_reduce_scatter = True
+        if self.native_shard_collectives:  # in place: the output is this rank's slice of the input
+            self.used_reduce_scatter = True
+            return dist.reduce_scatter_tensor(view[self.rank * n:(self.rank + 1) * n], view, op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True)
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    _no_reduce_scatter = False
-    _no_all_gather = False
+    used_reduce_scatter = False  # set on the instance when the in-place reduce-scatter path ran (asserted by the RCCL test)
 
     def _launch(self, lo, hi):
         if hi <= lo:
@@ -140,7 +148,7 @@ class GradBucketReducer:
 
     def all_gather(self, flat):
         """shard mode, after the owners updated their chunks of `flat` (the parameters): every bucket's chunks are all-gathered in
-        place (rank r's input is its own slice of the output), on the communication stream when there is one."""
+        place (rank r's input is its own slice of the output), issued on the CURRENT stream and waited for before returning."""
         if not (self.shard and self.active):
             return
         works = []
@@ -153,12 +161,9 @@ class GradBucketReducer:
                     works.append(dist.broadcast(flat[clo:chi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
                                                 group=self.group, async_op=True))
                 continue
-            if not GradBucketReducer._no_all_gather:
-                try:
-                    works.append(dist.all_gather_into_tensor(view, view[self.rank * n:(self.rank + 1) * n], group=self.group, async_op=True))
-                    continue
-                except RuntimeError:
-                    GradBucketReducer._no_all_gather = True
+            if self.native_shard_collectives:
+                works.append(dist.all_gather_into_tensor(view, view[self.rank * n:(self.rank + 1) * n], group=self.group, async_op=True))
+                continue
             for r in range(self.world):
                 works.append(dist.broadcast(view[r * n:(r + 1) * n], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
                                             group=self.group, async_op=True))

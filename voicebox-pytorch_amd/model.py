@@ -313,6 +313,9 @@ class Transformer(nn.Module):
         return self._flat
 
     def forward(self, x, mask=None, adaptive_rmsnorm_cond=None):  # voicebox_pytorch.py:412-479
+        if precise_enabled():  # the process-wide precise switch must not silently return fast-path results here
+            raise NotImplementedError("precise mode (set_precise / precise_mode / VBX_PRECISE) covers VoiceBox only; the stand-alone "
+                                      "Transformer (and DurationPredictor) run on the fast path -- leave precise mode to call them")
         if self.adaptive_rmsnorm:
             assert exists(adaptive_rmsnorm_cond), "adaptive_rmsnorm = True needs adaptive_rmsnorm_cond (batch, cond_dim)"
         else:

@@ -124,9 +124,12 @@ class VoiceBoxTrainer(nn.Module):
             return wd_p + [p for p in params if p.ndim < 2], len(wd_p)
         return params, len(params)
 
-    def _optim_state_dict(self):
+    def _optim_state_dict(self, gathered=False):
         ts = self.train_step_fn
-        ts.gather_optimizer_state()  # grad_mode="shard": the moments of a chunk live on its owner (a collective: every rank calls save())
+        if not gathered:
+            # grad_mode="shard": the moments of a chunk live on its owner; gathering them is a collective, so a direct save() /
+            # _optim_state_dict() call must be made by EVERY rank (train_step() gathers on all ranks itself and passes gathered=True)
+            ts.gather_optimizer_state()
         fp = ts.fp
         by_param = {id(fp.slots[s]): s for s in fp.order}
         state = {}
@@ -180,8 +183,10 @@ class VoiceBoxTrainer(nn.Module):
         return dict(T_max=sc.T, eta_min=0, base_lrs=[sc.lr], last_epoch=sc.sched_epoch, _step_count=sc.sched_epoch + 1,
                     _get_lr_called_within_step=False, _last_lr=[sc.cur], verbose=False)
 
-    def save(self, path):
-        pkg = dict(model=self.cfm_wrapper.state_dict(), optim=self._optim_state_dict(), scheduler=self._scheduler_state_dict())
+    def save(self, path, gathered=False):
+        """Reference checkpoint format.  With TrainStep(grad_mode="shard") and world size > 1 call it on EVERY rank (only rank 0 needs
+        to pass a real path to keep) unless the optimizer state was gathered collectively beforehand (gathered=True)."""
+        pkg = dict(model=self.cfm_wrapper.state_dict(), optim=self._optim_state_dict(gathered), scheduler=self._scheduler_state_dict())
         torch.save(pkg, path)
 
     def load(self, path):
@@ -253,8 +258,13 @@ class VoiceBoxTrainer(nn.Module):
                 valid_loss = self.cfm_wrapper(x.to(self.device), **({'semantic_token_ids': ids.to(self.device)} if ids is not None else {}))
             self.print(f'{steps}: valid loss {float(valid_loss):0.3f}')
             logs['valid_loss'] = float(valid_loss)
+        if not (steps % self.save_model_every):
+            # grad_mode="shard": the Adam moments of a chunk live on its owner -- collecting them is a COLLECTIVE, so every rank takes
+            # part here, before rank 0 alone writes the file (a rank-0-only gather would hang or pair with the other ranks'
+            # next-step collectives).  A no-op in all-reduce mode.
+            self.train_step_fn.gather_optimizer_state()
         if self.is_main and not (steps % self.save_model_every):
-            self.save(str(self.results_folder / f'voicebox.{steps}.pt'))
+            self.save(str(self.results_folder / f'voicebox.{steps}.pt'), gathered=True)
             self.print(f'{steps}: saving model to {str(self.results_folder)}')
         self.steps += 1
         return logs
