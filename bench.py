@@ -254,6 +254,10 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="train mode: skip the 64-interval sample leg")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="wire dtype of the gradient all-reduce (N > 1)")
     ap.add_argument("--bucket-mb", type=int, default=0, help="gradient all-reduce bucket size in MiB (0: the library default)")
+    ap.add_argument("--adaln-exchange", default="auto", choices=["auto", "factors", "materialize"],
+                    help="gradient of the adaLN projection weights (49 %% of the parameters, rank-B outer products): 'factors' keeps it in "
+                         "factor form (N = 1: Adam expands it; N > 1: the factors are all-gathered instead of all-reducing the product: "
+                         "half of the wire), 'materialize' is round 4's path")
     ap.add_argument("--grad-mode", default="allreduce", choices=["allreduce", "shard"],
                     help="N > 1: all-reduce + replicated optimizer (DDP semantics) or reduce-scatter + sharded clip / Adam + parameter all-gather")
     args = ap.parse_args()
@@ -288,7 +292,7 @@ def main():
 
         kw = {"bucket_bytes": args.bucket_mb << 20} if args.bucket_mb > 0 else {}
         ts = TrainStep(wrapper, lr=3e-4, max_grad_norm=0.5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None,
-                       grad_mode=args.grad_mode, **kw)
+                       grad_mode=args.grad_mode, adaln_grads=args.adaln_exchange, **kw)
         step = lambda: ts.step(x)
         units_per_step = args.batch * args.frames
         flops_per_step_per_gpu = 3.0 * fwd_flops_per_frame(args.dim, args.depth, args.heads, args.frames, 16) * units_per_step
@@ -358,6 +362,9 @@ def main():
             out["grad_comm"] = args.grad_comm
             out["grad_mode"] = args.grad_mode
             out["bucket_mb"] = args.bucket_mb
+        if args.mode == "train":
+            out["adaln_grads"] = "factors" if ts.adaln_factors_apply() else "materialize"
+            out["wire_bytes_per_step"] = int(getattr(ts, "wire_bytes", 0) or 0)  # bytes this rank hands to collectives per step (0 at N = 1)
         if loss_val is not None:
             out["final_loss"] = round(loss_val, 5)
         # ---- roofline: the DOMINANT MFMA stage of the timed workload, timed in situ with HIP events on the launch stream

@@ -402,6 +402,26 @@ int vbx_adam_step_packed(float* p, const float* g, float* m, float* v, const vbx
                          void* stream);
 /* sum of squares of a flat buffer -> out[0] (two-stage, deterministic) ; scratch >= 1024 floats */
 int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
+/* ---- adaLN projection weight gradients in FACTOR form (round 5; vbx_model.adaln_factors).  The gradient of a layer's adaLN weight
+ * block W_l [J4 = 4 D, Th] (voicebox_pytorch.py:256-276: to_gamma / to_beta of the two AdaptiveRMSNorms, contiguous) is
+ * dada_l^T . temb with dada_l [B, J4] and temb [B, Th] -- half of all parameters, defined by B * (J4 + Th) numbers.  In factor
+ * mode the backward entry points leave that block of the gradient buffer UNWRITTEN and the optimizer works from the factors:
+ *   vbx_sumsq_adaln_factors : |dada_l^T . temb|_F^2 per layer -> out[l] (two B x B Gram matrices each);
+ *   vbx_sumsq_ranges        : sum of squares over n <= 32 ranges [lo, hi) of x (host array of 2 n longs, multiples of 4 floats)
+ *                             plus n_extra values already stored at scratch[1024 ..) -> out[0]; scratch >= 1024 + n_extra floats;
+ *   vbx_adam_adaln_factors  : torch.optim.Adam (as vbx_adam_step) on the L blocks at flat offsets w_off[l] with the gradient
+ *                             expanded on the fly, refreshing the fp16 operand copies dst_f16[l] ([J4][Th]; may be NULL).
+ * vbx_model_adaln_factors gives the factor pointers and the block offsets of a model's training arena. */
+int vbx_sumsq_adaln_factors(const float* dada /* [L][B][J4] */, const float* temb /* [B][Th] */, int L, int B, int J4, int Th,
+                            float* out /* [L] */, void* stream);
+/* dw [J4, Th] = dada^T . temb for any B (the data-parallel exchange gathers every rank's factors and expands the summed gradient
+ * locally: dp.GradBucketReducer(adaln_factors=...)) */
+int vbx_adaln_expand_dw(const float* temb /* [B][Th] */, const float* dada /* [B][J4] */, float* dw, int B, int Th, int J4, int reserved,
+                        void* stream);
+int vbx_sumsq_ranges(const float* x, const long* ranges /* host [2 n] */, int n, int n_extra, float* out, float* scratch, void* stream);
+int vbx_adam_adaln_factors(float* p, float* m, float* v, const long* w_off /* host [L] */, void* const* dst_f16 /* host [L] or NULL */,
+                           const float* dada, const float* temb, int L, int B, int J4, int Th, float lr, float beta1, float beta2,
+                           float eps, int step, const float* gscale, void* stream);
 /* gradient-clip coefficient for a buffer holding the SUM over `world` ranks (inv_world = 1/world):
  * norm = sqrt(sumsq)*inv_world; coef[0] = min(1, max_norm/(norm+1e-6)) * inv_world (max_norm <= 0: no clipping);
  * coef[1] = norm.  (accelerator.clip_grad_norm_, trainer.py:274-275) */
@@ -457,6 +477,10 @@ typedef struct {
   int unet;               /* use_unet_skip_connection (voicebox_pytorch.py:368-369,391-398,453-463; stack_only models: VoiceBox never
                              enables it): layer l >= L / 2 starts with x = Linear(2 * dim, dim)(cat(x, skip_scale * input of layer L-1-l)) */
   float skip_scale;       /* skip_connect_scale (:390), 2^-0.5 by default */
+  int adaln_factors;      /* 1 (training, adaptive norms): vbx_model_backward_layer does NOT write the gradients of the adaLN projection
+                             WEIGHTS (slots VBX_L_G1W .. VBX_L_B2W) -- they stay in factor form (vbx_model_adaln_factors; the
+                             optimizer expands them, see vbx_adam_adaln_factors) and vbx_model_adam_segments leaves those blocks
+                             out of the fused Adam's table.  Biases, d(time_emb) and every other gradient are unchanged. */
 } vbx_model;
 
 typedef struct {
@@ -487,6 +511,10 @@ typedef struct {
 size_t vbx_model_wpack_bytes(const vbx_model* m);
 size_t vbx_model_act_bytes(const vbx_model* m);
 int vbx_model_pack_weights(const vbx_model* m, void* stream);
+/* factor form of the adaLN weight gradients of the last backward (valid until the next forward of this arena): dada [L][B][4 D],
+ * temb [B][Th]; w_off[l] = flat offset of layer l's weight block, dst_f16[l] = its fp16 operand copy in the wpack arena (HOST arrays
+ * of L entries each, either may be NULL) */
+int vbx_model_adaln_factors(const vbx_model* m, const float** dada, const float** temb, long* w_off, void** dst_f16);
 /* segment table for vbx_adam_step_packed (see there) */
 int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam_seg* out, int max_segs, long* total_blocks);
 int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);

@@ -244,3 +244,82 @@ def test_sharded_exchange_equals_replicated_bit_for_bit():
     assert own_ok and p_same and mv_same
     assert dcoef < 1e-6, dcoef
     assert covered * 2 == n  # each rank owns exactly half of the flat buffer
+
+
+def _factor_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from voicebox_pytorch_amd.dp import GradBucketReducer, gather_adaln_factors
+
+    # a flat buffer in this package's layout: head | layer 1 = [adaLN weight block | rest] | layer 0 = [adaLN weight block | rest] | embed
+    L, B, J4, Th = 2, 3, 128, 192
+    blk = J4 * Th
+    sizes = [64 * 5, blk + 64 * 9, blk + 64 * 7, 64 * 4]
+    bounds = [0]
+    for z in sizes:
+        bounds.append(bounds[-1] + z)
+    ranges = [(bounds[i], bounds[i + 1]) for i in range(4)]
+    ada = {1: (bounds[1], bounds[1] + blk), 0: (bounds[2], bounds[2] + blk)}  # layer -> its adaLN weight block
+    n = bounds[-1]
+    gen = torch.Generator().manual_seed(100 + rank)
+    dada, temb = torch.randn(L, B, J4, generator=gen), torch.randn(B, Th, generator=gen)
+    g_local = torch.randn(n, generator=gen)
+    for l, (lo, hi) in ada.items():
+        g_local[lo:hi] = (dada[l].t() @ temb).flatten()  # what the backward writes in "materialize" mode
+    # A: every gradient all-reduced (DDP)
+    gA = g_local.clone()
+    redA = GradBucketReducer(gA, ranges, bucket_bytes=64 * 30 * 4)
+    for i, rng in enumerate(ranges):
+        redA.stage_done(i, rng)
+    redA.finish()
+    # B: the adaLN weight blocks travel as factors; their slots of the local buffer were never written (NaN here)
+    gB = g_local.clone()
+    for lo, hi in ada.values():
+        gB[lo:hi] = float("nan")
+    redB = GradBucketReducer(gB, ranges, bucket_bytes=64 * 30 * 4, skip_ranges=list(ada.values()))
+    for i, rng in enumerate(ranges):
+        redB.stage_done(i, rng)
+    dada_all, temb_all, fwire = gather_adaln_factors(dada, temb)
+    redB.finish()
+    for l, (lo, hi) in ada.items():
+        gB[lo:hi] = (dada_all[l].t() @ temb_all).flatten()  # vbx_adaln_expand_dw on the GPU
+    covered = sorted(redB.buckets_launched)
+    gaps_ok = all(not (lo < b and a < hi) for lo, hi in covered for a, b in ada.values())  # no bucket touches a factor block
+    lr, b1, b2, eps = 1e-3, 0.9, 0.99, 1e-8
+
+    def adam(g):
+        p = torch.randn(n, generator=torch.Generator().manual_seed(7))
+        coef = torch.clamp(0.5 / (g.pow(2).sum().sqrt() / world + 1e-6), max=1.0) / world
+        gr = g * coef
+        m, v = (1 - b1) * gr, (1 - b2) * gr * gr
+        return p - lr / (1 - b1) * m / (v.sqrt() / (1 - b2) ** 0.5 + eps)
+
+    pA, pB = adam(gA), adam(gB)
+    if rank == 0:
+        out.put((float((gA - gB).abs().max() / gA.abs().max()), float((pA - pB).abs().max()), gaps_ok, redA.wire_floats,
+                 redB.wire_floats + fwire, sum(hi - lo for lo, hi in covered), n - 2 * blk, bool(torch.isfinite(gB).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_adaln_factor_exchange_equals_allreduce_of_the_products():
+    """TrainStep(adaln_grads="factors") at world size > 1: the adaLN weight blocks are left out of the bucketed
+    all-reduce (GradBucketReducer(skip_ranges=...)), every rank all-gathers the factors dada [L, B, 4 D] / temb [B, Th] and expands
+    dada_all^T . temb_all locally.  gloo, world 2: the resulting gradient equals the all-reduce of the materialised products to fp32
+    rounding, so does the parameter after one clipped Adam step; no bucket touches a factor block; the wire carries the rest of the
+    buffer plus B * (L * 4 D + Th) floats per rank instead of the whole buffer."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_factor_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gerr, perr, gaps_ok, wireA, wireB, covered, rest, finite = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert finite and gaps_ok and covered == rest
+    assert gerr < 1e-6 and perr < 1e-6, (gerr, perr)
+    assert wireB < 0.1 * wireA, (wireA, wireB)  # here the factor blocks are 97 % of the buffer; at dim 512 / depth 12 they are 49 %

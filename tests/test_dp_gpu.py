@@ -198,6 +198,69 @@ def test_train_step_shard_mode_equals_allreduce_mode_world2_on_one_gpu():
     assert d < 2e-7, d  # one Adam step of size ~lr = 1e-3: the clip coefficient differs in the last fp32 bits only
 
 
+def test_adaln_factor_mode_equals_materialised_gradients():
+    """TrainStep(adaln_grads="factors") on one GPU (round 5): the adaLN projection weight gradients are never written -- the global norm
+    takes their sum of squares from the B x B Gram matrices of the factors (vbx_sumsq_adaln_factors + vbx_sumsq_ranges), Adam expands
+    dada_l^T . temb on the fly (vbx_adam_adaln_factors) -- against adaln_grads="materialize" (round 4's path) from the same weights and
+    draws: same clip coefficient and gradient norm to fp32 rounding, same parameters after each of three steps (the update of every
+    tensor, adaLN weights included, to 1e-4 of its norm), the fp16 operand copies of the adaLN weights refreshed (next forward's loss
+    equal), every other gradient bit-identical, and the adaLN weight blocks of the gradient buffer left untouched."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+    from oracle import restate
+
+    cfg = restate.Cfg(dim=128, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=11)
+    for k in state:  # the reference zero-initialises the adaLN projections (:264-268): randomise them so that they matter
+        if ".to_gamma." in k or ".to_beta." in k:
+            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(hash(k) % 1000))
+    d = _draws(321, 3, 72, 128)
+    runs = {}
+    for mode in ("materialize", "factors"):
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(state, strict=False)
+        ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to(dev)), lr=1e-3, max_grad_norm=0.5, adaln_grads=mode)
+        assert ts.adaln_factors_apply() == (mode == "factors")
+        ts.gflat.fill_(7.0)  # sentinel: factor mode must not touch the adaLN weight blocks
+        p0 = ts.fp.flat.clone()
+        rec = []
+        for _ in range(3):
+            with rng_override(**{k: v for k, v in d.items() if k != "x1"}):
+                loss = ts.step(d["x1"].to(dev))
+            torch.cuda.synchronize()
+            rec.append((float(loss), ts.coef.clone().cpu(), ts.fp.flat.clone()))
+        runs[mode] = dict(rec=rec, g=ts.gflat.clone(), p0=p0, ranges=ts.adaln_weight_ranges(), fp=ts.fp)
+    a, b = runs["materialize"], runs["factors"]
+    for step, ((la, ca, pa), (lb, cb, pb)) in enumerate(zip(a["rec"], b["rec"])):
+        assert abs(la - lb) < 1e-6 * max(1.0, abs(la)) if step == 0 else abs(la - lb) < 2e-3, (step, la, lb)  # (later steps: chaotic init)
+        if step == 0:
+            assert float((ca - cb).abs().max() / ca.abs().max()) < 1e-5, (ca, cb)  # clip coefficient and norm
+            fp = a["fp"]
+            for slot in fp.order:
+                o, n = fp.offsets[slot], fp.slots[slot].numel()
+                ua, ub = pa[o:o + n] - a["p0"][o:o + n], pb[o:o + n] - b["p0"][o:o + n]
+                e = float((ua - ub).norm() / ua.norm().clamp(min=1e-30))
+                assert e < 1e-4, (slot, e)
+    inside = torch.zeros_like(b["g"], dtype=torch.bool)
+    for lo, hi in b["ranges"]:
+        inside[lo:hi] = True
+    assert bool((b["g"][inside] == 7.0).all())  # never written
+    assert not bool((a["g"][inside] == 7.0).any())
+    # the first step's other gradients are the same kernels on the same inputs; compare after step 1 only is not possible here (three
+    # steps ran), so: a fresh single step of each mode
+    gs = {}
+    for mode in ("materialize", "factors"):
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(state, strict=False)
+        ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to(dev)), lr=1e-3, max_grad_norm=0.5, adaln_grads=mode)
+        with rng_override(**{k: v for k, v in d.items() if k != "x1"}):
+            ts.step(d["x1"].to(dev))
+        torch.cuda.synchronize()
+        gs[mode] = ts.gflat.clone()
+    assert torch.equal(gs["materialize"][~inside], gs["factors"][~inside])
+
+
 def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
     """wd > 0 (optimizer.py:10-35): AdamW with decoupled decay on the ndim >= 2 parameters only.  TrainStep(wd=...) must equal torch:
     the same gradients -> clip_grad_norm_(0.5) -> torch.optim.AdamW over get_optimizer's two parameter groups; and the trainer's
@@ -374,8 +437,12 @@ def _nccl_world1_worker(port, out):
             with rng_override(**{k: v for k, v in d.items() if k != "x1"}):
                 loss = ts.step(d["x1"].cuda())
         torch.cuda.synchronize()
+        outside = torch.ones(ts.gflat.numel(), dtype=torch.bool)
+        for lo, hi in ts.adaln_weight_ranges():
+            outside[lo:hi] = False
         res[forced] = dict(loss=float(loss), flat=ts.fp.flat.detach().cpu().clone(), g=ts.gflat.detach().cpu().clone(),
-                           exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None)
+                           exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None, outside=outside,
+                           wire_bytes=getattr(ts, "wire_bytes", None))
     # shard mode over RCCL: the in-place reduce_scatter_tensor / all_gather_into_tensor path must be the one that runs (ADVICE r4:
     # the gloo tests only ever see the all-reduce fallback)
     os.environ["VBX_FORCE_DIST"] = "1"
@@ -406,7 +473,12 @@ def test_rccl_path_executes_at_world_size_1(tmp_path):
     assert p.exitcode == 0, p.exitcode
     res = torch.load(out)
     assert res["1"]["exchange"] and res["1"]["comm_stream"] and not res["0"]["exchange"]
-    assert res["1"]["loss"] == res["0"]["loss"]
+    assert abs(res["1"]["loss"] - res["0"]["loss"]) < 2e-3  # third step of two runs whose adaLN weights differ in their last bits
     assert res["shard"]["native"] and res["shard"]["used_reduce_scatter"], res["shard"]
     assert float((res["shard"]["flat"] - res["0"]["flat"]).abs().max()) < 2e-6  # same update up to the last bits of the clip coefficient
-    assert torch.equal(res["1"]["g"], res["0"]["g"]) and torch.equal(res["1"]["flat"], res["0"]["flat"])
+    # forced = "1": the exchange is active, the adaLN weight gradients travel as factors and are expanded into the buffer; forced = "0":
+    # one GPU without exchange, they stay in factor form and their blocks of the buffer are not written -- compare everything else
+    # bit for bit, and the parameters (whose adaLN blocks were updated from the same factors by two different kernels) to rounding
+    outside = res["0"]["outside"]
+    assert torch.equal(res["1"]["g"][outside], res["0"]["g"][outside])
+    assert float((res["1"]["flat"] - res["0"]["flat"]).abs().max()) < 1e-4  # three steps of size ~lr = 1e-3 each

@@ -600,7 +600,7 @@ VBX_DEV void adaln_bwd_w_role(const float* __restrict__ temb, const float* __res
         s.x += g * t[b].x; s.y += g * t[b].y; s.z += g * t[b].z; s.w += g * t[b].w;
         sb += g;
       }
-      *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
+      if (dw) *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
       if (t4 == 0) dbias[j] = sb;
     }
     return;
@@ -616,7 +616,7 @@ VBX_DEV void adaln_bwd_w_role(const float* __restrict__ temb, const float* __res
       s.x += g * t.x; s.y += g * t.y; s.z += g * t.z; s.w += g * t.w;
       sb += g;
     }
-    *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
+    if (dw) *reinterpret_cast<float4*>(dw + (long)j * Th + t4 * 4) = s;
     if (t4 == 0) dbias[j] = sb;
   }
 }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel_v2(const float* __restri
     for (int r = 0; r < ADA_WROWS; r++) {
       const int j = j0 + r;
       if (j < J) {
-        *reinterpret_cast<float4*>(dw + (long)j * Th + (long)t4 * 4) = s[r];
+        if (dw) *reinterpret_cast<float4*>(dw + (long)j * Th + (long)t4 * 4) = s[r];  // NULL: the gradient stays in factor form
         if (t4 == 0) dbias[j] = sb[r];
       }
     }
@@ -1196,6 +1196,145 @@ __global__ __launch_bounds__(256) void adam_packed_kernel(float* __restrict__ p,
     }
   }
 }
+// ---- adaLN projection weights in FACTOR form (round 5) ------------------------------------------------------------------------
+// The gradient of the adaLN projection weight block of a layer, W_l [J4 = 4 D rows, Th cols], is the rank-B outer product
+//   dW_l = dada_l^T . temb        (dada_l [B, J4]: d(gamma | beta) of the layer's two norms per batch row, temb [B, Th])
+// -- 49 % of all parameters at dim 512 / depth 12, written (201 MB), re-read by the norm pass and re-read by Adam every step although
+// it is defined by B * (J4 + Th) numbers.  In factor mode (vbx_model.adaln_factors) the backward never writes it: Adam expands the
+// product on the fly, the global norm takes its sum of squares from two B x B Gram matrices per layer, and a data-parallel run puts
+// the factors on the wire instead of the product (dp.py).
+// Adam: one block = ADAF_ROWS weight rows x 1024 columns; a thread keeps its 4 columns of every temb row in registers (8 batch rows
+// per pass) and walks the rows: the factors cost 4 bytes of L2 traffic per parameter instead of 4 bytes of HBM read + the 8 bytes
+// the materialised gradient cost elsewhere.
+constexpr int ADAF_ROWS = 16;
+struct AdaFactorArgs {
+  long w_off[32];     // flat offset of W_l (floats)
+  u16* dst_f16[32];   // packed fp16 copy of W_l ([J4][Th], row stride Th)
+  const float* dada;  // [L][B][J4]
+  const float* temb;  // [B][Th]
+  int L, B, J4, Th;
+};
+__global__ __launch_bounds__(256) void adam_adaln_factor_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                                const AdaFactorArgs a, float lr_bc1, float b1, float b2, float eps,
+                                                                float bc2_sqrt, const float* __restrict__ gscale) {
+  const int l = blockIdx.z, r0 = blockIdx.y * ADAF_ROWS;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= a.Th) return;
+  const AdamCoef k{lr_bc1, b1, b2, eps, bc2_sqrt, gscale ? gscale[0] : 1.0f};
+  const float* da = a.dada + (long)l * a.B * a.J4;
+  float4 acc[ADAF_ROWS];
+#pragma unroll
+  for (int r = 0; r < ADAF_ROWS; r++) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < a.B; b0 += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++)
+      t[kk] = (b0 + kk < a.B) ? *reinterpret_cast<const float4*>(a.temb + (long)(b0 + kk) * a.Th + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < ADAF_ROWS; r++) {
+      const int j = min(r0 + r, a.J4 - 1);
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const float g = (b0 + kk < a.B) ? da[(long)(b0 + kk) * a.J4 + j] : 0.f;  // block-uniform address: scalar loads
+        acc[r].x += g * t[kk].x; acc[r].y += g * t[kk].y; acc[r].z += g * t[kk].z; acc[r].w += g * t[kk].w;
+      }
+    }
+  }
+  u16* dh = a.dst_f16[l];
+#pragma unroll
+  for (int r = 0; r < ADAF_ROWS; r++) {
+    const int j = r0 + r;
+    if (j >= a.J4) break;
+    const long i = a.w_off[l] + (long)j * a.Th + c;
+    float4 mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+    float4 pv = *reinterpret_cast<const float4*>(p + i);
+    pv.x = adam_one(pv.x, acc[r].x, mv.x, vv.x, k);
+    pv.y = adam_one(pv.y, acc[r].y, mv.y, vv.y, k);
+    pv.z = adam_one(pv.z, acc[r].z, mv.z, vv.z, k);
+    pv.w = adam_one(pv.w, acc[r].w, mv.w, vv.w, k);
+    *reinterpret_cast<float4*>(m + i) = mv;
+    *reinterpret_cast<float4*>(v + i) = vv;
+    *reinterpret_cast<float4*>(p + i) = pv;
+    if (dh) *reinterpret_cast<uint2*>(dh + (long)j * a.Th + c) = make_uint2(pack_f16x2(pv.x, pv.y), pack_f16x2(pv.z, pv.w));
+  }
+}
+// dW [J4, Th] = dada^T . temb for ANY number of batch rows B (the data-parallel exchange gathers every rank's factors and expands the
+// summed gradient locally: dp.GradBucketReducer(adaln="factors")) -- the weight-gradient half of adaln_bwd_kernel_v2 on its own.
+__global__ __launch_bounds__(256) void adaln_expand_dw_kernel(const float* __restrict__ temb, const float* __restrict__ dada,
+                                                              float* __restrict__ dw, int B, int Th, int J) {
+  __shared__ float gsh[8 * ADA_WROWS];
+  const int tid = threadIdx.x;
+  const int j0 = (int)blockIdx.y * ADA_WROWS;
+  const int t4 = blockIdx.x * 256 + tid;
+  const bool tv = (long)t4 * 4 < Th;
+  const float* tcol = temb + (tv ? t4 : 0) * 4;
+  float4 s[ADA_WROWS];
+#pragma unroll
+  for (int r = 0; r < ADA_WROWS; r++) s[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    __syncthreads();
+    if (tid < 8 * ADA_WROWS) {
+      const int j = j0 + (tid >> 3), b = b0 + (tid & 7);
+      gsh[tid] = (j < J && b < B) ? dada[(long)b * J + j] : 0.f;
+    }
+    __syncthreads();
+    float4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const float4*>(tcol + (long)min(b0 + k, B - 1) * Th);  // weight 0 past B
+#pragma unroll
+    for (int r = 0; r < ADA_WROWS; r++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float g = gsh[r * 8 + k];
+        s[r].x += g * t[k].x; s[r].y += g * t[k].y; s[r].z += g * t[k].z; s[r].w += g * t[k].w;
+      }
+    }
+  }
+  if (tv) {
+#pragma unroll
+    for (int r = 0; r < ADA_WROWS; r++)
+      if (j0 + r < J) *reinterpret_cast<float4*>(dw + (long)(j0 + r) * Th + (long)t4 * 4) = s[r];
+  }
+}
+// |dada_l^T . temb|_F^2 = sum_{b,b'} (dada_l[b] . dada_l[b']) (temb[b] . temb[b'])  ->  out[l]   (one block per layer, B <= 16)
+__global__ __launch_bounds__(256) void adaln_factor_sumsq_kernel(const float* __restrict__ dada, const float* __restrict__ temb,
+                                                                 float* __restrict__ out, int B, int J4, int Th) {
+  __shared__ float red[4];
+  const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* da = dada + (long)l * B * J4;
+  float tot = 0.f;
+  for (int pair = wave; pair < B * B; pair += 4) {  // wave-uniform pair (b, b'), b <= b' counted twice off the diagonal
+    const int b = pair / B, bp = pair - b * B;
+    if (bp < b) continue;
+    float g1 = 0.f, g2 = 0.f;
+    for (int j = lane; j < J4; j += 64) g1 += da[(long)b * J4 + j] * da[(long)bp * J4 + j];
+    for (int t = lane; t < Th; t += 64) g2 += temb[(long)b * Th + t] * temb[(long)bp * Th + t];
+    g1 = wave_sum(g1);
+    g2 = wave_sum(g2);
+    tot += (bp == b ? 1.0f : 2.0f) * g1 * g2;
+  }
+  if (lane == 0) red[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) out[l] = red[0] + red[1] + red[2] + red[3];
+}
+// sum of squares over up to 32 ranges [lo, hi) of a flat buffer (every lo / hi a multiple of 4 floats, 16-byte aligned base):
+// the flat gradient buffer minus the adaLN weight blocks that stay in factor form
+struct SumsqRanges { long lo[32], pre[33]; int n; };  // pre[k] = float4 count of ranges 0..k-1
+__global__ __launch_bounds__(256) void sumsq_ranges_stage1(const float* __restrict__ x, const SumsqRanges rg, float* __restrict__ scratch) {
+  __shared__ float red[4];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long n4 = rg.pre[rg.n];
+  int kr = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    while (i >= rg.pre[kr + 1]) kr++;  // the virtual index only grows
+    const float4 vv = *reinterpret_cast<const float4*>(x + rg.lo[kr] + (i - rg.pre[kr]) * 4);
+    s0 = fmaf(vv.x, vv.x, s0); s1 = fmaf(vv.y, vv.y, s1); s2 = fmaf(vv.z, vv.z, s2); s3 = fmaf(vv.w, vv.w, s3);
+  }
+  float s = wave_sum((s0 + s1) + (s2 + s3));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
                             const float* __restrict__ gscale) {
@@ -1536,7 +1675,7 @@ extern "C" int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J) { return 
 
 extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias,
                                   float* dtemb, float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream) {
-  VBX_REQUIRE(temb && w_bf16 && dada && dw && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");
+  VBX_REQUIRE(temb && w_bf16 && dada && dbias && dtemb && scratch && Th % 8 == 0, "vbx_adaln_proj_bwd: bad args");  // dw NULL: factor form (vbx_model.adaln_factors)
   static const int ver = getenv("VBX_ADALN_BWD") ? atoi(getenv("VBX_ADALN_BWD")) : 2;
   const dim3 grid(cdiv(Th / 4, 256), cdiv(J, ADA_WROWS) + ADA_SLICES);
   if (ver != 1 && J <= ADA_SLICES * ADA_PER_MAX)
@@ -1734,6 +1873,66 @@ extern "C" int vbx_sumsq(const float* x, long n, float* out, float* scratch, voi
   hipLaunchKernelGGL(sumsq_stage1, dim3(nb), dim3(256), 0, ST, x, n, scratch);
   VBX_LAUNCH_CHECK();
   hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, ST, scratch, nb, out);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+// sum of squares over n <= 32 ranges [lo_k, hi_k) of x (floats; multiples of 4) plus n_extra values already sitting in
+// scratch[1024 .. 1024 + n_extra) (the factor-form terms of vbx_model_sumsq_adaln_factors) -> out[0].  scratch >= 1024 + n_extra floats.
+extern "C" int vbx_sumsq_ranges(const float* x, const long* ranges /* host [2 n] */, int n, int n_extra, float* out, float* scratch,
+                                void* stream) {
+  VBX_REQUIRE(x && ranges && out && scratch && n > 0 && n <= 32 && n_extra >= 0 && ((size_t)x & 15) == 0, "vbx_sumsq_ranges: bad args");
+  SumsqRanges rg;
+  rg.n = n;
+  rg.pre[0] = 0;
+  for (int k = 0; k < n; k++) {
+    const long lo = ranges[2 * k], hi = ranges[2 * k + 1];
+    VBX_REQUIRE(lo >= 0 && hi >= lo && lo % 4 == 0 && hi % 4 == 0, "vbx_sumsq_ranges: range %d [%ld, %ld) must be 4-float aligned", k, lo, hi);
+    rg.lo[k] = lo;
+    rg.pre[k + 1] = rg.pre[k] + (hi - lo) / 4;
+  }
+  const int nb = grid_for(rg.pre[n] * 4, 1024);
+  hipLaunchKernelGGL(sumsq_ranges_stage1, dim3(nb), dim3(256), 0, ST, x, rg, scratch);
+  VBX_LAUNCH_CHECK();
+  if (n_extra > 0) {  // append the extra terms behind the block partials (stage 2 sums a contiguous run)
+    if (hipMemcpyAsync(scratch + nb, scratch + 1024, (size_t)n_extra * sizeof(float), hipMemcpyDeviceToDevice, ST) != hipSuccess) {
+      vbx_set_error("vbx_sumsq_ranges: copy of the extra terms failed");
+      return VBX_EINVAL;
+    }
+  }
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, ST, scratch, nb + n_extra, out);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+// factor-form adaLN weight gradients (see adam_adaln_factor_kernel): Adam on the L weight blocks, and their sums of squares
+extern "C" int vbx_adam_adaln_factors(float* p, float* m, float* v, const long* w_off /* host [L] */, void* const* dst_f16 /* host [L] */,
+                                      const float* dada, const float* temb, int L, int B, int J4, int Th, float lr, float beta1,
+                                      float beta2, float eps, int step, const float* gscale, void* stream) {
+  VBX_REQUIRE(p && m && v && w_off && dada && temb && L > 0 && L <= 32 && B > 0 && J4 > 0 && Th > 0 && Th % 4 == 0 && step >= 1,
+              "vbx_adam_adaln_factors: bad args");
+  AdaFactorArgs a{};
+  for (int l = 0; l < L; l++) {
+    VBX_REQUIRE(w_off[l] % 4 == 0, "vbx_adam_adaln_factors: weight offsets must be 16-byte aligned");
+    a.w_off[l] = w_off[l];
+    a.dst_f16[l] = dst_f16 ? (u16*)dst_f16[l] : nullptr;
+  }
+  a.dada = dada; a.temb = temb; a.L = L; a.B = B; a.J4 = J4; a.Th = Th;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_adaln_factor_kernel, dim3(cdiv(Th, 1024), cdiv(J4, ADAF_ROWS), L), dim3(256), 0, ST, p, m, v, a, lr / bc1,
+                     beta1, beta2, eps, sqrtf(bc2), gscale);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_adaln_expand_dw(const float* temb, const float* dada, float* dw, int B, int Th, int J4, int reserved, void* stream) {
+  (void)reserved;
+  VBX_REQUIRE(temb && dada && dw && B > 0 && Th > 0 && Th % 4 == 0 && J4 > 0, "vbx_adaln_expand_dw: bad args");
+  hipLaunchKernelGGL(adaln_expand_dw_kernel, dim3(cdiv(Th / 4, 256), cdiv(J4, ADA_WROWS)), dim3(256), 0, ST, temb, dada, dw, B, Th, J4);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vbx_sumsq_adaln_factors(const float* dada, const float* temb, int L, int B, int J4, int Th, float* out /* [L] */,
+                                       void* stream) {
+  VBX_REQUIRE(dada && temb && out && L > 0 && B > 0 && B <= 64, "vbx_sumsq_adaln_factors: bad args");
+  hipLaunchKernelGGL(adaln_factor_sumsq_kernel, dim3(L), dim3(256), 0, ST, dada, temb, out, B, J4, Th);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -923,7 +923,9 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   }
   if (m->plain_norm) return 0;
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
-  CK(vbx_adaln_proj_bwd(m->stack_only ? io->cond : a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l, Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
+  // (adaln_factors: the weight gradient dada_l^T . temb is not materialised -- include/vbx.h, vbx_adam_adaln_factors)
+  CK(vbx_adaln_proj_bwd(m->stack_only ? io->cond : a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l,
+                        m->adaln_factors ? nullptr : Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
                         a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));
   return 0;
 }
@@ -1012,7 +1014,8 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
     if (!m->plain_norm) {
-      add(o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, nullptr, d.Th, 0, 0);
+      // (factor mode: the block is served by vbx_adam_adaln_factors -- rowmap 2 marks it, it gets no blocks of the fused launch)
+      add(o[VBX_L_G1W], 4 * d.D, d.Th, nullptr, w.adah + (size_t)l * 4 * d.D * d.Th, nullptr, d.Th, m->adaln_factors ? 2 : 0, 0);
       add(o[VBX_L_G1B], 1, 4 * d.D, nullptr, nullptr, w.bada + (size_t)l * 4 * d.D, 4 * d.D, 0, 0);
     }
     add(o[VBX_L_QKVW], 3 * d.I, d.D, w.layer[l].qkv, w.layer[l].qkvh, nullptr, d.D, 0, 0);
@@ -1034,13 +1037,30 @@ extern "C" int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam
   }
   if (cur < n_flat) { vbx_adam_seg gseg{}; gseg.off = cur; gseg.count = n_flat - cur; gseg.cols = 1; all.push_back(gseg); }
   long blocks = 0;
-  for (auto& s : all) { s.block0 = blocks; blocks += (s.count + 2047) / 2048; }
+  for (auto& s : all) { s.block0 = blocks; blocks += s.rowmap == 2 ? 0 : (s.count + 2047) / 2048; }
   *total_blocks = blocks;
   if (out) {
     VBX_REQUIRE((int)all.size() <= max_segs, "vbx_model_adam_segments: table needs %d entries", (int)all.size());
     for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
   }
   return (int)all.size();
+}
+
+extern "C" int vbx_model_adaln_factors(const vbx_model* m, const float** dada, const float** temb, long* w_off, void** dst_f16) {
+  CK(check_model(m));
+  VBX_REQUIRE(m->training && !m->plain_norm && !m->stack_only, "vbx_model_adaln_factors: needs a training VoiceBox arena with adaptive norms");
+  const Dims d = dims_of(m);
+  WPack w;
+  carve_wpack(m, w);
+  Acts a;
+  carve_acts(m, a);
+  if (dada) *dada = a.dada;
+  if (temb) *temb = a.temb;
+  for (int l = 0; l < d.L; l++) {
+    if (w_off) w_off[l] = (m->off + VBX_NG + (long)l * VBX_NL)[VBX_L_G1W];
+    if (dst_f16) dst_f16[l] = w.adah + (size_t)l * 4 * d.D * d.Th;
+  }
+  return d.L;
 }
 
 extern "C" int vbx_prof_enable(int on) {

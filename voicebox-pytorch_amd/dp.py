@@ -25,12 +25,17 @@ class GradBucketReducer:
     bound) so buckets are large: whole backward stages are merged until `bucket_bytes` is reached."""
 
     def __init__(self, gflat, stage_ranges, group=None, bucket_bytes=64 << 20, comm_stream=None, comm_dtype=None, tail_bytes=16 << 20,
-                 stage_buf=None, shard=False):
+                 stage_buf=None, shard=False, skip_ranges=()):
         """shard=True: every bucket is REDUCE-SCATTERED instead of all-reduced -- rank r ends up with the sum of chunk r (1 / world
         of the bucket, in place) and `owned` lists the flat ranges this rank must clip / Adam before all-gathering the updated
         parameters (TrainStep(grad_mode="shard")): the optimizer's HBM traffic and arithmetic drop by the world size; the wire
         carries the same bytes as a ring all-reduce (whose two halves these are)."""
         self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
+        # skip_ranges: flat ranges that are NOT exchanged here -- the adaLN projection weight blocks whose gradient travels in factor
+        # form (TrainStep(adaln_grads="factors"): all-gather of dada / temb, < 1 MB per rank, instead of 201 MB of products).  A stage
+        # that contains one is exchanged as the pieces around it.
+        self.skip_ranges = sorted((int(a), int(b)) for a, b in skip_ranges)
+        self.wire_floats = 0  # floats handed to collectives by this reducer (bench.py reports the wire bytes per step)
         self.shard = bool(shard)
         self.owned = []
         # The LAST bucket cannot overlap any backward work (nothing is left to run), so it must be small: as soon as what remains
@@ -90,6 +95,7 @@ class GradBucketReducer:
         if hi <= lo:
             return
         self.buckets_launched.append((lo, hi))
+        self.wire_floats += hi - lo
         if self.shard:
             self.owned.append(self.chunk_of(lo, hi))
         if not self.active:
@@ -118,6 +124,25 @@ class GradBucketReducer:
 
     def stage_done(self, i, rng=None):
         lo, hi = rng if rng is not None else self.ranges[i]
+        if self.skip_ranges:
+            pieces, cur = [], lo
+            for a, b in self.skip_ranges:
+                if b <= lo or a >= hi:
+                    continue
+                if a > cur:
+                    pieces.append((cur, a))
+                cur = max(cur, b)
+            if cur < hi:
+                pieces.append((cur, hi))
+            for plo, phi in pieces:
+                self._piece_done(plo, phi)
+            return
+        self._piece_done(lo, hi)
+
+    def _piece_done(self, lo, hi):
+        if self.pending_lo is not None and lo != self.pending_hi and self.skip_ranges:
+            self._launch(self.pending_lo, self.pending_hi)  # a skipped block lies in between: the pending run ends here
+            self.pending_lo = None
         if self.pending_lo is None:
             self.pending_lo, self.pending_hi = lo, hi
         else:
@@ -171,6 +196,29 @@ class GradBucketReducer:
             w.wait()
 
 
+def gather_adaln_factors(dada, temb, group=None):
+    """Every rank's adaLN gradient factors -> (dada_all [L, W * B, J4], temb_all [W * B, Th], floats this rank put on the wire).
+    dada [L, B, J4], temb [B, Th] (fp32, any device the backend serves).  The gradient of layer l's adaLN weight block summed over the
+    ranks is dada_all[l]^T . temb_all -- what an all-reduce of the per-rank products dada_r[l]^T . temb_r would deliver, from
+    B * (L * J4 + Th) floats per rank instead of L * J4 * Th."""
+    L, B, J4 = dada.shape
+    Th = temb.shape[1]
+    mine = torch.cat((dada.reshape(-1), temb.reshape(-1)))
+    W = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if W > 1:
+        allf = torch.empty(W * mine.numel(), dtype=mine.dtype, device=mine.device)
+        if mine.is_cuda and dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(allf, mine, group=group)
+        else:
+            dist.all_gather(list(allf.view(W, -1).unbind(0)), mine, group=group)
+        allf = allf.view(W, -1)
+    else:
+        allf = mine.view(1, -1)
+    dada_all = allf[:, :L * B * J4].reshape(W, L, B, J4).permute(1, 0, 2, 3).reshape(L, W * B, J4).contiguous()
+    temb_all = allf[:, L * B * J4:].reshape(W * B, Th).contiguous()
+    return dada_all, temb_all, int(mine.numel())
+
+
 class WarmupCosineLR:
     """The learning-rate rule of VoiceBoxTrainer.train_step (trainer.py:231-253, scheduler built at :144-145): linear warm-up
     `initial_lr + (lr - initial_lr) * step / num_warmup_steps` while `step < num_warmup_steps`, afterwards one
@@ -204,13 +252,25 @@ class WarmupCosineLR:
 class TrainStep:
     def __init__(self, wrapper, lr=3e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=0.5, group=None,
                  bucket_bytes=64 << 20, broadcast_params=True, lr_schedule=None, grad_comm_dtype=None, wd=0., length_bucket=0,
-                 grad_mode="allreduce"):
-        """grad_mode: "allreduce" (DDP's exchange: every rank holds the summed gradient and runs the whole optimizer) or "shard"
+                 grad_mode="allreduce", adaln_grads="auto"):
+        """adaln_grads: what step() does with the gradient of the adaLN projection WEIGHTS (voicebox_pytorch.py:256-276; 49 % of the
+        parameters at dim 512 / depth 12, each layer's block a rank-B outer product dada_l^T . temb):
+          "materialize"  the backward writes it into the flat gradient buffer like every other gradient (the only form in which the
+                         gradient buffer is complete: accumulation, the autograd path and shard mode always use it);
+          "factors"      it stays in factor form.  One GPU: the global norm takes its sum of squares from B x B Gram matrices and Adam
+                         expands the product on the fly -- no 201 MB write, no two 201 MB reads per step; the adaLN weight blocks of
+                         `gflat` are then NOT written.  Several GPUs (all-reduce mode): every rank all-gathers the factors
+                         (B * (L * 4 D + Th) floats per rank, < 1 MB) instead of all-reducing the product (half of the wire), then
+                         expands the summed gradient locally into `gflat`.
+          "auto"         "factors" wherever it applies (adaptive norms, depth <= 32, all-reduce mode), unless VBX_ADALN_FACTORS=0.
+        grad_mode: "allreduce" (DDP's exchange: every rank holds the summed gradient and runs the whole optimizer) or "shard"
         (reduce-scatter the buckets, each rank clips / Adams its 1 / world of the flat buffers, all-gather the updated fp32
         parameters, repack the operand copies in one pass): same results up to the summation order of the gradient norm, the
         optimizer's 3.3 GB of HBM traffic per step divided by the world size."""
         assert grad_mode in ("allreduce", "shard"), grad_mode
+        assert adaln_grads in ("auto", "factors", "materialize"), adaln_grads
         self.grad_mode = grad_mode
+        self.adaln_grads = adaln_grads
         self.wrapper, self.vb = wrapper, wrapper.voicebox
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         # wd > 0: AdamW as get_optimizer builds it (optimizer.py:10-35): decoupled decay p *= 1 - lr * wd on the parameters with
@@ -233,7 +293,7 @@ class TrainStep:
         self.v = torch.zeros_like(flat)
         self.sumsq = torch.zeros(1, device=dev)
         self.coef = torch.zeros(2, device=dev)
-        self.scratch = torch.zeros(1024, device=dev)
+        self.scratch = torch.zeros(2048, device=dev)  # 1024 block partials + the per-layer factor terms of the gradient norm
         self.steps = 0
         self.exchange = self.world > 1 or (force_dist() and self.distributed)
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and dev.type == "cuda") else None
@@ -268,12 +328,48 @@ class TrainStep:
         self.acc_pending = True
         return loss
 
-    def _reducer(self, comm_dtype=None):
+    def adaln_factors_apply(self):
+        """True when step() keeps the adaLN weight gradients in factor form (see __init__)."""
+        if self.adaln_grads == "materialize" or self.grad_mode == "shard":
+            return False
+        if self.adaln_grads == "auto" and os.environ.get("VBX_ADALN_FACTORS", "1") == "0":
+            return False
+        c = self.vb._cfg
+        ok = not c.get("plain_norm") and not c.get("stack_only") and c["L"] <= 32 and self.fp.flat.is_cuda
+        assert ok or self.adaln_grads == "auto", "adaln_grads='factors' needs a VoiceBox with adaptive norms (depth <= 32) on a GPU"
+        return bool(ok)
+
+    def adaln_weight_ranges(self):
+        """Flat ranges [lo, hi) of every layer's adaLN projection weight block (G1W | B1W | G2W | B2W, contiguous)."""
+        fp = self.fp
+        out = []
+        for l in range(fp.depth):
+            lo = fp.offsets[f"L{l}.G1W"]
+            hi = fp.offsets[f"L{l}.B2W"] + fp.slots[f"L{l}.B2W"].numel()
+            out.append((lo, hi))
+        return sorted(out)
+
+    def _reducer(self, comm_dtype=None, skip_adaln=False):
         red = GradBucketReducer(self.gflat, self.fp.stage_ranges, group=self.group, bucket_bytes=self.bucket_bytes,
                                 comm_stream=self.comm_stream, comm_dtype=comm_dtype, stage_buf=self._stage_buf,
-                                shard=self.grad_mode == "shard" and self.exchange)
+                                shard=self.grad_mode == "shard" and self.exchange,
+                                skip_ranges=self.adaln_weight_ranges() if skip_adaln else ())
         self._red = red
         return red
+
+    def _exchange_adaln_factors(self, eng):
+        """Data-parallel exchange of the adaLN weight gradients in factor form: all-gather every rank's dada [L, B, 4 D] and temb
+        [B, Th] (one small collective), then expand the SUM over ranks, sum_r dada_r^T . temb_r = dada_all^T . temb_all, into the
+        adaLN weight blocks of the flat gradient buffer on every rank -- what the all-reduce of the products would have left there."""
+        from .engine import _rt, _check
+        _, _, woff, _, J4, Th = eng.adaln_factor_info()
+        dada, temb = eng.adaln_factor_tensors()  # views of the engine's activation arena
+        dada_all, temb_all, self.factor_wire_floats = gather_adaln_factors(dada, temb, self.group)  # (world 1 + VBX_FORCE_DIST: no-op gather)
+        st = _lib.current_stream()
+        for l in range(eng.cfg["L"]):
+            _check(_rt().vbx_adaln_expand_dw(temb_all.data_ptr(), dada_all[l].data_ptr(), self.gflat.data_ptr() + 4 * int(woff[l]),
+                                             dada_all.shape[1], Th, J4, 0, st), "vbx_adaln_expand_dw")
+        self._keep_factors = (dada_all, temb_all)  # alive until the launches have run
 
     def accumulate_last_and_apply(self, x1, weight, mask=None, cond_token_ids=None, lr=None):
         """The LAST micro-batch of an accumulation window, with the exchange overlapped with its backward (DDP leaves `no_sync`
@@ -314,7 +410,7 @@ class TrainStep:
             self._stage_buf = red.stage_buf
         self._clip_adam(self._last_eng, lr)
 
-    def _forward_backward(self, x1, mask, cond_token_ids, on_stage):
+    def _forward_backward(self, x1, mask, cond_token_ids, on_stage, adaln_factors=False):
         vb, w = self.vb, self.wrapper
         dev = self.fp.flat.device
         st = _lib.current_stream
@@ -361,7 +457,7 @@ class TrainStep:
             N = Nb
         eng = vb.engine(B, N, training=True)
         loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
-        eng.backward(self.gflat, gscale=None, on_stage=on_stage)
+        eng.backward(self.gflat, gscale=None, on_stage=on_stage, adaln_factors=adaln_factors)
         self._last_eng = eng
         return loss
 
@@ -398,8 +494,10 @@ class TrainStep:
             red.all_gather(self.m)
             red.all_gather(self.v)
 
-    def _clip_adam(self, eng, lr):
+    def _clip_adam(self, eng, lr, adaln_factors=False):
         # --- clip (global norm of the rank-averaged gradient) + Adam, all on device, no host sync
+        # adaln_factors (one GPU): the adaLN weight blocks of gflat were not written; their share of the norm and their Adam update
+        # come from the factors left in `eng`'s arena (include/vbx.h "FACTOR form")
         st = _lib.current_stream
         n = self.gflat.numel()
         if lr is None and self.lr_schedule is not None:
@@ -408,7 +506,10 @@ class TrainStep:
         red = getattr(self, "_red", None)
         if self.grad_mode == "shard" and red is not None and red.shard and red.active:
             return self._clip_adam_sharded(eng, lr, red)
-        _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
+        if adaln_factors:
+            eng.sumsq_with_adaln_factors(self.gflat, self.sumsq, self.scratch)
+        else:
+            _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
         if self._wd_params:
             with torch.no_grad():
@@ -419,8 +520,9 @@ class TrainStep:
         # Adam + refresh of the training engine's fp16/bf16 operand copies in one pass (other engines repack lazily)
         if os.environ.get("VBX_FUSED_ADAM", "1") != "0":
             eng.adam_step_packed(self.gflat, self.m, self.v, float(lr if lr is not None else self.lr), self.betas[0], self.betas[1],
-                                 self.eps, self.steps, self.coef)  # bumps the weights epoch; `eng` itself stays current
+                                 self.eps, self.steps, self.coef, adaln_factors=adaln_factors)  # bumps the weights epoch; `eng` stays current
         else:  # A/B: plain Adam, the next forward repacks every weight
+            assert not adaln_factors, "VBX_FUSED_ADAM=0 needs the materialised gradient: set VBX_ADALN_FACTORS=0 too"
             self._dirty()
             _lib.call("vbx_adam_step", self.fp.flat, self.gflat, self.m, self.v, n, float(lr if lr is not None else self.lr),
                       float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps, self.coef, st())
@@ -429,9 +531,15 @@ class TrainStep:
         """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
         Returns the (un-synchronised) local loss tensor."""
         # --- backward with overlapped gradient exchange
-        red = self._reducer(self.grad_comm_dtype)
-        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None)
+        factors = self.adaln_factors_apply() and os.environ.get("VBX_FUSED_ADAM", "1") != "0"
+        red = self._reducer(self.grad_comm_dtype, skip_adaln=factors and self.exchange)
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None, adaln_factors=factors)
+        if factors and self.exchange:  # the factors travel (one small all-gather) while the last buckets are still in flight
+            self._exchange_adaln_factors(self._last_eng)
         red.finish()
         self._stage_buf = red.stage_buf
-        self._clip_adam(self._last_eng, lr)
+        self.wire_bytes = (red.wire_floats * (2 if self.grad_comm_dtype == torch.bfloat16 else 4)
+                           + 4 * getattr(self, "factor_wire_floats", 0) * (1 if factors and self.exchange else 0)) if self.exchange else 0
+        # one GPU: clip + Adam straight from the factors; several: the expanded sum is in gflat like any other gradient
+        self._clip_adam(self._last_eng, lr, adaln_factors=factors and not self.exchange)
         return loss

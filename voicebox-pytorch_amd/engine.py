@@ -21,7 +21,7 @@ class VbxModel(C.Structure):
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
                 ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I),
-                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F)]
+                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F), ("adaln_factors", I)]
 
 
 class VbxIO(C.Structure):
@@ -88,6 +88,16 @@ def _rt():
         l.vbx_model_precise_scratch_bytes.restype = C.c_size_t
         l.vbx_model_adaln_table.argtypes = [MP, P, I, P, P]
         l.vbx_model_adaln_table.restype = I
+        l.vbx_model_adaln_factors.argtypes = [MP, C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), C.POINTER(P)]
+        l.vbx_model_adaln_factors.restype = I
+        l.vbx_sumsq_adaln_factors.argtypes = [P, P, I, I, I, I, P, P]
+        l.vbx_sumsq_adaln_factors.restype = I
+        l.vbx_sumsq_ranges.argtypes = [P, C.POINTER(C.c_long), I, I, P, P, P]
+        l.vbx_sumsq_ranges.restype = I
+        l.vbx_adam_adaln_factors.argtypes = [P, P, P, C.POINTER(C.c_long), C.POINTER(P), P, P, I, I, I, I, F, F, F, F, I, P, P]
+        l.vbx_adam_adaln_factors.restype = I
+        l.vbx_adaln_expand_dw.argtypes = [P, P, P, I, I, I, I, P]
+        l.vbx_adaln_expand_dw.restype = I
         for name, at in (("vbx_model_pack_weights", [MP, P]), ("vbx_model_pack_weights_precise", [MP, P]), ("vbx_model_forward", [MP, IP, P]),
                          ("vbx_model_backward_head", [MP, IP, P, P]), ("vbx_model_backward_layer", [MP, IP, I, P]),
                          ("vbx_model_backward_embed", [MP, IP, P])):
@@ -288,25 +298,92 @@ class Engine:
             self.packed3_version = key
 
     # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
-    def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale):
+    # -- adaLN weight gradients in factor form (include/vbx.h "FACTOR form"; dp.TrainStep decides when)
+    def supports_adaln_factors(self):
+        c = self.cfg
+        return bool(self.training and not c.get("plain_norm") and not c.get("stack_only") and c["L"] <= 32)
+
+    def adaln_factor_info(self):
+        """(dada ptr, temb ptr, [w_off], [dst_f16 ptr], J4, Th) of this arena's factor-form adaLN weight gradients."""
+        if getattr(self, "_adaln_info", None) is None:
+            L = self.cfg["L"]
+            dada, temb = P(), P()
+            woff, dst = (C.c_long * L)(), (P * L)()
+            _check(0 if _rt().vbx_model_adaln_factors(C.byref(self.m), C.byref(dada), C.byref(temb), woff, dst) == L else -1,
+                   "vbx_model_adaln_factors")
+            self._adaln_info = (dada.value, temb.value, woff, dst, 4 * self.cfg["D"], self.cfg["Th"])
+        return self._adaln_info
+
+    def adaln_factor_tensors(self):
+        """(dada [L, B, 4 D], temb [B, Th]) as fp32 views of this arena (valid between a backward and the next forward)."""
+        dada_p, temb_p, _, _, J4, Th = self.adaln_factor_info()
+        L, B = self.cfg["L"], self.B
+
+        def view(ptr, shape):
+            off, n = ptr - self.act.data_ptr(), 4
+            for d in shape:
+                n *= d
+            return self.act[off:off + n].view(torch.float32).view(*shape)
+
+        return view(dada_p, (L, B, J4)), view(temb_p, (B, Th))
+
+    def adaln_factor_ranges(self):
+        """Flat ranges [lo, hi) of the adaLN projection weight blocks (one per layer, ascending)."""
+        _, _, woff, _, J4, Th = self.adaln_factor_info()
+        return sorted((int(o), int(o) + J4 * Th) for o in woff)
+
+    def sumsq_with_adaln_factors(self, gflat, out, scratch):
+        """out[0] = sum of squares of the gradient whose adaLN weight blocks are in factor form: the flat buffer minus those blocks
+        (never written in that mode) plus |dada_l^T . temb|_F^2 per layer from the factors.  scratch: >= 1024 + L floats."""
+        l = _rt()
+        dada, temb, woff, dst, J4, Th = self.adaln_factor_info()
+        L, n = self.cfg["L"], gflat.numel()
+        st = _lib.current_stream()
+        _check(l.vbx_sumsq_adaln_factors(dada, temb, L, self.B, J4, Th, scratch.data_ptr() + 4 * 1024, st), "vbx_sumsq_adaln_factors")
+        if getattr(self, "_rest_ranges", None) is None:
+            rest, cur = [], 0
+            for lo, hi in self.adaln_factor_ranges():
+                if lo > cur:
+                    rest += [cur, lo]
+                cur = hi
+            if cur < n:
+                rest += [cur, n]
+            self._rest_ranges = ((C.c_long * len(rest))(*rest), len(rest) // 2)
+        arr, nr = self._rest_ranges
+        _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, L, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
+
+    # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
+    def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale, adaln_factors=False):
+        """adaln_factors=True: the adaLN weight blocks are updated from their factor-form gradients (the last backward ran with
+        adaln_factors) by a second launch; the fused launch leaves them out."""
         l = _rt()
         flat = self.fp.flat
         self.bind_params()  # the packed arena must be current before it is updated incrementally
-        if getattr(self, "_adam_segs", None) is None:
-            nblocks = C.c_long(0)
-            n = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), None, 0, C.byref(nblocks))
-            if n <= 0:
-                _check(n if n < 0 else -1, "vbx_model_adam_segments")
-            tab = (VbxAdamSeg * n)()
-            n2 = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), tab, n, C.byref(nblocks))
-            assert n2 == n
+        cache = self.__dict__.setdefault("_adam_segs_by_mode", {})
+        if bool(adaln_factors) not in cache:
+            self.m.adaln_factors = int(bool(adaln_factors))
+            try:
+                nblocks = C.c_long(0)
+                n = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), None, 0, C.byref(nblocks))
+                if n <= 0:
+                    _check(n if n < 0 else -1, "vbx_model_adam_segments")
+                tab = (VbxAdamSeg * n)()
+                n2 = l.vbx_model_adam_segments(C.byref(self.m), flat.numel(), tab, n, C.byref(nblocks))
+                assert n2 == n
+            finally:
+                self.m.adaln_factors = 0
             raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
-            self._adam_segs = (raw, n, nblocks.value)
-        raw, n, nblocks = self._adam_segs
+            cache[bool(adaln_factors)] = (raw, n, nblocks.value)
+        raw, n, nblocks = cache[bool(adaln_factors)]
+        gs = gscale.data_ptr() if gscale is not None else None
         _check(l.vbx_adam_step_packed(flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), raw.data_ptr(), n, nblocks,
-                                      float(lr), float(beta1), float(beta2), float(eps), int(step),
-                                      gscale.data_ptr() if gscale is not None else None, _lib.current_stream()),
+                                      float(lr), float(beta1), float(beta2), float(eps), int(step), gs, _lib.current_stream()),
                "vbx_adam_step_packed")
+        if adaln_factors:
+            dada, temb, woff, dst, J4, Th = self.adaln_factor_info()
+            _check(l.vbx_adam_adaln_factors(flat.data_ptr(), m.data_ptr(), v.data_ptr(), woff, dst, dada, temb, self.cfg["L"], self.B, J4,
+                                            Th, float(lr), float(beta1), float(beta2), float(eps), int(step), gs, _lib.current_stream()),
+                   "vbx_adam_adaln_factors")
         self.fp.bump()  # the flat buffer was written through a raw pointer: every other engine must repack
         self.packed_version = self.fp.weights_key()  # this engine's operand copies were refreshed in the same pass
 
@@ -459,8 +536,18 @@ class Engine:
         return self.act[off:off + n].view(dtype).view(*shape)
 
     # -- backward, stage by stage; `on_stage(i, (lo, hi))` fires after the gradients in flat range [lo,hi) are final
-    def backward(self, gflat, gscale=None, on_stage=None):
+    def backward(self, gflat, gscale=None, on_stage=None, adaln_factors=False):
+        """adaln_factors=True: the adaLN projection WEIGHT gradients are not written into gflat -- they stay in factor form in this
+        arena (adaln_factor_info) until the next forward; the caller's optimizer / exchange must take them from there."""
         assert self.training
+        assert not adaln_factors or self.supports_adaln_factors()
+        self.m.adaln_factors = int(bool(adaln_factors))
+        try:
+            return self._backward(gflat, gscale, on_stage)
+        finally:
+            self.m.adaln_factors = 0
+
+    def _backward(self, gflat, gscale, on_stage):
         self.m.grads = gflat.data_ptr()
         st = _lib.current_stream()
         l = _rt()
