@@ -406,14 +406,15 @@ int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
  * block W_l [J4 = 4 D, Th] (voicebox_pytorch.py:256-276: to_gamma / to_beta of the two AdaptiveRMSNorms, contiguous) is
  * dada_l^T . temb with dada_l [B, J4] and temb [B, Th] -- half of all parameters, defined by B * (J4 + Th) numbers.  In factor
  * mode the backward entry points leave that block of the gradient buffer UNWRITTEN and the optimizer works from the factors:
- *   vbx_sumsq_adaln_factors : |dada_l^T . temb|_F^2 per layer -> out[l] (two B x B Gram matrices each);
+ *   vbx_sumsq_adaln_factors : the L * B * B terms (dada_l[b] . dada_l[b']) (temb[b] . temb[b']) whose sum over (b, b') is
+ *                             |dada_l^T . temb|_F^2 -> out[(l * B + b) * B + b'];
  *   vbx_sumsq_ranges        : sum of squares over n <= 32 ranges [lo, hi) of x (host array of 2 n longs, multiples of 4 floats)
  *                             plus n_extra values already stored at scratch[1024 ..) -> out[0]; scratch >= 1024 + n_extra floats;
  *   vbx_adam_adaln_factors  : torch.optim.Adam (as vbx_adam_step) on the L blocks at flat offsets w_off[l] with the gradient
  *                             expanded on the fly, refreshing the fp16 operand copies dst_f16[l] ([J4][Th]; may be NULL).
  * vbx_model_adaln_factors gives the factor pointers and the block offsets of a model's training arena. */
 int vbx_sumsq_adaln_factors(const float* dada /* [L][B][J4] */, const float* temb /* [B][Th] */, int L, int B, int J4, int Th,
-                            float* out /* [L] */, void* stream);
+                            float* out /* [L * B * B] */, void* stream);
 /* dw [J4, Th] = dada^T . temb for any B (the data-parallel exchange gathers every rank's factors and expands the summed gradient
  * locally: dp.GradBucketReducer(adaln_factors=...)) */
 int vbx_adaln_expand_dw(const float* temb /* [B][Th] */, const float* dada /* [B][J4] */, float* dw, int B, int Th, int J4, int reserved,

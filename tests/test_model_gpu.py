@@ -34,6 +34,7 @@ dev = "cuda"
 INIT_RMS_SMALL = 1.4e-3   # dim 64, depth 2, N ~ 100
 INIT_RMS_D12 = 4.0e-3     # dim 512 / 1024, depth 12, N = 1024
 FOUR_SIGMA_SMALL, FOUR_SIGMA_D12 = 4 * INIT_RMS_SMALL, 4 * INIT_RMS_D12
+EMU_RMS_SMALL = 3.0e-4    # dim 64: rms of (fast path - CPU oracle with the SAME operand roundings emulated), 48 seeds (asserted below)
 
 
 def rel(got, ref):
@@ -138,7 +139,9 @@ def test_small_golden_loss_and_grads(golden):
         assert worst0 < REF_GRAD_CLASS0 and worst1 < REF_GRAD_CLASS1, (worst0, worst1)
         # gradients vs the emulated-precision oracle: every tensor, bf16-GEMM tolerance
         eloss, egrads = emulated_oracle_grads(cfg, g["state"], g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask)
-        assert abs(float(loss) - eloss) < 2e-4, (float(loss), eloss)
+        # (the emulation rounds the operands like the kernels but not in their accumulation order / P rounding mode: at this chaotic
+        #  init those last-bit differences are amplified too -- 48 seeds: test_small_reference_init_loss_statistics reports the RMS)
+        assert abs(float(loss) - eloss) < 4 * EMU_RMS_SMALL, (float(loss), eloss)
         errs = {k: rel(named[k].grad, ref) for k, ref in egrads.items()}
         worst = sorted(errs.items(), key=lambda kv: -kv[1])
         print("relative grad errors vs emulated oracle", mask_key, [(k, round(v, 4)) for k, v in worst[:8]])
@@ -956,7 +959,7 @@ def test_small_reference_init_loss_statistics():
     from voicebox_pytorch_amd.masks import rng_override
 
     cfg = restate.Cfg(dim=64, depth=2, heads=2, dim_head=64)
-    ds = []
+    ds, es = [], []
     for s_ in range(48):
         state = restate.init_state_dict(cfg, seed=50 + s_)
         _, vb, wrapper = build(dict(dim=64, depth=2, heads=2), state)
@@ -965,11 +968,18 @@ def test_small_reference_init_loss_statistics():
         times, frac, rand = torch.rand(2, generator=gen), 0.7 + 0.3 * torch.rand(2, generator=gen), torch.rand(2, generator=gen)
         with torch.no_grad():
             ref = float(restate.cfm_loss(state, cfg, x1, x0, times, frac, rand))
+            with restate.emulate_fp16_operands():
+                emu = float(restate.cfm_loss(state, cfg, x1, x0, times, frac, rand))
             with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
-                ds.append(float(wrapper(x1.to(dev))) - ref)
+                got = float(wrapper(x1.to(dev)))
+        ds.append(got - ref)
+        es.append(got - emu)
     m, r, x = _stats(ds)
+    em, er, ex = _stats(es)
     print(f"dim-64 reference init, 48 seeds: fast path - fp32 oracle: mean|d| {m:.2e} rms {r:.2e} max {x:.2e}", [round(d, 5) for d in ds[:12]])
+    print(f"   fast path - oracle with the same operand roundings emulated: mean|d| {em:.2e} rms {er:.2e} max {ex:.2e}")
     assert m <= INIT_RMS_SMALL and r <= 1.25 * INIT_RMS_SMALL and x <= 5 * INIT_RMS_SMALL, (m, r, x)
+    assert er <= 1.25 * EMU_RMS_SMALL and ex <= 5 * EMU_RMS_SMALL, (em, er, ex)
 
 
 def test_cfg3_dim1024_depth12_vs_reference(golden):

@@ -1296,42 +1296,54 @@ __global__ __launch_bounds__(256) void adaln_expand_dw_kernel(const float* __res
       if (j0 + r < J) *reinterpret_cast<float4*>(dw + (long)(j0 + r) * Th + (long)t4 * 4) = s[r];
   }
 }
-// |dada_l^T . temb|_F^2 = sum_{b,b'} (dada_l[b] . dada_l[b']) (temb[b] . temb[b'])  ->  out[l]   (one block per layer, B <= 16)
+// |dada_l^T . temb|_F^2 = sum_{b,b'} (dada_l[b] . dada_l[b']) (temb[b] . temb[b'])  ->  out[l * B * B + b * B + b'] (one term per
+// block: 12 x 64 blocks at the benchmark shape; the first version -- one block per layer walking its 36 pairs -- took 114 us)
 __global__ __launch_bounds__(256) void adaln_factor_sumsq_kernel(const float* __restrict__ dada, const float* __restrict__ temb,
                                                                  float* __restrict__ out, int B, int J4, int Th) {
-  __shared__ float red[4];
-  const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[8];
+  const int l = blockIdx.y, b = blockIdx.x / B, bp = blockIdx.x - b * B;
   const float* da = dada + (long)l * B * J4;
-  float tot = 0.f;
-  for (int pair = wave; pair < B * B; pair += 4) {  // wave-uniform pair (b, b'), b <= b' counted twice off the diagonal
-    const int b = pair / B, bp = pair - b * B;
-    if (bp < b) continue;
-    float g1 = 0.f, g2 = 0.f;
-    for (int j = lane; j < J4; j += 64) g1 += da[(long)b * J4 + j] * da[(long)bp * J4 + j];
-    for (int t = lane; t < Th; t += 64) g2 += temb[(long)b * Th + t] * temb[(long)bp * Th + t];
-    g1 = wave_sum(g1);
-    g2 = wave_sum(g2);
-    tot += (bp == b ? 1.0f : 2.0f) * g1 * g2;
-  }
-  if (lane == 0) red[wave] = tot;
+  float g1 = 0.f, g2 = 0.f;
+  for (int j = threadIdx.x; j < J4; j += 256) g1 += da[(long)b * J4 + j] * da[(long)bp * J4 + j];
+  for (int t = threadIdx.x; t < Th; t += 256) g2 += temb[(long)b * Th + t] * temb[(long)bp * Th + t];
+  g1 = wave_sum(g1);
+  g2 = wave_sum(g2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave] = g1; red[4 + wave] = g2; }
   __syncthreads();
-  if (threadIdx.x == 0) out[l] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0)
+    out[((long)l * B + b) * B + bp] = (red[0] + red[1] + red[2] + red[3]) * (red[4] + red[5] + red[6] + red[7]);
 }
 // sum of squares over up to 32 ranges [lo, hi) of a flat buffer (every lo / hi a multiple of 4 floats, 16-byte aligned base):
 // the flat gradient buffer minus the adaLN weight blocks that stay in factor form
 struct SumsqRanges { long lo[32], pre[33]; int n; };  // pre[k] = float4 count of ranges 0..k-1
 __global__ __launch_bounds__(256) void sumsq_ranges_stage1(const float* __restrict__ x, const SumsqRanges rg, float* __restrict__ scratch) {
+  // the virtual concatenation of the ranges is cut into gridDim.x contiguous chunks; the table sits in LDS (indexing a kernel-argument
+  // array by a run-time value made the first version walk scratch memory: 79 us for 209 MB)
+  __shared__ long slo[32], spre[33];
   __shared__ float red[4];
+  if (threadIdx.x < 32) slo[threadIdx.x] = rg.lo[threadIdx.x];
+  if (threadIdx.x < 33) spre[threadIdx.x] = rg.pre[threadIdx.x];
+  __syncthreads();
+  const int n = rg.n;
+  const long n4 = spre[n];
+  const long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long c0 = blockIdx.x * per, c1 = min(n4, c0 + per);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const long n4 = rg.pre[rg.n];
   int kr = 0;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    while (i >= rg.pre[kr + 1]) kr++;  // the virtual index only grows
-    const float4 vv = *reinterpret_cast<const float4*>(x + rg.lo[kr] + (i - rg.pre[kr]) * 4);
-    s0 = fmaf(vv.x, vv.x, s0); s1 = fmaf(vv.y, vv.y, s1); s2 = fmaf(vv.z, vv.z, s2); s3 = fmaf(vv.w, vv.w, s3);
+  while (kr + 1 < n && c0 >= spre[kr + 1]) kr++;
+  long i = c0 + threadIdx.x;
+  while (i < c1) {
+    while (i >= spre[kr + 1]) kr++;  // the index only grows
+    const long seg_end = min(c1, spre[kr + 1]);
+    const float4* base = reinterpret_cast<const float4*>(x + slo[kr]) - spre[kr];
+    for (; i < seg_end; i += 256) {
+      const float4 vv = base[i];
+      s0 = fmaf(vv.x, vv.x, s0); s1 = fmaf(vv.y, vv.y, s1); s2 = fmaf(vv.z, vv.z, s2); s3 = fmaf(vv.w, vv.w, s3);
+    }
   }
-  float s = wave_sum((s0 + s1) + (s2 + s3));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  float sm = wave_sum((s0 + s1) + (s2 + s3));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
   __syncthreads();
   if (threadIdx.x == 0) scratch[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
@@ -1929,10 +1941,10 @@ extern "C" int vbx_adaln_expand_dw(const float* temb, const float* dada, float* 
   VBX_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int vbx_sumsq_adaln_factors(const float* dada, const float* temb, int L, int B, int J4, int Th, float* out /* [L] */,
+extern "C" int vbx_sumsq_adaln_factors(const float* dada, const float* temb, int L, int B, int J4, int Th, float* out /* [L * B * B] */,
                                        void* stream) {
   VBX_REQUIRE(dada && temb && out && L > 0 && B > 0 && B <= 64, "vbx_sumsq_adaln_factors: bad args");
-  hipLaunchKernelGGL(adaln_factor_sumsq_kernel, dim3(L), dim3(256), 0, ST, dada, temb, out, B, J4, Th);
+  hipLaunchKernelGGL(adaln_factor_sumsq_kernel, dim3(B * B, L), dim3(256), 0, ST, dada, temb, out, B, J4, Th);
   VBX_LAUNCH_CHECK();
   return 0;
 }

@@ -293,7 +293,7 @@ class TrainStep:
         self.v = torch.zeros_like(flat)
         self.sumsq = torch.zeros(1, device=dev)
         self.coef = torch.zeros(2, device=dev)
-        self.scratch = torch.zeros(2048, device=dev)  # 1024 block partials + the per-layer factor terms of the gradient norm
+        self.scratch = torch.zeros(1024 + 32 * 64 * 64, device=dev)  # 1024 block partials + the L * B * B factor terms of the gradient norm
         self.steps = 0
         self.exchange = self.world > 1 or (force_dist() and self.distributed)
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and dev.type == "cuda") else None

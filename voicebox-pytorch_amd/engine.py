@@ -334,11 +334,13 @@ class Engine:
 
     def sumsq_with_adaln_factors(self, gflat, out, scratch):
         """out[0] = sum of squares of the gradient whose adaLN weight blocks are in factor form: the flat buffer minus those blocks
-        (never written in that mode) plus |dada_l^T . temb|_F^2 per layer from the factors.  scratch: >= 1024 + L floats."""
+        (never written in that mode) plus |dada_l^T . temb|_F^2 per layer from the factors.  scratch: >= 1024 + L * B * B floats."""
         l = _rt()
         dada, temb, woff, dst, J4, Th = self.adaln_factor_info()
         L, n = self.cfg["L"], gflat.numel()
         st = _lib.current_stream()
+        nterms = L * self.B * self.B  # (dada_l[b] . dada_l[b']) (temb[b] . temb[b']) for every (l, b, b')
+        assert scratch.numel() >= 1024 + nterms, "sumsq scratch too small for the factor terms"
         _check(l.vbx_sumsq_adaln_factors(dada, temb, L, self.B, J4, Th, scratch.data_ptr() + 4 * 1024, st), "vbx_sumsq_adaln_factors")
         if getattr(self, "_rest_ranges", None) is None:
             rest, cur = [], 0
@@ -350,7 +352,7 @@ class Engine:
                 rest += [cur, n]
             self._rest_ranges = ((C.c_long * len(rest))(*rest), len(rest) // 2)
         arr, nr = self._rest_ranges
-        _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, L, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
+        _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, nterms, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
 
     # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
     def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale, adaln_factors=False):
