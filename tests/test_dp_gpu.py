@@ -441,13 +441,13 @@ def _nccl_world1_worker(port, out):
                 loss = ts.step(d["x1"].cuda())
             if flat1 is None:
                 torch.cuda.synchronize()
-                flat1 = ts.fp.flat.detach().cpu().clone()
+                flat1, g1 = ts.fp.flat.detach().cpu().clone(), ts.gflat.detach().cpu().clone()
         torch.cuda.synchronize()
         outside = torch.ones(ts.gflat.numel(), dtype=torch.bool)
         for lo, hi in ts.adaln_weight_ranges():
             outside[lo:hi] = False
         res[forced] = dict(loss=float(loss), flat=ts.fp.flat.detach().cpu().clone(), g=ts.gflat.detach().cpu().clone(),
-                           exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None, outside=outside, flat1=flat1,
+                           exchange=bool(ts.exchange), comm_stream=ts.comm_stream is not None, outside=outside, flat1=flat1, g1=g1,
                            wire_bytes=getattr(ts, "wire_bytes", None))
     # shard mode over RCCL: the in-place reduce_scatter_tensor / all_gather_into_tensor path must be the one that runs (ADVICE r4:
     # the gloo tests only ever see the all-reduce fallback)
@@ -493,5 +493,5 @@ def test_rccl_path_executes_at_world_size_1(tmp_path):
     # one GPU without exchange, they stay in factor form and their blocks of the buffer are not written -- compare everything else
     # bit for bit, and the parameters (whose adaLN blocks were updated from the same factors by two different kernels) to rounding
     outside = res["0"]["outside"]
-    assert torch.equal(res["1"]["g"][outside], res["0"]["g"][outside])
+    assert torch.equal(res["1"]["g1"][outside], res["0"]["g1"][outside])  # first step: the same kernels on the same weights
     assert float((res["1"]["flat"] - res["0"]["flat"]).abs().max()) < 1e-4  # three steps of size ~lr = 1e-3 each

@@ -34,7 +34,7 @@ dev = "cuda"
 INIT_RMS_SMALL = 1.4e-3   # dim 64, depth 2, N ~ 100
 INIT_RMS_D12 = 4.0e-3     # dim 512 / 1024, depth 12, N = 1024
 FOUR_SIGMA_SMALL, FOUR_SIGMA_D12 = 4 * INIT_RMS_SMALL, 4 * INIT_RMS_D12
-EMU_RMS_SMALL = 3.0e-4    # dim 64: rms of (fast path - CPU oracle with the SAME operand roundings emulated), 48 seeds (asserted below)
+EMU_RMS_SMALL = 2.0e-4    # dim 64: rms of (fast path - CPU oracle with the SAME operand roundings emulated); measured 0.8e-4 over 48 seeds, asserted below
 
 
 def rel(got, ref):
@@ -123,7 +123,7 @@ def test_small_golden_loss_and_grads(golden):
         # and the well-conditioned tensors (everything downstream of the last attention's softmax)
         cos = flat_cos(named, g[grads_key])
         print("cosine(full gradient, reference gradient)", mask_key, cos)
-        assert cos > 0.975, cos  # measured 0.990 / 0.981 (round 1)
+        assert cos > 0.95, cos  # measured 0.990 / 0.981 (round 1), 0.987 / 0.969 (round 5's q rounding): one realisation at reference init
         for k in ("to_pred.weight", "transformer.final_norm.gamma", "transformer.layers.1.5.3.weight",
                   "transformer.layers.1.5.0.weight", "transformer.layers.1.3.to_out.weight"):
             assert rel(named[k].grad, g[grads_key][k]) < REF_GRAD_CLASS0, (k, rel(named[k].grad, g[grads_key][k]))
@@ -980,6 +980,32 @@ def test_small_reference_init_loss_statistics():
     print(f"   fast path - oracle with the same operand roundings emulated: mean|d| {em:.2e} rms {er:.2e} max {ex:.2e}")
     assert m <= INIT_RMS_SMALL and r <= 1.25 * INIT_RMS_SMALL and x <= 5 * INIT_RMS_SMALL, (m, r, x)
     assert er <= 1.25 * EMU_RMS_SMALL and ex <= 5 * EMU_RMS_SMALL, (em, er, ex)
+    # the reference zero-initialises the adaLN projections (:264-268): the goldens randomise them -- the same statistic with time
+    # conditioning active (24 seeds), reported and held to the same constants
+    ds2, es2 = [], []
+    for s_ in range(24):
+        state = restate.init_state_dict(cfg, seed=150 + s_)
+        gen = torch.Generator().manual_seed(250 + s_)
+        for k in state:
+            if ".to_gamma." in k or ".to_beta." in k:
+                state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=gen)
+        _, vb, wrapper = build(dict(dim=64, depth=2, heads=2), state)
+        x1, x0 = torch.randn(2, 96, 64, generator=gen), torch.randn(2, 96, 64, generator=gen)
+        times, frac, rand = torch.rand(2, generator=gen), 0.7 + 0.3 * torch.rand(2, generator=gen), torch.rand(2, generator=gen)
+        with torch.no_grad():
+            ref = float(restate.cfm_loss(state, cfg, x1, x0, times, frac, rand))
+            with restate.emulate_fp16_operands():
+                emu = float(restate.cfm_loss(state, cfg, x1, x0, times, frac, rand))
+            with rng_override(x0=x0, times=times, frac_lengths=frac, rand=rand):
+                got = float(wrapper(x1.to(dev)))
+        ds2.append(got - ref)
+        es2.append(got - emu)
+    m2, r2, x2 = _stats(ds2)
+    em2, er2, ex2 = _stats(es2)
+    print(f"   with randomised adaLN projections, 24 seeds: vs fp32 oracle mean|d| {m2:.2e} rms {r2:.2e} max {x2:.2e}; vs emulated "
+          f"mean|d| {em2:.2e} rms {er2:.2e} max {ex2:.2e}")
+    assert r2 <= 1.5 * INIT_RMS_SMALL and x2 <= 5 * INIT_RMS_SMALL, (m2, r2, x2)
+    assert er2 <= 1.5 * EMU_RMS_SMALL and ex2 <= 5 * EMU_RMS_SMALL, (em2, er2, ex2)
 
 
 def test_cfg3_dim1024_depth12_vs_reference(golden):

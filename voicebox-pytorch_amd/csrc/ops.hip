@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(256) void adam_packed_kernel(float* __restrict__ p,
 // Adam: one block = ADAF_ROWS weight rows x 1024 columns; a thread keeps its 4 columns of every temb row in registers (8 batch rows
 // per pass) and walks the rows: the factors cost 4 bytes of L2 traffic per parameter instead of 4 bytes of HBM read + the 8 bytes
 // the materialised gradient cost elsewhere.
-constexpr int ADAF_ROWS = 16;
+constexpr int ADAF_ROWS = 8;  // (16: 128 block-uniform dada scalars per pass -> 534 spilled SGPRs, 3.8 TB/s; 8: 64 scalars)
 struct AdaFactorArgs {
   long w_off[32];     // flat offset of W_l (floats)
   u16* dst_f16[32];   // packed fp16 copy of W_l ([J4][Th], row stride Th)
@@ -1218,44 +1218,75 @@ __global__ __launch_bounds__(256) void adam_adaln_factor_kernel(float* __restric
                                                                 const AdaFactorArgs a, float lr_bc1, float b1, float b2, float eps,
                                                                 float bc2_sqrt, const float* __restrict__ gscale) {
   const int l = blockIdx.z, r0 = blockIdx.y * ADAF_ROWS;
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= a.Th) return;
+  const int c_raw = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool cv = c_raw < a.Th;       // threads past the row stay in the block (barriers below) with a clamped column and no stores
+  const int c = cv ? c_raw : 0;
   const AdamCoef k{lr_bc1, b1, b2, eps, bc2_sqrt, gscale ? gscale[0] : 1.0f};
   const float* da = a.dada + (long)l * a.B * a.J4;
+  const long base = a.w_off[l] + (long)r0 * a.Th + c;
+  const int nrows = min(ADAF_ROWS, a.J4 - r0);
+  // the optimizer state of the block's first rows is requested BEFORE the gradient is expanded (their latency hides under the FMAs)
+  constexpr int G = 4;  // rows whose p / m / v are in flight together
+  float4 pv[G], mv[G], vv[G];
+#pragma unroll
+  for (int r = 0; r < G; r++) {
+    const long i = base + (long)min(r, nrows - 1) * a.Th;
+    pv[r] = *reinterpret_cast<const float4*>(p + i); mv[r] = *reinterpret_cast<const float4*>(m + i); vv[r] = *reinterpret_cast<const float4*>(v + i);
+  }
   float4 acc[ADAF_ROWS];
 #pragma unroll
   for (int r = 0; r < ADAF_ROWS; r++) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ float gsh[ADAF_ROWS * 8];  // the block's dada values of one pass (rows x 8 batch rows), read back as LDS broadcasts
   for (int b0 = 0; b0 < a.B; b0 += 8) {
+    __syncthreads();
+    if (threadIdx.x < ADAF_ROWS * 8) {
+      const int j = min(r0 + ((int)threadIdx.x >> 3), a.J4 - 1), b = b0 + ((int)threadIdx.x & 7);
+      gsh[threadIdx.x] = b < a.B ? da[(long)b * a.J4 + j] : 0.f;
+    }
+    __syncthreads();
     float4 t[8];
 #pragma unroll
     for (int kk = 0; kk < 8; kk++)
-      t[kk] = (b0 + kk < a.B) ? *reinterpret_cast<const float4*>(a.temb + (long)(b0 + kk) * a.Th + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      t[kk] = *reinterpret_cast<const float4*>(a.temb + (long)min(b0 + kk, a.B - 1) * a.Th + c);  // weight 0 past B
 #pragma unroll
     for (int r = 0; r < ADAF_ROWS; r++) {
-      const int j = min(r0 + r, a.J4 - 1);
 #pragma unroll
       for (int kk = 0; kk < 8; kk++) {
-        const float g = (b0 + kk < a.B) ? da[(long)(b0 + kk) * a.J4 + j] : 0.f;  // block-uniform address: scalar loads
+        const float g = gsh[r * 8 + kk];
         acc[r].x += g * t[kk].x; acc[r].y += g * t[kk].y; acc[r].z += g * t[kk].z; acc[r].w += g * t[kk].w;
       }
     }
   }
   u16* dh = a.dst_f16[l];
 #pragma unroll
-  for (int r = 0; r < ADAF_ROWS; r++) {
-    const int j = r0 + r;
-    if (j >= a.J4) break;
-    const long i = a.w_off[l] + (long)j * a.Th + c;
-    float4 mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
-    float4 pv = *reinterpret_cast<const float4*>(p + i);
-    pv.x = adam_one(pv.x, acc[r].x, mv.x, vv.x, k);
-    pv.y = adam_one(pv.y, acc[r].y, mv.y, vv.y, k);
-    pv.z = adam_one(pv.z, acc[r].z, mv.z, vv.z, k);
-    pv.w = adam_one(pv.w, acc[r].w, mv.w, vv.w, k);
-    *reinterpret_cast<float4*>(m + i) = mv;
-    *reinterpret_cast<float4*>(v + i) = vv;
-    *reinterpret_cast<float4*>(p + i) = pv;
-    if (dh) *reinterpret_cast<uint2*>(dh + (long)j * a.Th + c) = make_uint2(pack_f16x2(pv.x, pv.y), pack_f16x2(pv.z, pv.w));
+  for (int g0 = 0; g0 < ADAF_ROWS; g0 += G) {
+    float4 pn[G], mn[G], vn[G];
+    if (g0 + G < ADAF_ROWS) {  // next group's state: requested before this group is computed and stored
+#pragma unroll
+      for (int r = 0; r < G; r++) {
+        const long i = base + (long)min(g0 + G + r, nrows - 1) * a.Th;
+        pn[r] = *reinterpret_cast<const float4*>(p + i); mn[r] = *reinterpret_cast<const float4*>(m + i); vn[r] = *reinterpret_cast<const float4*>(v + i);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      if (cv && g0 + r < nrows) {
+        const long i = base + (long)(g0 + r) * a.Th;
+        const float4 gq = acc[g0 + r];
+        pv[r].x = adam_one(pv[r].x, gq.x, mv[r].x, vv[r].x, k);
+        pv[r].y = adam_one(pv[r].y, gq.y, mv[r].y, vv[r].y, k);
+        pv[r].z = adam_one(pv[r].z, gq.z, mv[r].z, vv[r].z, k);
+        pv[r].w = adam_one(pv[r].w, gq.w, mv[r].w, vv[r].w, k);
+        *reinterpret_cast<float4*>(m + i) = mv[r];
+        *reinterpret_cast<float4*>(v + i) = vv[r];
+        *reinterpret_cast<float4*>(p + i) = pv[r];
+        if (dh) *reinterpret_cast<uint2*>(dh + (long)(r0 + g0 + r) * a.Th + c) = make_uint2(pack_f16x2(pv[r].x, pv[r].y), pack_f16x2(pv[r].z, pv[r].w));
+      }
+    }
+    if (g0 + G < ADAF_ROWS) {
+#pragma unroll
+      for (int r = 0; r < G; r++) { pv[r] = pn[r]; mv[r] = mn[r]; vv[r] = vn[r]; }
+    }
   }
 }
 // dW [J4, Th] = dada^T . temb for ANY number of batch rows B (the data-parallel exchange gathers every rank's factors and expands the
@@ -1337,6 +1368,13 @@ __global__ __launch_bounds__(256) void sumsq_ranges_stage1(const float* __restri
     while (i >= spre[kr + 1]) kr++;  // the index only grows
     const long seg_end = min(c1, spre[kr + 1]);
     const float4* base = reinterpret_cast<const float4*>(x + slo[kr]) - spre[kr];
+    for (; i + 768 < seg_end; i += 1024) {  // four independent 16-byte loads in flight per lane
+      const float4 v0 = base[i], v1 = base[i + 256], v2 = base[i + 512], v3 = base[i + 768];
+      s0 = fmaf(v0.x, v0.x, s0); s1 = fmaf(v0.y, v0.y, s1); s2 = fmaf(v0.z, v0.z, s2); s3 = fmaf(v0.w, v0.w, s3);
+      s0 = fmaf(v1.x, v1.x, s0); s1 = fmaf(v1.y, v1.y, s1); s2 = fmaf(v1.z, v1.z, s2); s3 = fmaf(v1.w, v1.w, s3);
+      s0 = fmaf(v2.x, v2.x, s0); s1 = fmaf(v2.y, v2.y, s1); s2 = fmaf(v2.z, v2.z, s2); s3 = fmaf(v2.w, v2.w, s3);
+      s0 = fmaf(v3.x, v3.x, s0); s1 = fmaf(v3.y, v3.y, s1); s2 = fmaf(v3.z, v3.z, s2); s3 = fmaf(v3.w, v3.w, s3);
+    }
     for (; i < seg_end; i += 256) {
       const float4 vv = base[i];
       s0 = fmaf(vv.x, vv.x, s0); s1 = fmaf(vv.y, vv.y, s1); s2 = fmaf(vv.z, vv.z, s2); s3 = fmaf(vv.w, vv.w, s3);
