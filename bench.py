@@ -152,7 +152,7 @@ def isolated_gemm_us(args, dev, which):
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the COMMITTED PMC passes of this command (tools/pmc_summary.py) -- a
     constant read from profiles/, not measured in this run: returns (bytes, source file)."""
-    for name in ("r04_train_pmc.json", "r03_train_pmc.json", "r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
+    for name in ("r05_train_pmc.json", "r04_train_pmc.json", "r03_train_pmc.json", "r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue

@@ -34,7 +34,7 @@ dev = "cuda"
 INIT_RMS_SMALL = 1.4e-3   # dim 64, depth 2, N ~ 100
 INIT_RMS_D12 = 4.0e-3     # dim 512 / 1024, depth 12, N = 1024
 FOUR_SIGMA_SMALL, FOUR_SIGMA_D12 = 4 * INIT_RMS_SMALL, 4 * INIT_RMS_D12
-EMU_RMS_SMALL = 2.0e-4    # dim 64: rms of (fast path - CPU oracle with the SAME operand roundings emulated); measured 0.8e-4 over 48 seeds, asserted below
+EMU_RMS_SMALL = 1.0e-4    # dim 64: rms of (fast path - fp32 CPU oracle with the SAME operand roundings emulated): measured 0.82e-4 / 0.85e-4
 
 
 def rel(got, ref):
@@ -79,7 +79,13 @@ def emulated_oracle_grads(cfg, state, x1, x0, times, frac, rand, mask=None):
     with restate.emulate_fp16_operands():
         loss = restate.cfm_loss(p, cfg, x1.double(), x0.double(), times.double(), frac, rand, mask=mask)
     loss.backward()
-    return float(loss), {k: v.grad for k, v in p.items() if v.grad is not None}
+    # The LOSS the kernels are held to is the emulation in fp32 -- the arithmetic the kernels accumulate in: at a chaotic (reference-init)
+    # point the fp64 and fp32 emulations of the same roundings already differ by 4e-4 on the dim-64 golden (an operand that lands within
+    # an fp32 ulp of an fp16 rounding boundary rounds differently), while the kernels sit within 5e-5 of the fp32 one.  Gradients: fp64.
+    with torch.no_grad(), restate.emulate_fp16_operands():
+        loss32 = restate.cfm_loss({k: v.float() if v.is_floating_point() else v for k, v in state.items()}, cfg, x1.float(), x0.float(),
+                                  times.float(), frac, rand, mask=mask)
+    return float(loss32), {k: v.grad for k, v in p.items() if v.grad is not None}
 
 
 # Per-tensor relative error of the random-init dim-64 golden's gradients against the unmodified reference's, by how many
@@ -139,9 +145,8 @@ def test_small_golden_loss_and_grads(golden):
         assert worst0 < REF_GRAD_CLASS0 and worst1 < REF_GRAD_CLASS1, (worst0, worst1)
         # gradients vs the emulated-precision oracle: every tensor, bf16-GEMM tolerance
         eloss, egrads = emulated_oracle_grads(cfg, g["state"], g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask)
-        # (the emulation rounds the operands like the kernels but not in their accumulation order / P rounding mode: at this chaotic
-        #  init those last-bit differences are amplified too -- 48 seeds: test_small_reference_init_loss_statistics reports the RMS)
-        assert abs(float(loss) - eloss) < 4 * EMU_RMS_SMALL, (float(loss), eloss)
+        # (48 + 24 seeds of this statistic: test_small_reference_init_loss_statistics -- rms 0.8e-4, max 2.7e-4)
+        assert abs(float(loss) - eloss) < 2e-4, (float(loss), eloss)
         errs = {k: rel(named[k].grad, ref) for k, ref in egrads.items()}
         worst = sorted(errs.items(), key=lambda kv: -kv[1])
         print("relative grad errors vs emulated oracle", mask_key, [(k, round(v, 4)) for k, v in worst[:8]])
@@ -979,7 +984,7 @@ def test_small_reference_init_loss_statistics():
     print(f"dim-64 reference init, 48 seeds: fast path - fp32 oracle: mean|d| {m:.2e} rms {r:.2e} max {x:.2e}", [round(d, 5) for d in ds[:12]])
     print(f"   fast path - oracle with the same operand roundings emulated: mean|d| {em:.2e} rms {er:.2e} max {ex:.2e}")
     assert m <= INIT_RMS_SMALL and r <= 1.25 * INIT_RMS_SMALL and x <= 5 * INIT_RMS_SMALL, (m, r, x)
-    assert er <= 1.25 * EMU_RMS_SMALL and ex <= 5 * EMU_RMS_SMALL, (em, er, ex)
+    assert er <= 1.25 * EMU_RMS_SMALL and ex <= 4e-4, (em, er, ex)
     # the reference zero-initialises the adaLN projections (:264-268): the goldens randomise them -- the same statistic with time
     # conditioning active (24 seeds), reported and held to the same constants
     ds2, es2 = [], []
@@ -1005,7 +1010,7 @@ def test_small_reference_init_loss_statistics():
     print(f"   with randomised adaLN projections, 24 seeds: vs fp32 oracle mean|d| {m2:.2e} rms {r2:.2e} max {x2:.2e}; vs emulated "
           f"mean|d| {em2:.2e} rms {er2:.2e} max {ex2:.2e}")
     assert r2 <= 1.5 * INIT_RMS_SMALL and x2 <= 5 * INIT_RMS_SMALL, (m2, r2, x2)
-    assert er2 <= 1.5 * EMU_RMS_SMALL and ex2 <= 5 * EMU_RMS_SMALL, (em2, er2, ex2)
+    assert er2 <= 1.5 * EMU_RMS_SMALL and ex2 <= 4e-4, (em2, er2, ex2)
 
 
 def test_cfg3_dim1024_depth12_vs_reference(golden):

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT; O=gpurun_out/r5i; mkdir -p $O
+cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT; O=gpurun_out/r5j; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q -s > $O/suite.log 2>&1; grep -n "passed\|failed\|^FAILED" $O/suite.log | tail -20
 timeout 600 python bench.py --no-cpu-baseline --no-sample > $O/bench_factors.json 2> $O/bench_factors.err

@@ -2,10 +2,10 @@
 # Round-end verification + measurement bundle (GPU box): full GPU test suite, smoke, the default bench line (train + sample leg +
 # CPU baseline), the sample-mode and dim-1024 bench lines, then the rocprofv3 bundle (kernel stats of train step and sample, three
 # PMC passes) -> gpurun_out/<tag>/<tag>_*; the summaries are copied into profiles/ afterwards.
-#   usage: gpurun --timeout 1800 -- 'bash tools/round_bundle.sh r04'
-T=${1:-r04}
+#   usage: gpurun --timeout 2400 -- 'bash tools/round_bundle.sh r05'
+T=${1:-r05}
 cd $GRAFT_REPO_ROOT; O=gpurun_out/$T; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 600 python bench.py > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log > $O/${T}_bench_train.json; tail -c 700 $O/${T}_bench_train.json
 timeout 300 python bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_sample.json
@@ -32,4 +32,4 @@ python tools/prof_summary.py $(find $O/prof_sample -name "*.db" | head -1) 18 > 
 python tools/pmc_summary.py $O/${T}_train_pmc.json $O/pmc_fetch $O/pmc_write $O/pmc_mfma > $O/${T}_train_pmc.txt 2>&1
 rm -rf $O/prof_train $O/prof_sample $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 head -24 $O/${T}_train_step_kernel_stats.txt
-bash tools/precise_report.sh $T > /dev/null 2>&1; tail -12 $O/r04_precise_parity.txt
+bash tools/precise_report.sh $T > /dev/null 2>&1; tail -12 $O/${T}_precise_parity.txt
