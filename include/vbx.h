@@ -192,6 +192,8 @@ int vbx_attn_dropout_bits(void* bits_rm, void* bits_cm, int BH, int Np, unsigned
                           void* stream);
 int vbx_dropout_rows(void* x_f16, void* x_bf16, long rows, int cols, int ld, unsigned long long seed, unsigned stream_id, float p,
                      void* stream);
+/* the same mask (same seed / stream_id / element index) on an fp32 matrix: precise mode's unrounded GEGLU output */
+int vbx_dropout_rows_f32(float* x, long rows, int cols, int ld, unsigned long long seed, unsigned stream_id, float p, void* stream);
 int vbx_attn_fwd_dropout(const void* q16, const void* k16, const void* v16, const uint8_t* mask, void* out16, void* out_bf16,
                          float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p, void* stream);
 int vbx_attn_bwd_dropout(const void* q16, const void* k16, const void* qb, const void* kb, const void* v, const uint8_t* mask,
@@ -225,6 +227,10 @@ int vbx_pack_embed_input(const float* x, const float* cond, const uint8_t* cond_
 int vbx_pack_embed_input_text(const float* x, const float* cond, const uint8_t* cond_mask, const uint8_t* drop_mask,
                               const float* null_cond, const long* ids, int T, const float* table, int E, long null_id,
                               void* out_f16, void* out_bf16, int B, int N, int D, void* stream);
+/* the same rows unrounded (fp32 [B*N, 2*D + E]): precise mode's to_embed operand */
+int vbx_embed_input_text_f32(const float* x, const float* cond, const uint8_t* cond_mask, const uint8_t* drop_mask,
+                             const float* null_cond, const long* ids, int T, const float* table, int E, long null_id,
+                             float* out_f32, int B, int N, int D, void* stream);
 int vbx_cond_emb_bwd(const void* demb_bf16, int ld, const long* ids, int T, const uint8_t* drop_mask, long null_id,
                      float* gtable, int B, int N, int E, void* stream);
 /* DurationPredictor front end (voicebox_pytorch.py:793-823): out fp16 [B*N, E+D] = [ to_phoneme_emb(max(ids,0)) | cond'' ] with
@@ -541,8 +547,12 @@ void* vbx_model_debug_ptr(const vbx_model* m, const char* name, int layer);
  *  - MultiheadRMSNorm + rotary (:286-287,193-199, 323-328) and GEGLU (:338-340) as fp32 kernels on the fp32 GEMM results
  *    (vbx_qknorm_rope_f32, vbx_geglu_f32), which also write the fp16 / bf16 copies the backward entry points read;
  *  - Attend (attend.py:121-135) as an fp32 FMA flash kernel (vbx_attn_fwd_f32), q / k / v / P never rounded;
- *  - AdaptiveRMSNorm's to_gamma / to_beta (:273) from the fp32 master weights (vbx_adaln_proj_f32).
- * Serves the unconditional model (E == 0, no GateLoop, no dropout); other configurations return VBX_EINVAL. */
+ *  - AdaptiveRMSNorm's to_gamma / to_beta (:273) from the fp32 master weights (vbx_adaln_proj_f32);
+ *  - text conditioning (:1056-1078): the fp32 rows of vbx_embed_input_text_f32 through the same split GEMM (K = 2 * Din + E);
+ *  - GateLoop (:465-466): its to_qkva projection through the split GEMM, scan and LayerNorm are fp32 on both paths;
+ *  - dropout (attend.py:131, :346): the fast path's Philox masks (vbx_attn_dropout_bits, vbx_dropout_rows[_f32]) on the unrounded
+ *    probabilities / GEGLU output, so a precise step and a fast step with the same seed drop the same elements.
+ * Serves VoiceBox (not the standalone Transformer stack, u-net skips or plain RMSNorm); those return VBX_EINVAL. */
 /* dst fp16 [rows, 3*Kp] = [hi | hi 2^-8 | lo 2^8] of src fp32 [rows, K] (row stride ld floats), columns K..Kp zero; Kp % 8 == 0 */
 int vbx_split3_f16(const float* src, long rows, int K, long ld, void* dst_f16, int Kp, void* stream);
 /* dst fp16 [dst_rows, 3*dst_cols] = [hi | lo 2^8 | hi 2^-8] of the weight, rows mapped / padded as vbx_pack_weight does */
@@ -558,6 +568,9 @@ int vbx_qknorm_rope_f32(const float* raw, int B, int H, int Np, float qk_scale, 
 /* attend.py:121-135 in fp32: q, k, v fp32 [B,H,Np,64] -> out32 fp32 [B,Np,H*64] (+ optional fp16 / bf16 copies, log2-LSE [B,H,Np]) */
 int vbx_attn_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16, void* out_bf16,
                      float* lse, int B, int H, int Np, float scale, void* stream);
+/* ... with attention dropout: bits_rm / p as in vbx_attn_fwd_dropout (the statistics stay those of the undropped probabilities) */
+int vbx_attn_fwd_f32_dropout(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16,
+                             void* out_bf16, float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p, void* stream);
 /* GEGLU (libm erff) on the fp32 pre-activation h1 [M, 2*Fp] in the packed column order (128-column blocks: 64 "x", their 64 "gate"):
  * g32 [M, Fp] (+ optional fp16 / bf16 copies of g and the bf16 pre-activation the backward reads) */
 int vbx_geglu_f32(const float* h1, float* g32, void* g16, void* g_bf16, void* h1_bf16, long M, int Fp, void* stream);

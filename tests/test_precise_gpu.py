@@ -388,3 +388,127 @@ def test_precise_switch_keeps_the_fast_engines(golden):
     with vbx.precise_mode():
         p2 = run()
     assert p2 != p  # the split weights were repacked from the updated parameters
+
+
+# ---- the checker mode checks what is built -- text conditioning, GateLoop layers, dropout
+PRECISE_LOSS_TOL = 5e-5  # fp32-class: the precise forward against an fp32 (reference) or fp64 (restatement) evaluation of a dim-64 model
+
+
+def test_precise_text_conditioned_golden(golden):
+    """condition_on_text=True (voicebox_pytorch.py:1056-1078) in precise mode: the fp32 [x | cond_emb | cond] rows through the split
+    GEMM (K = 2 * 64 + 48).  Loss against the UNMODIFIED reference for phoneme ids with classifier-free drop and for semantic ids
+    without; the embedding-table gradient flows through the unchanged backward; eval prediction and guided prediction."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small_text")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=50, dim_cond_emb=48, depth=2, dim_head=64, heads=2, condition_on_text=True)
+    res = vb.load_state_dict(g["state"], strict=False)
+    assert not res.unexpected_keys and all("inv_freq" in k for k in res.missing_keys)
+    vb = vb.to(dev)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    for ids_key, loss_key, grads_key, p_drop, kw in (("ids", "loss", "grads", 0.5, "phoneme_ids"),
+                                                      ("ids_n", "loss_n", "grads_n", 0.0, "semantic_token_ids")):
+        wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb, cond_drop_prob=p_drop)
+        vb.zero_grad(set_to_none=True)
+        with vbx.precise_mode(), rng_override(cond_drop=g["drop"], **draws):
+            loss = wrapper(g["x1"].to(dev), **{kw: g[ids_key].to(dev)})
+            loss.backward()
+        with rng_override(cond_drop=g["drop"], **draws):
+            fast = wrapper(g["x1"].to(dev), **{kw: g[ids_key].to(dev)})
+        dl = abs(float(loss) - float(g[loss_key]))
+        print(f"text model ({ids_key}): precise |dloss| {dl:.2e}, fast path {abs(float(fast) - float(g[loss_key])):.2e}")
+        assert dl < PRECISE_LOSS_TOL, dl
+        named = dict(vb.named_parameters())
+        assert named["to_cond_emb.weight"].grad is not None and torch.isfinite(named["to_cond_emb.weight"].grad).all()
+        for k in ("to_pred.weight", "transformer.final_norm.gamma", "transformer.layers.1.5.3.weight"):
+            assert rel(named[k].grad, g[grads_key][k]) < 5e-2, (k, rel(named[k].grad, g[grads_key][k]))
+        from test_model_gpu import flat_cos
+        assert flat_cos(named, g[grads_key]) > 0.99
+    vb.eval()
+    with vbx.precise_mode(), torch.no_grad():
+        pred = vb(g["x1"].to(dev), times=torch.tensor(0.4), cond_token_ids=g["ids"].to(dev), cond=g["cond"].to(dev), cond_drop_prob=0.0)
+        pc = vb.forward_with_cond_scale(g["x1"].to(dev), times=torch.tensor(0.4), cond_token_ids=g["ids"].to(dev), cond=g["cond"].to(dev),
+                                        cond_scale=1.7)
+    print("text model eval, precise: rel", rel(pred, g["pred"]), "guided", rel(pc, g["pred_cfg"]))
+    assert rel(pred, g["pred"]) < 2e-3 and rel(pc, g["pred_cfg"]) < 3e-3
+
+
+def test_precise_gateloop_golden(golden):
+    """use_gateloop_layers=True (:399, :465-466) in precise mode: to_qkva through the split GEMM, the scan and the post LayerNorm are
+    fp32 on both paths.  Loss and eval prediction against the golden of the reference module tree; the backward runs from what the
+    precise forward saved."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+
+    g = golden("small_gateloop")
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=500, depth=2, dim_head=64, heads=2, condition_on_text=False, use_gateloop_layers=True)
+    res = vb.load_state_dict(g["state"], strict=False)
+    assert not res.unexpected_keys and all("inv_freq" in k for k in res.missing_keys)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    with vbx.precise_mode(), rng_override(**draws):
+        loss = wrapper(g["x1"].to(dev))
+        loss.backward()
+    with rng_override(**draws):
+        fast = wrapper(g["x1"].to(dev))
+    dl = abs(float(loss) - float(g["loss"]))
+    print(f"gateloop: precise |dloss| {dl:.2e}, fast path {abs(float(fast) - float(g['loss'])):.2e}")
+    assert dl < PRECISE_LOSS_TOL, dl
+    named = dict(vb.named_parameters())
+    from test_model_gpu import flat_cos
+    assert flat_cos(named, g["grads"]) > 0.99
+    for k in ("transformer.layers.0.1.norm.gamma", "transformer.layers.1.1.to_qkva.0.weight", "transformer.layers.0.1.maybe_post_ln.weight",
+              "transformer.layers.1.1.maybe_post_ln.bias", "to_pred.weight"):
+        assert torch.isfinite(named[k].grad).all() and rel(named[k].grad, g["grads"][k]) < 0.15, (k, rel(named[k].grad, g["grads"][k]))
+    vb.eval()
+    with vbx.precise_mode(), torch.no_grad():
+        pred = vb(g["x1"].to(dev), times=g["eval_times"].to(dev), cond_token_ids=None, cond=g["x1"].to(dev), cond_drop_prob=0.0)
+    print("gateloop eval prediction, precise: rel", rel(pred, g["pred"]))
+    assert rel(pred, g["pred"]) < 2e-3
+
+
+def test_precise_dropout_same_masks(golden):
+    """attn_dropout / ff_dropout (attend.py:131, :346) in precise mode: the fast path's Philox masks on the UNROUNDED probabilities and
+    GEGLU output.  The loss against the fp64 restatement given the masks this forward drew; the same torch seed drops the same elements
+    on the fast path (its loss is within its own fp16 distance of the precise one); another seed moves both."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.masks import rng_override
+    from test_model_gpu import _model_dropout_multipliers
+
+    g = golden("small_dropout")
+    cfg = restate.Cfg(**g["cfg"])
+    pa, pf = g["attn_dropout"], g["ff_dropout"]
+    vb = vbx.VoiceBox(dim=cfg.dim, num_cond_tokens=500, depth=cfg.depth, dim_head=64, heads=cfg.heads, condition_on_text=False,
+                      attn_dropout=pa, ff_dropout=pf)
+    vb.load_state_dict(g["state"], strict=False)
+    vb = vb.to(dev)
+    wrapper = vbx.ConditionalFlowMatcherWrapper(voicebox=vb)
+    draws = dict(x0=g["x0"], times=g["times"], frac_lengths=g["frac"], rand=g["rand"])
+    B, N = g["x1"].shape[:2]
+    torch.manual_seed(1234)
+    with vbx.precise_mode(), rng_override(**draws):
+        loss = wrapper(g["x1"].to(dev))
+        loss.backward()
+    eng = vb._engines[(B, N, 3)]  # training engine of the precise mode (model.py::engine)
+    assert eng.precise and eng.io.dropout == 1
+    attn, ff = _model_dropout_multipliers(vbx, eng, cfg, B, N, pa, pf)
+    p = {k: v.double().clone().requires_grad_(v.is_floating_point() and k != "null_cond") for k, v in g["state"].items()}
+    with restate.dropout_multipliers(attn=attn, ff=ff):
+        ref = restate.cfm_loss(p, cfg, g["x1"].double(), g["x0"].double(), g["times"].double(), g["frac"], g["rand"])
+    ref.backward()
+    dl = abs(float(loss) - float(ref))
+    torch.manual_seed(1234)
+    with rng_override(**draws):
+        fast = wrapper(g["x1"].to(dev))
+    torch.manual_seed(99)
+    with vbx.precise_mode(), rng_override(**draws):
+        other = wrapper(g["x1"].to(dev))
+    print(f"dropout: precise |dloss| vs fp64 restatement with the same masks {dl:.2e}; fast path, same seed: {abs(float(fast) - float(ref)):.2e}; "
+          f"another seed: {abs(float(other) - float(ref)):.2e}")
+    assert dl < PRECISE_LOSS_TOL, dl
+    assert abs(float(fast) - float(loss)) < 1e-3 and abs(float(other) - float(loss)) > 1e-4
+    worst = max(rel(prm.grad, p[k].grad) for k, prm in vb.named_parameters() if p[k].grad is not None)
+    print(f"dropout: precise forward + bf16 backward, worst gradient vs restatement {worst:.3%}")
+    assert worst < 0.03, worst

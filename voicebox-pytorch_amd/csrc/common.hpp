@@ -169,6 +169,9 @@ struct VbxPreciseLayer {
   u16 *hn1, *q16, *k16, *qb, *kb, *v, *vh, *oh, *o, *hn2, *gh, *g, *h1;
   float *qrn, *krn, *lse;
   const float* b1;  // packed FeedForward[0] bias (wpack arena)
+  u16* hg;                  // GateLoop: bf16 copy of its pre-norm output (the backward's wgrad operand)
+  float *glp, *gls, *glh;   // GateLoop: to_qkva output, scan output, kept scan state
+  unsigned *dbr, *dbc;      // attention dropout keep bits of this layer (both orientations)
 };
 struct VbxPreciseActs {
   float *four, *pre, *temb, *ada, *e, *pred, *per_b;

@@ -71,7 +71,7 @@ VBX_DEV void interp_src(int n, int N, int T, int& i0, int& i1, float& lam) {
 __global__ void pack_embed_text_kernel(const float* __restrict__ x, const float* __restrict__ cond, const uint8_t* __restrict__ cmask,
                                        const uint8_t* __restrict__ drop, const float* __restrict__ null_cond,
                                        const long* __restrict__ ids, int T, const float* __restrict__ table, int E, long null_id,
-                                       u16* __restrict__ out, u16* __restrict__ outb, int B, int N, int D) {
+                                       u16* __restrict__ out, u16* __restrict__ outb, float* __restrict__ out32, int B, int N, int D) {
   const int cx = D / 8, ce = E / 8, cpr = 2 * cx + ce;  // 8-wide chunks per output row
   const long total = (long)B * N * cpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -110,8 +110,12 @@ __global__ void pack_embed_text_kernel(const float* __restrict__ x, const float*
       }
     }
     const long oo = row * (2L * D + E) + (long)c * 8;
-    *reinterpret_cast<uint4*>(out + oo) = pack8_h(v);
+    if (out) *reinterpret_cast<uint4*>(out + oo) = pack8_h(v);
     if (outb) *reinterpret_cast<uint4*>(outb + oo) = pack8(v);
+    if (out32) {  // precise mode: the same rows, unrounded
+      *reinterpret_cast<float4*>(out32 + oo) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out32 + oo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
   }
 }
 // ---- DurationPredictor embed input (voicebox_pytorch.py:793-823): row (b, n) of N phoneme positions =
@@ -1501,7 +1505,19 @@ extern "C" int vbx_pack_embed_input_text(const float* x, const float* cond, cons
   VBX_REQUIRE(!drop_mask || null_cond, "vbx_pack_embed_input_text: a drop mask needs null_cond");
   const long chunks = (long)B * N * (2 * D + E) / 8;
   hipLaunchKernelGGL(pack_embed_text_kernel, dim3(grid_for(chunks)), dim3(256), 0, ST, x, cond, cond_mask, drop_mask, null_cond, ids, T,
-                     table, E, null_id, (u16*)out_f16, (u16*)out_bf16, B, N, D);
+                     table, E, null_id, (u16*)out_f16, (u16*)out_bf16, (float*)nullptr, B, N, D);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+// the same rows in fp32 (precise mode's to_embed operand)
+extern "C" int vbx_embed_input_text_f32(const float* x, const float* cond, const uint8_t* cond_mask, const uint8_t* drop_mask,
+                                        const float* null_cond, const long* ids, int T, const float* table, int E, long null_id,
+                                        float* out_f32, int B, int N, int D, void* stream) {
+  VBX_REQUIRE(x && cond && ids && table && out_f32 && T > 0 && D % 8 == 0 && E > 0 && E % 8 == 0, "vbx_embed_input_text_f32: bad args");
+  VBX_REQUIRE(!drop_mask || null_cond, "vbx_embed_input_text_f32: a drop mask needs null_cond");
+  const long chunks = (long)B * N * (2 * D + E) / 8;
+  hipLaunchKernelGGL(pack_embed_text_kernel, dim3(grid_for(chunks)), dim3(256), 0, ST, x, cond, cond_mask, drop_mask, null_cond, ids, T,
+                     table, E, null_id, (u16*)nullptr, (u16*)nullptr, out_f32, B, N, D);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -2043,8 +2059,8 @@ __global__ __launch_bounds__(256) void attn_dropout_bits_kernel(unsigned* __rest
 
 // In-place dropout of a [rows, cols] 16-bit matrix (row stride ld) held as an fp16 copy and / or a bf16 copy: 8 elements
 // (one Philox call, one 16-byte access per copy) per thread.  cols, ld multiples of 8.
-__global__ __launch_bounds__(256) void dropout_rows_kernel(u16* __restrict__ xh, u16* __restrict__ xb, long rows, int cols, int ld,
-                                                           unsigned k0, unsigned k1, unsigned stream_id, unsigned thr16, float rkeep) {
+__global__ __launch_bounds__(256) void dropout_rows_kernel(u16* __restrict__ xh, u16* __restrict__ xb, float* __restrict__ x32, long rows,
+                                                           int cols, int ld, unsigned k0, unsigned k1, unsigned stream_id, unsigned thr16, float rkeep) {
   const int c8 = cols >> 3;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows * c8) return;
@@ -2074,6 +2090,10 @@ __global__ __launch_bounds__(256) void dropout_rows_kernel(u16* __restrict__ xh,
     }
     *reinterpret_cast<uint4*>(xb + off) = make_uint4(w[0], w[1], w[2], w[3]);
   }
+  if (x32) {  // precise mode: the unrounded copy takes the same mask
+#pragma unroll
+    for (int i = 0; i < 8; i++) x32[off + i] = ((keep >> i) & 1u) ? x32[off + i] * rkeep : 0.f;
+  }
 }
 
 }  // namespace
@@ -2097,7 +2117,18 @@ extern "C" int vbx_dropout_rows(void* x_f16, void* x_bf16, long rows, int cols, 
   VBX_REQUIRE((x_f16 || x_bf16) && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vbx_dropout_rows: bad args (cols, ld multiples of 8)");
   VBX_REQUIRE(p > 0.f && p < 1.f, "vbx_dropout_rows: p must be in (0, 1)");
   const long n = rows * (cols / 8);
-  hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (u16*)x_f16, (u16*)x_bf16, rows, cols, ld,
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (u16*)x_f16, (u16*)x_bf16, (float*)nullptr, rows, cols, ld,
+                     (unsigned)seed, (unsigned)(seed >> 32), stream_id, dropout_thr16(p), vbx_dropout_keep_scale(p));
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+// the same mask on an fp32 matrix (precise mode keeps the GEGLU output unrounded)
+extern "C" int vbx_dropout_rows_f32(float* x, long rows, int cols, int ld, unsigned long long seed, unsigned stream_id, float p,
+                                    void* stream) {
+  VBX_REQUIRE(x && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "vbx_dropout_rows_f32: bad args (cols, ld multiples of 8)");
+  VBX_REQUIRE(p > 0.f && p < 1.f, "vbx_dropout_rows_f32: p must be in (0, 1)");
+  const long n = rows * (cols / 8);
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, (u16*)nullptr, (u16*)nullptr, x, rows, cols, ld,
                      (unsigned)seed, (unsigned)(seed >> 32), stream_id, dropout_thr16(p), vbx_dropout_keep_scale(p));
   VBX_LAUNCH_CHECK();
   return 0;

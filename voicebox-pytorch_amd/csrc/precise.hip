@@ -157,7 +157,8 @@ constexpr int PA_KT = 64, PA_CH = 16;
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const uint8_t* __restrict__ mask,
                                                            float* __restrict__ o32, u16* __restrict__ o16, u16* __restrict__ ob,
-                                                           float* __restrict__ lse, int H, int Np, float scale_log2e) {
+                                                           float* __restrict__ lse, int H, int Np, float scale_log2e,
+                                                           const unsigned* __restrict__ bits_rm, int W2, float rkeep) {
   __shared__ __attribute__((aligned(16))) float Ks[PA_KT][64];
   __shared__ __attribute__((aligned(16))) float Vs[PA_KT][64];
   __shared__ float valid_s[PA_KT];
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
     acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
   }
   float m = -1e30f, l = 0.f;
+  // attention dropout (attend.py:131): keep bit (key % 32) of word key / 32 of this query's row (ops.hip::attn_dropout_bits_kernel)
+  const unsigned* brow = bits_rm ? bits_rm + ((long)bh * Np + (qok ? qi : 0)) * W2 : nullptr;
   for (int k0 = 0; k0 < Np; k0 += PA_KT) {
     __syncthreads();
     for (int i = threadIdx.x; i < PA_KT * 16; i += 256) {
@@ -209,10 +212,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
       l *= alpha;
 #pragma unroll
       for (int d = 0; d < 64; d++) acc[d] *= alpha;
+      static_assert(PA_CH == 16, "a chunk is one half of a keep-bit word");
+      const unsigned kbits = brow ? brow[(k0 + c0) >> 5] >> ((k0 + c0) & 31) : 0xFFFFu;
 #pragma unroll
       for (int j = 0; j < PA_CH; j++) {
-        const float p = valid_s[c0 + j] != 0.f ? exp2f(s[j] - mn) : 0.f;
-        l += p;
+        float p = valid_s[c0 + j] != 0.f ? exp2f(s[j] - mn) : 0.f;
+        l += p;  // the normaliser is that of the undropped probabilities
+        if (brow) p = ((kbits >> j) & 1u) ? p * rkeep : 0.f;
 #pragma unroll
         for (int d = 0; d < 64; d += 4) {
           const float4 vv = *reinterpret_cast<const float4*>(&Vs[c0 + j][d]);
@@ -307,11 +313,21 @@ extern "C" int vbx_qknorm_rope_f32(const float* raw, int B, int H, int Np, float
   VBX_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int vbx_attn_fwd_f32_dropout(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16,
+                                        void* out_bf16, float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p,
+                                        void* stream) {
+  VBX_REQUIRE(q && k && v && out32 && bits_rm && B > 0 && H > 0 && Np > 0 && p > 0.f && p < 1.f, "vbx_attn_fwd_f32_dropout: bad args");
+  hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16, (u16*)out_bf16,
+                     lse, H, Np, scale * 1.44269504088896340736f, (const unsigned*)bits_rm, vbx_dropout_bits_words(Np),
+                     vbx_dropout_keep_scale(p));
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int vbx_attn_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16,
                                 void* out_bf16, float* lse, int B, int H, int Np, float scale, void* stream) {
   VBX_REQUIRE(q && k && v && out32 && B > 0 && H > 0 && Np > 0, "vbx_attn_fwd_f32: bad args");
   hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16,
-                     (u16*)out_bf16, lse, H, Np, scale * 1.44269504088896340736f);
+                     (u16*)out_bf16, lse, H, Np, scale * 1.44269504088896340736f, (const unsigned*)nullptr, 0, 1.0f);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -347,19 +363,20 @@ struct PCarver {
   }
 };
 struct PDims {
-  int B, N, R, Np, D, H, I, F, Fp, Th, L, Din, Ke;
+  int B, N, R, Np, D, H, I, F, Fp, Th, L, Din, E, Ke;
   long M, M0;
 };
 PDims pdims(const vbx_model* m) {
   PDims d;
   d.B = m->B; d.N = m->N; d.R = m->R; d.Np = m->N + m->R; d.D = m->D; d.H = m->H; d.I = m->H * 64;
   d.Din = m->Din > 0 ? m->Din : m->D;
-  d.Ke = 2 * d.Din;
+  d.E = m->E;
+  d.Ke = 2 * d.Din + d.E;  // to_embed input: [x | cond_emb | cond]  (:1075-1078)
   d.F = m->F; d.Fp = ((m->F + 63) / 64) * 64; d.Th = m->Th; d.L = m->L;
   d.M = (long)d.B * d.Np; d.M0 = (long)d.B * d.N;
   return d;
 }
-struct W3Layer { u16 *qkv, *out, *w1, *w2; };
+struct W3Layer { u16 *qkv, *out, *w1, *w2, *glw; };
 struct W3 {
   u16 *emb, *pred;
   std::vector<W3Layer> layer;
@@ -376,6 +393,7 @@ void carve_w3(const vbx_model* m, void* base, W3& w) {
     w.layer[l].out = c.take<u16>((size_t)d.D * 3 * d.I);
     w.layer[l].w1 = c.take<u16>((size_t)2 * d.Fp * 3 * d.D);
     w.layer[l].w2 = c.take<u16>((size_t)d.D * 3 * d.Fp);
+    w.layer[l].glw = m->gateloop ? c.take<u16>((size_t)3 * d.D * 3 * d.D) : nullptr;
   }
   w.bytes = al256(c.off);
 }
@@ -400,8 +418,8 @@ void carve_ps(const vbx_model* m, void* base, PScratch& s) {
   s.bytes = al256(c.off);
 }
 int supported(const vbx_model* m) {
-  VBX_REQUIRE(!m->stack_only && !m->gateloop && m->E == 0 && !m->plain_norm,
-              "precise mode serves the unconditional VoiceBox forward (no GateLoop, no text conditioning, no standalone stack)");
+  VBX_REQUIRE(!m->stack_only && !m->plain_norm && !m->unet,
+              "precise mode serves the VoiceBox forward (not the standalone Transformer stack, u-net skips or plain RMSNorm)");
   return 0;
 }
 }  // namespace
@@ -432,6 +450,8 @@ extern "C" int vbx_model_pack_weights_precise(const vbx_model* m, void* stream) 
     if (int rc = vbx_pack_weight3(P + o[VBX_L_OUTW], d.D, d.I, w.layer[l].out, d.D, d.I, 0, 0, stream)) return rc;
     if (int rc = vbx_pack_weight3(P + o[VBX_L_FF1W], 2 * d.F, d.D, w.layer[l].w1, 2 * d.Fp, d.D, 1, d.F, stream)) return rc;
     if (int rc = vbx_pack_weight3(P + o[VBX_L_FF2W], d.D, d.F, w.layer[l].w2, d.D, d.Fp, 0, 0, stream)) return rc;
+    if (m->gateloop)
+      if (int rc = vbx_pack_weight3(P + o[VBX_L_GLW], 3 * d.D, d.D, w.layer[l].glw, 3 * d.D, d.D, 0, 0, stream)) return rc;
   }
   return 0;
 }
@@ -440,7 +460,6 @@ extern "C" int vbx_model_pack_weights_precise(const vbx_model* m, void* stream) 
 int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseActs* a, void* stream) {
   if (int rc = supported(m)) return rc;
   VBX_REQUIRE(m->wpack3 && m->pscratch, "vbx_model_forward: precise mode needs the wpack3 / pscratch arenas");
-  VBX_REQUIRE(!(io->dropout && (m->attn_dropout > 0.f || m->ff_dropout > 0.f)), "precise mode does not implement dropout");
   const PDims d = pdims(m);
   W3 w;
   carve_w3(m, m->wpack3, w);
@@ -468,33 +487,62 @@ int vbx_forward_precise(const vbx_model* m, const vbx_io* io, const VbxPreciseAc
     }
   }
   // to_embed(cat(x, cond * ~cond_mask))   (:1035,1075-1078); the bf16 copy of the input is the backward's wgrad operand
-  if (a->embed_in_bf16)
-    PCK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a->embed_in_f16, a->embed_in_bf16, d.B, d.N, d.Din, stream));
-  hipLaunchKernelGGL(embed_cat_kernel, dim3(grid_for(d.M0 * 2 * d.Din / 4)), dim3(256), 0, ST, io->x, io->cond, io->cond_mask, s.h32, d.M0, d.Din);
-  VBX_LAUNCH_CHECK();
+  if (d.E) {  // condition_on_text (:1056-1078): [x | interpolated cond_emb rows | cond'] -- the same rows the fast path rounds to fp16
+    VBX_REQUIRE(io->cond_ids && io->T > 0, "vbx_model_forward: a text-conditioned model needs cond_ids");
+    if (a->embed_in_bf16)
+      PCK(vbx_pack_embed_input_text(io->x, io->cond, io->cond_mask, io->drop_mask, io->null_cond, io->cond_ids, io->T, P + G[VBX_P_CEMB],
+                                    d.E, io->null_id, a->embed_in_f16, a->embed_in_bf16, d.B, d.N, d.Din, stream));
+    PCK(vbx_embed_input_text_f32(io->x, io->cond, io->cond_mask, io->drop_mask, io->null_cond, io->cond_ids, io->T, P + G[VBX_P_CEMB],
+                                 d.E, io->null_id, s.h32, d.B, d.N, d.Din, stream));
+  } else {
+    if (a->embed_in_bf16)
+      PCK(vbx_pack_embed_input(io->x, io->cond, io->cond_mask, a->embed_in_f16, a->embed_in_bf16, d.B, d.N, d.Din, stream));
+    hipLaunchKernelGGL(embed_cat_kernel, dim3(grid_for(d.M0 * 2 * d.Din / 4)), dim3(256), 0, ST, io->x, io->cond, io->cond_mask, s.h32, d.M0, d.Din);
+    VBX_LAUNCH_CHECK();
+  }
   PCK(gemm3(s.h32, d.M0, d.Ke, d.Ke, w.emb, d.D, a->e, d.D, P + G[VBX_P_EMBB], nullptr));
   PCK(vbx_convpos_fwd_libm(a->e, P + G[VBX_P_CONVW], P + G[VBX_P_CONVB], io->attn_mask, d.R ? P + G[VBX_P_REG] : nullptr, a->xs[0], d.B, d.N, d.R, d.D, m->ksize, stream));
   for (int l = 0; l < d.L; l++) {
     const long* o = m->off + VBX_NG + (long)l * VBX_NL;
     const VbxPreciseLayer& y = a->layer[l];
     const float* ada_l = a->ada + (size_t)l * d.B * 4 * d.D;
-    float* x_in = a->xs[2 * l];
-    float* x_mid = a->xs[2 * l + 1];
-    float* x_out = a->xs[2 * l + 2];
+    const int S = m->gateloop ? 3 : 2;  // residual snapshots per layer (runtime.hip::carve_acts)
+    float* x0 = a->xs[S * l];
+    float* x_in = m->gateloop ? a->xs[S * l + 1] : x0;
+    float* x_mid = a->xs[S * l + S - 1];
+    float* x_out = a->xs[S * l + S];
+    if (m->gateloop) {
+      // x = GateLoop(x) + x   (:465-466): RMSNorm -> to_qkva (split GEMM) -> gated scan -> post LayerNorm + residual (fp32 on both paths)
+      PCK(vbx_rmsnorm_fwd_multi(x0, P + o[VBX_L_GLG], nullptr, 0, y.hg, nullptr, s.h32, d.B, d.Np, 0, d.Np, d.D, stream));
+      PCK(gemm3(s.h32, d.M, d.D, d.D, w.layer[l].glw, 3 * d.D, y.glp, 3 * d.D, nullptr, nullptr));
+      PCK(vbx_gateloop_scan_fwd(y.glp, y.gls, y.glh, d.B, d.Np, d.D, stream));
+      PCK(vbx_layernorm_fwd(y.gls, P + o[VBX_L_GLLNW], P + o[VBX_L_GLLNB], x0, x_in, d.M, d.D, 1e-5f, stream));
+    }
+    const bool drop_on = io->dropout != 0;
     PCK(vbx_rmsnorm_fwd_multi(x_in, ada_l, ada_l + d.D, 4 * d.D, y.hn1, nullptr, s.h32, d.B, d.Np, 0, d.Np, d.D, stream));
     PCK(gemm3(s.h32, d.M, d.D, d.D, w.layer[l].qkv, 3 * d.I, s.raw, 3 * d.I, nullptr, nullptr));
     PCK(vbx_qknorm_rope_f32(s.raw, d.B, d.H, d.Np, m->qk_norm ? 8.0f : 0.0f, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                             m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, s.q32, s.k32, s.v32, y.q16, y.k16, y.qb, y.kb,
                             y.v, y.vh, y.qrn, y.krn, vbx_attn_q_prescale(m->attn_scale), stream));
-    PCK(vbx_attn_fwd_f32(s.q32, s.k32, s.v32, io->attn_mask_p, s.o32, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
+    if (y.dbr && drop_on) {  // attend.py:131 with the fast path's keep bits (same seed and stream id: the backward re-reads them)
+      PCK(vbx_attn_dropout_bits(y.dbr, y.dbc, d.B * d.H, d.Np, io->drop_seed, 2u * l, m->attn_dropout, stream));
+      PCK(vbx_attn_fwd_f32_dropout(s.q32, s.k32, s.v32, io->attn_mask_p, s.o32, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, y.dbr,
+                                   m->attn_dropout, stream));
+    } else {
+      PCK(vbx_attn_fwd_f32(s.q32, s.k32, s.v32, io->attn_mask_p, s.o32, y.oh, y.o, y.lse, d.B, d.H, d.Np, m->attn_scale, stream));
+    }
     PCK(gemm3(s.o32, d.M, d.I, d.I, w.layer[l].out, d.D, x_mid, d.D, nullptr, x_in));
     PCK(vbx_rmsnorm_fwd_multi(x_mid, ada_l + 2 * d.D, ada_l + 3 * d.D, 4 * d.D, y.hn2, nullptr, s.h32, d.B, d.Np, 0, d.Np, d.D, stream));
     PCK(gemm3(s.h32, d.M, d.D, d.D, w.layer[l].w1, 2 * d.Fp, s.raw, 2 * d.Fp, y.b1, nullptr));
     PCK(vbx_geglu_f32(s.raw, s.g32, y.gh, y.g, y.h1, d.M, d.Fp, stream));
+    if (drop_on && m->ff_dropout > 0.f) {  // nn.Dropout between GEGLU and the output projection (:346): the mask of the fast path
+      PCK(vbx_dropout_rows_f32(s.g32, d.M, d.Fp, d.Fp, io->drop_seed, 2u * l + 1u, m->ff_dropout, stream));
+      PCK(vbx_dropout_rows(y.gh, y.g, d.M, d.Fp, d.Fp, io->drop_seed, 2u * l + 1u, m->ff_dropout, stream));
+    }
     PCK(gemm3(s.g32, d.M, d.Fp, d.Fp, w.layer[l].w2, d.D, x_out, d.D, P + o[VBX_L_FF2B], x_mid));
   }
   // strip registers, final RMSNorm, to_pred, masked MSE   (:476-479, :1092, :1099-1115)
-  PCK(vbx_rmsnorm_fwd_multi(a->xs[2 * d.L], P + G[VBX_P_FNG], nullptr, 0, a->hf, nullptr, s.h32, d.B, d.Np, d.R, d.N, d.D, stream));
+  PCK(vbx_rmsnorm_fwd_multi(a->xs[(m->gateloop ? 3 : 2) * d.L], P + G[VBX_P_FNG], nullptr, 0, a->hf, nullptr, s.h32, d.B, d.Np, d.R, d.N, d.D, stream));
   float* pred = io->pred ? io->pred : a->pred;
   PCK(gemm3(s.h32, d.M0, d.D, d.D, w.pred, d.Din, pred, d.Din, nullptr, nullptr));
   if (io->target) PCK(vbx_masked_mse_fwd(pred, io->target, io->loss_mask, a->per_b, io->loss, d.B, d.N, d.Din, stream));

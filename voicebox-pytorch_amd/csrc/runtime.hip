@@ -96,8 +96,8 @@ struct ALayer {
   float *qrn, *krn, *lse;
   unsigned *dbr = nullptr, *dbc = nullptr;  // attention dropout keep bits, row- / column-major (training with attn_dropout > 0)
   // GateLoop: normed input (bf16 | fp16), projection q|kv|a, scan state h, scan output s
-  u16 *hg, *hgh;
-  float *glp, *glh, *gls;
+  u16 *hg = nullptr, *hgh = nullptr;
+  float *glp = nullptr, *glh = nullptr, *gls = nullptr;
 };
 struct Acts {
   u16 *embed_in, *embed_inh;
@@ -580,7 +580,7 @@ extern "C" int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* str
     for (int l = 0; l < d.L; l++) {
       const ALayer& y = a.layer[l];
       pl[l] = VbxPreciseLayer{y.hn1, y.q16, y.k16, y.qb, y.kb, y.v, y.vh, y.oh, y.o, y.hn2, y.gh, y.g, tr ? y.h1 : nullptr,
-                              y.qrn, y.krn, y.lse, w.layer[l].b1};
+                              y.qrn, y.krn, y.lse, w.layer[l].b1, y.hg, y.glp, y.gls, tr ? y.glh : nullptr, (unsigned*)y.dbr, (unsigned*)y.dbc};
     }
     VbxPreciseActs pa{a.four, a.pre, a.temb, a.ada, a.e, a.pred, a.per_b, a.xs.data(), pl.data(), a.embed_in, a.embed_inh, a.hf};
     return vbx_forward_precise(m, io, &pa, stream);

@@ -474,8 +474,6 @@ class VoiceBox(nn.Module):
             raise _lib.VbxError("VoiceBox compute runs only on an MI355X (gfx950) through libvbx_hip.so; "
                                 f"parameters are on '{dev}' and there is no CPU fallback")
         precise = precise_enabled()
-        if precise and (self._cfg.get("gateloop") or self._cfg.get("E") or self._cfg["attn_dropout"] > 0. or self._cfg["ff_dropout"] > 0.):
-            raise NotImplementedError("precise mode serves the unconditional VoiceBox (no GateLoop / text conditioning / dropout)")
         # key[2] carries the mode: 0/1 = inference/training on the fast path, 2/3 = the same in precise mode (own arenas)
         tkey = int(bool(training)) + (2 if precise else 0)
         key = (B, N, tkey) if slot == 0 else (B, N, tkey, slot)
