@@ -146,7 +146,10 @@ int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, c
  * Two kernels serve it.  The two-body kernel (default): dq and dk/dv bodies in one launch, S / dP evaluated in both.  The ONE-PASS
  * kernel (vbx_attn_bwd_select(2) or VBX_ATTN_BWD_ONEPASS=1; needs `scratch`): every S / dP block evaluated once, dq summed over the
  * key blocks of a head by an ordered, deterministic chain of workgroups through the scratch -- bit-identical dk / dv, measured slower
- * on MI355X so far, kept selectable.
+ * on MI355X so far, kept selectable.  The one-pass kernel needs an EXCLUSIVE device: its workgroups wait on
+ * each other through device memory, and a wait that exceeds the spin limit (a preempted or time-sliced GPU) traps -- the HIP context
+ * of the process is lost (every stream, cached graph and communicator), by design rather than returning a partial dq.  An A/B tool,
+ * not a production path; the default kernels have no inter-workgroup waits.
  * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL (two-body only).
  * vbx_attn_bwd_select: 0 automatic (= two-body), 1 two-body, 2 one-pass (error without scratch; under stream capture the two-body
  * kernel runs, because the chain's flags carry a per-launch epoch passed by value), 3 two-body WITHOUT round 5's fold of the softmax
