@@ -283,6 +283,12 @@ int vbx_adaln_proj_fwd(const float* temb, const void* w_bf16, const float* bias,
 int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const float* dada, float* dw, float* dbias, float* dtemb,
                        float* scratch, int B, int Th, int J, int accumulate_dtemb, void* stream);
 int vbx_adaln_proj_bwd_scratch_floats(int B, int Th, int J);
+/* d(time_emb) of EVERY layer's projections in one launch (+ one reduction): dtemb[b][t] = sum over l, j of dada[l][b][j] * W[l][j][t];
+ * W fp16 [L][J][Th] (the packed arena's order), dada fp32 [L][B][J], scratch vbx_adaln_dtemb_all_scratch_floats() floats.  With the
+ * weight gradient kept in factor form (vbx_model.adaln_factors) and the bias gradient taken from the norm partial records, this is all
+ * that is left of the adaLN backward: once per step instead of two launches per layer. */
+long vbx_adaln_dtemb_all_scratch_floats(int L, int B, int Th, int J);
+int vbx_adaln_dtemb_all(const void* w_f16, const float* dada, float* dtemb, float* scratch, int L, int B, int Th, int J, void* stream);
 /* reduce rmsnorm_bwd partials over chunks: out[b][2][D] = sum_chunk part[b][chunk][2][D] */
 int vbx_reduce_norm_partials(const float* part, float* out, long out_b_stride, int B, int chunks, int D, int sum_batch,
                              void* stream);
@@ -366,7 +372,7 @@ int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream);
 /* Several small column reductions in one launch: for job i, out[b][map(c)] = sum over r < rows of
  * src[b*src_bstride + r*row_stride + c], c < cols, b < batches; map = identity or the GEGLU row un-interleave (rowmap = 1, F), columns
  * mapping outside [0, dst_len) are dropped.  block0 is filled in by the library. */
-#define VBX_MR_MAX 8
+#define VBX_MR_MAX 48
 typedef struct {
   const float* src;
   float* dst;
@@ -378,6 +384,8 @@ typedef struct {
   int n;
 } vbx_mr_jobs;
 int vbx_multi_reduce(const vbx_mr_jobs* jobs, void* stream);
+/* vbx_splitk_reduce_multi(sjobs) and vbx_multi_reduce(mjobs) as ONE launch (the end of a layer's backward); results bit-identical */
+int vbx_layer_reduce(const vbx_skr_jobs* sjobs, const vbx_mr_jobs* mjobs, void* stream);
 /* vbx_geglu_bwd that also writes per-slab column sums of dh1: scratch[vbx_geglu_bwd_colsum_slabs()][2*Fp] (same interleaved column
  * order as dh1; finish with vbx_multi_reduce + the GEGLU row un-interleave) -- the FeedForward[0].bias gradient without a second
  * pass over dh1 */
@@ -491,6 +499,11 @@ typedef struct {
                              WEIGHTS (slots VBX_L_G1W .. VBX_L_B2W) -- they stay in factor form (vbx_model_adaln_factors; the
                              optimizer expands them, see vbx_adam_adaln_factors) and vbx_model_adam_segments leaves those blocks
                              out of the fused Adam's table.  Biases, d(time_emb) and every other gradient are unchanged. */
+  int defer_reduce;       /* 1: the caller runs vbx_model_backward_layer for L-1 .. 0 and reads NO gradient before layer 0 has
+                             returned (no per-stage gradient exchange): every layer keeps its partial records (norm gamma / beta, bias
+                             column sums, qk-norm gammas) in its own arena region and layer 0 reduces them all in two launches
+                             instead of one launch per layer.  0 (default): each layer's small gradients are final when it returns.
+                             Same per-tensor summation order either way. */
 } vbx_model;
 
 typedef struct {

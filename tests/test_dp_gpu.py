@@ -260,7 +260,18 @@ def test_adaln_factor_mode_equals_materialised_gradients():
             ts.step(d["x1"].to(dev))
         torch.cuda.synchronize()
         gs[mode] = ts.gflat.clone()
-    assert torch.equal(gs["materialize"][~inside], gs["factors"][~inside])
+    # the factor form takes the projections' bias gradient from the norm partial records and d(time_emb) from one all-layer launch
+    # (runtime.hip: ada_all) -- another summation order for those tensors; every other gradient is the same kernel on the same inputs
+    fp = ts.fp
+    for slot in fp.order:
+        o, n = fp.offsets[slot], fp.slots[slot].numel()
+        if bool(inside[o]):
+            continue
+        ga, gb = gs["materialize"][o:o + n], gs["factors"][o:o + n]
+        if slot in ("SINW", "T1W", "T1B") or slot.split(".")[-1] in ("G1B", "B1B", "G2B", "B2B"):  # time MLP, projection biases
+            assert float((ga - gb).norm() / ga.norm().clamp(min=1e-30)) < 1e-5, slot
+        else:
+            assert torch.equal(ga, gb), slot
 
 
 def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
@@ -487,7 +498,9 @@ def test_rccl_path_executes_at_world_size_1(tmp_path):
     assert res["shard"]["native"] and res["shard"]["used_reduce_scatter"], res["shard"]
     # the FIRST step of every variant starts from the same weights: same update up to the last bits of the clip coefficient and the
     # operation order of the adaLN blocks' gradient (expanded into the buffer vs inside Adam); later steps are chaotic at this init
-    assert float((res["shard"]["flat1"] - res["0"]["flat1"]).abs().max()) < 2e-6
+    # (the shard run materialises the adaLN weight gradients: its projection-bias and time-MLP gradients are summed in another order
+    #  -- runtime.hip: ada_all -- and the first Adam step turns a last-bit change of a tiny gradient into up to ~2e-6 of update)
+    assert float((res["shard"]["flat1"] - res["0"]["flat1"]).abs().max()) < 5e-6
     assert float((res["1"]["flat1"] - res["0"]["flat1"]).abs().max()) < 2e-6
     # forced = "1": the exchange is active, the adaLN weight gradients travel as factors and are expanded into the buffer; forced = "0":
     # one GPU without exchange, they stay in factor form and their blocks of the buffer are not written -- compare everything else

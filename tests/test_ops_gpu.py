@@ -845,6 +845,85 @@ def test_adaln_proj_bwd_shapes(L, Bsz, Th, J):
     assert rel_err(dtemb, 2 * keep) < 1e-6  # accumulate_dtemb
 
 
+@pytest.mark.parametrize("Lyr,Bsz,Th,J", [(12, 8, 2048, 2048), (3, 11, 264, 516), (2, 1, 8, 4)])
+def test_adaln_dtemb_all_layers(L, Lyr, Bsz, Th, J):
+    """Factor form of the adaLN weight gradient: what is left of the projections' backward is d(time_emb) = sum over layers of
+    dada_l W_l, one launch for all layers (vbx_adaln_dtemb_all) -- against fp64, and against the per-layer entry point accumulated."""
+    g = torch.Generator().manual_seed(Lyr + Bsz + Th + J)
+    W = (torch.randn(Lyr, J, Th, generator=g) * 0.02).half()
+    dada = torch.randn(Lyr, Bsz, J, generator=g)
+    temb = torch.randn(Bsz, Th, generator=g).to(dev)
+    scratch = torch.full((L.lib().vbx_adaln_dtemb_all_scratch_floats(Lyr, Bsz, Th, J),), float("nan"), device=dev)
+    dtemb = torch.full((Bsz, Th), float("nan"), device=dev)
+    L.call("vbx_adaln_dtemb_all", W.to(dev), dada.to(dev), dtemb, scratch, Lyr, Bsz, Th, J, st())
+    want = torch.einsum("lbj,ljt->bt", dada.double(), W.double())
+    assert rel_err(dtemb, want) < 1e-5
+    per = torch.empty(Bsz, Th, device=dev)
+    dbias = torch.empty(J, device=dev)
+    sc = torch.empty(L.lib().vbx_adaln_proj_bwd_scratch_floats(Bsz, Th, J), device=dev)
+    for l in range(Lyr):
+        L.call("vbx_adaln_proj_bwd", temb, W[l].contiguous().to(dev), dada[l].contiguous().to(dev), None, dbias, per, sc, Bsz, Th, J, int(l > 0), st())
+    assert rel_err(dtemb, per) < 1e-5
+
+
+def test_layer_reduce_equals_the_two_launches(L):
+    """vbx_layer_reduce = vbx_splitk_reduce_multi + vbx_multi_reduce in ONE launch: bit-identical outputs (weight-gradient slabs with
+    and without the GEGLU row un-interleave, ragged sizes; a plain and a batched column reduction)."""
+    import ctypes as C
+
+    class SJob(C.Structure):
+        _fields_ = [("slabs", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in
+                    ("splits", "M", "N", "dst_rows", "dst_cols", "dst_ld", "rowmap", "F", "block0", "pad_")]
+
+    class SJobs(C.Structure):
+        _fields_ = [("job", SJob * 6), ("n", C.c_int)]  # VBX_SKR_MAX
+
+    class MJob(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_bstride", C.c_long), ("dst_bstride", C.c_long),
+                    ("row_stride", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("batches", C.c_int), ("dst_len", C.c_int),
+                    ("rowmap", C.c_int), ("F", C.c_int), ("block0", C.c_int), ("pad_", C.c_int)]
+
+    class MJobs(C.Structure):
+        _fields_ = [("job", MJob * 48), ("n", C.c_int)]  # VBX_MR_MAX
+
+    g = torch.Generator().manual_seed(31)
+    Fd, Fp = 170, 192
+    specs = [(5, 3 * 128, 512, 3 * 128, 512, 0, 0), (3, 2 * Fp, 264, 2 * Fd, 264, 1, Fd), (7, 72, 1028, 72, 1026, 0, 0)]
+    slabs = [torch.randn(sp, M, N, generator=g).to(dev) for sp, M, N, *_ in specs]
+    x0 = torch.randn(130, 300, generator=g).to(dev)
+    x1 = torch.randn(3, 37, 100, generator=g).to(dev)
+
+    def run(fused):
+        outs = [torch.full((dr, dc), 7.0, device=dev) for _, _, _, dr, dc, _, _ in specs]
+        o0, o1 = torch.full((300,), 7.0, device=dev), torch.full((3, 80), 7.0, device=dev)
+        sj, mj = SJobs(), MJobs()
+        sj.n, mj.n = len(specs), 2
+        for i, (sp, M, N, dr, dc, rm, F) in enumerate(specs):
+            j = sj.job[i]
+            j.slabs, j.dst, j.splits, j.M, j.N, j.dst_rows, j.dst_cols, j.dst_ld, j.rowmap, j.F = slabs[i].data_ptr(), outs[i].data_ptr(), sp, M, N, dr, dc, dc, rm, F
+        a, b = mj.job[0], mj.job[1]
+        a.src, a.dst, a.rows, a.cols, a.row_stride, a.batches, a.dst_len = x0.data_ptr(), o0.data_ptr(), 130, 300, 300, 1, 300
+        b.src, b.dst, b.rows, b.cols, b.row_stride, b.batches = x1.data_ptr(), o1.data_ptr(), 37, 64, 100, 3
+        b.src_bstride, b.dst_bstride, b.dst_len = 37 * 100, 80, 64
+        lib = L.lib()
+        lib.vbx_layer_reduce.argtypes = [C.POINTER(SJobs), C.POINTER(MJobs), C.c_void_p]
+        lib.vbx_splitk_reduce_multi.argtypes = [C.POINTER(SJobs), C.c_void_p]
+        lib.vbx_multi_reduce.argtypes = [C.POINTER(MJobs), C.c_void_p]
+        if fused:
+            assert lib.vbx_layer_reduce(C.byref(sj), C.byref(mj), st()) == 0, lib.vbx_last_error()
+        else:
+            assert lib.vbx_splitk_reduce_multi(C.byref(sj), st()) == 0, lib.vbx_last_error()
+            assert lib.vbx_multi_reduce(C.byref(mj), st()) == 0, lib.vbx_last_error()
+        torch.cuda.synchronize()
+        return outs + [o0, o1]
+
+    sep, fus = run(False), run(True)
+    for a, b in zip(sep, fus):
+        assert torch.equal(a, b)
+    assert rel_err(fus[0], slabs[0].double().sum(0)) < 1e-6 and rel_err(fus[3], x0.double().sum(0)) < 1e-6
+    assert rel_err(fus[2], slabs[2].double().sum(0)[:, :1026]) < 1e-6  # ragged: unaligned row stride, columns past dst_cols dropped
+
+
 def test_geglu_bwd_and_colsum(L):
     M, Fd, Fp = 100, 170, 192
     g = torch.Generator().manual_seed(6)
@@ -1101,7 +1180,7 @@ def test_geglu_bwd_colsum_and_multi_reduce(L):
                     ("rowmap", C.c_int), ("F", C.c_int), ("block0", C.c_int), ("pad_", C.c_int)]
 
     class Jobs(C.Structure):
-        _fields_ = [("job", Job * 8), ("n", C.c_int)]
+        _fields_ = [("job", Job * 48), ("n", C.c_int)]  # VBX_MR_MAX
 
     out = torch.zeros(2 * Fd, device=dev)
     x = torch.randn(3, 37, 100, generator=g).to(dev)  # a second, batched job: per-batch sums over 37 rows of the first 64 columns

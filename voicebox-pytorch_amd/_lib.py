@@ -74,6 +74,7 @@ _PROTOS = {
     "vbx_adaln_proj_fwd": [P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
     "vbx_adaln_proj_bwd_scratch_floats": [I, I, I],
+    "vbx_adaln_dtemb_all": [P, P, P, P, I, I, I, I, P],
     "vbx_reduce_norm_partials": [P, P, L, I, I, I, I, P],
     "vbx_reduce_col_partials": [P, P, P, I, I, I, P],
     "vbx_gateloop_scan_fwd": [P, P, P, I, I, I, P],
@@ -151,12 +152,15 @@ def lib():
     l.vbx_dropout_keep_scale.restype = F
     l.vbx_attn_q_prescale.argtypes = [F]
     l.vbx_attn_q_prescale.restype = F
+    l.vbx_adaln_dtemb_all_scratch_floats.argtypes = [I, I, I, I]
+    l.vbx_adaln_dtemb_all_scratch_floats.restype = C.c_long
     _lib = l
     return l
 
 
 def exported_symbols():
-    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes", "vbx_dropout_keep_scale", "vbx_attn_q_prescale"]  # + the stage-level entries bound in engine.py
+    return sorted(_PROTOS) + ["vbx_last_error", "vbx_attn_bwd_scratch_bytes", "vbx_dropout_keep_scale", "vbx_attn_q_prescale",
+                              "vbx_adaln_dtemb_all_scratch_floats"]  # + the stage-level entries bound in engine.py
 
 
 def ptr(t):

@@ -6,6 +6,7 @@
 // hardware transpose read ds_read_b64_tr_b16, so no transposed copies of weights or activations
 // ever exist in HBM.  The fp32 C tile is staged through LDS so every epilogue stores 16/32 B per lane.
 #include "common.hpp"
+#include "reduce_roles.hpp"
 #include "gemm3_layout.hpp"  // g3::kc_slot / g3::kc_byte: the 128-byte-row K-contiguous layout shared with the one-round 64-deep tile
 #include <stdlib.h>
 #include <type_traits>
@@ -1156,35 +1157,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs j
   for (int i = 1; i < VBX_SKR_MAX; i++)
     if (i < jobs.n && (int)blockIdx.x >= jobs.job[i].block0) j = i;
   const vbx_skr_job jb = jobs.job[j];
-  const long total = (long)jb.M * jb.N;
-  const long i4 = ((long)(blockIdx.x - jb.block0) * 256 + threadIdx.x) * 4;  // N % 4 == 0: four columns of one row
-  if (i4 >= total) return;
-  const int r = (int)(i4 / jb.N), c = (int)(i4 - (long)r * jb.N);
-  int dr = r;
-  if (jb.rowmap == 1) dr = geglu_row_unmap(r, jb.F);
-  if (dr < 0 || dr >= jb.dst_rows) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* sp = jb.slabs + i4;
-  int k = 0;
-  for (; k + 4 <= jb.splits; k += 4) {  // four slabs requested before the first is consumed (same summation order)
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(sp + (long)(k + u) * total);
-#pragma unroll
-    for (int u = 0; u < 4; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-  }
-  for (; k < jb.splits; k++) {
-    const float4 v = *reinterpret_cast<const float4*>(sp + (long)k * total);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  float* o = jb.dst + (long)dr * jb.dst_ld + c;
-  if (c + 3 < jb.dst_cols && (jb.dst_ld & 3) == 0) {
-    *reinterpret_cast<float4*>(o) = s;
-  } else {
-    const float t[4] = {s.x, s.y, s.z, s.w};
-    for (int e = 0; e < 4; e++)
-      if (c + e < jb.dst_cols) o[e] = t[e];
-  }
+  skr_role(jb, ((long)(blockIdx.x - jb.block0) * 256 + threadIdx.x) * 4);  // N % 4 == 0: four columns of one row (reduce_roles.hpp)
 }
 
 }  // namespace

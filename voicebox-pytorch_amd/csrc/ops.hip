@@ -2,6 +2,7 @@
 // attention): embed packing, conv positional embedding, time embedding, adaLN projections, GEGLU
 // backward, column sums, masked MSE, CFM inputs, ODE axpy, weight packing, Adam, grad-norm.
 #include "common.hpp"
+#include "reduce_roles.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -778,6 +779,91 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel_v2(const float* __restri
   }
 }
 
+// ---- factor form (vbx_model.adaln_factors): the weight gradient is never formed and the bias gradient is a column sum of the norm
+// partial records, so what is left of the adaLN backward is d(time_emb)[b][t] = sum over (layer, j) of dada[l][b][j] * W[l][j][t].
+// ONE launch per step for every layer (per layer it was a latency-bound 11 us kernel + a 4.7 us reduction, x depth): slices of
+// ADA_PER_MAX rows of the stacked [L * J, Th] weight -> scratch[slice][b][t], then sum_rows_wide_kernel.
+__global__ __launch_bounds__(256) void adaln_dtemb_all_kernel(const u16* __restrict__ w, const float* __restrict__ dada,
+                                                              float* __restrict__ scratch, int B, int Th, int J, int spl) {
+  __shared__ __attribute__((aligned(16))) float gsh[ADA_PER_MAX * 8];  // [row of the slice][8 batch rows]
+  const int tid = threadIdx.x;
+  if ((long)blockIdx.x * 256 * 8 >= Th) return;  // block-uniform
+  const int slice = blockIdx.y, l = slice / spl;
+  const int jb = (slice - l * spl) * ADA_PER_MAX, je = min(J, jb + ADA_PER_MAX), per = je - jb;
+  const float* dl = dada + (long)l * B * J;      // dada [L][B][J]
+  const u16* wl = w + (long)l * J * Th;          // W [L][J][Th] fp16
+  const int t8 = blockIdx.x * 256 + tid;
+  const bool tv = (long)t8 * 8 < Th;
+  const u16* wcol = wl + (tv ? t8 : 0) * 8;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    __syncthreads();
+    for (int i = tid; i < ADA_PER_MAX * 8; i += 256) {
+      const int j = jb + (i >> 3), b = b0 + (i & 7);
+      gsh[i] = (j < je && b < B) ? dl[(long)b * J + j] : 0.f;
+    }
+    __syncthreads();
+    float acc[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[k][i] = 0.f;
+    for (int jj0 = 0; jj0 < per; jj0 += ADA_TG) {
+      uint4 wq[ADA_TG];
+#pragma unroll
+      for (int u = 0; u < ADA_TG; u++) wq[u] = *reinterpret_cast<const uint4*>(wcol + (long)min(jb + jj0 + u, J - 1) * Th);
+#pragma unroll
+      for (int u = 0; u < ADA_TG; u++) {  // rows past the slice were clamped above and carry a zero weight in gsh
+        float wv[8];
+        unpack8_f16(wq[u], wv);
+        const float4 g0 = *reinterpret_cast<const float4*>(gsh + (jj0 + u) * 8);
+        const float4 g1 = *reinterpret_cast<const float4*>(gsh + (jj0 + u) * 8 + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int i = 0; i < 8; i++) acc[k][i] += gv[k] * wv[i];
+      }
+    }
+    if (tv) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (b0 + k < B) {
+          float* o = scratch + ((long)slice * B + b0 + k) * Th + (long)t8 * 8;
+          *reinterpret_cast<float4*>(o) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+        }
+      }
+    }
+  }
+}
+// out[j] = sum_i in[i*ld + j] for MANY rows: block = 32 columns x 32 row lanes, four rows in flight per lane
+__global__ __launch_bounds__(1024) void sum_rows_wide_kernel(const float* __restrict__ in, long rows, long ld, float* __restrict__ out,
+                                                             long cols) {
+  __shared__ float red[32][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long j = blockIdx.x * 32L + cl;
+  float s = 0.f;
+  if (j < cols) {
+    long i = rl;
+    for (; i + 96 < rows; i += 128) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = in[(i + 32 * u) * ld + j];
+#pragma unroll
+      for (int u = 0; u < 4; u++) s += v[u];
+    }
+    for (; i < rows; i += 32) s += in[i * ld + j];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && j < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) t += red[k][cl];
+    out[j] = t;
+  }
+}
+
 // out[j] (+)= sum_i in[i*ld + j]
 // block = 64 columns x 4 row lanes (launch with 256 threads, grid = cdiv(cols, 64))
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, long rows, long ld, float* __restrict__ out,
@@ -927,34 +1013,28 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(vbx_mr_jobs jobs) {
   for (int i = 1; i < VBX_MR_MAX; i++)
     if (i < jobs.n && (int)blockIdx.x >= jobs.job[i].block0) j = i;
   const vbx_mr_job jb = jobs.job[j];
-  const int local = blockIdx.x - jb.block0;
-  const int cblocks = (jb.cols + 63) >> 6;
-  const int b = local / cblocks, cb = local - b * cblocks;
-  const int il = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = cb * 64 + il;
-  float s = 0.f;
-  if (c < jb.cols) {
-    const float* p = jb.src + (long)b * jb.src_bstride + c;
-    int r = rl;
-    for (; r + 48 < jb.rows; r += 64) {  // four rows requested before the first is consumed (same summation order)
-      float v[4];
+  mr_role(jb, blockIdx.x - jb.block0, red);  // reduce_roles.hpp
+}
+// Both job tables of a layer's backward in one launch: blocks [0, skr_blocks) reduce weight-gradient slabs (1024 threads x 4 columns
+// each), the rest run the small column reductions.  Results are bit-identical to the two separate launches (same per-element order).
+__global__ __launch_bounds__(1024) void layer_reduce_kernel(vbx_skr_jobs sj, vbx_mr_jobs mj, int skr_blocks) {
+  __shared__ float red[16][64];
+  if ((int)blockIdx.x < skr_blocks) {  // block-uniform
+    int j = 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = p[(long)(r + 16 * u) * jb.row_stride];
-#pragma unroll
-      for (int u = 0; u < 4; u++) s += v[u];
-    }
-    for (; r < jb.rows; r += 16) s += p[(long)r * jb.row_stride];
+    for (int i = 1; i < VBX_SKR_MAX; i++)
+      if (i < sj.n && (int)blockIdx.x >= sj.job[i].block0) j = i;
+    const vbx_skr_job jb = sj.job[j];
+    skr_role(jb, ((long)(blockIdx.x - jb.block0) * 1024 + threadIdx.x) * 4);
+    return;
   }
-  red[rl][il] = s;
-  __syncthreads();
-  if (rl == 0 && c < jb.cols) {
-    float t = 0.f;
+  const int bx = blockIdx.x - skr_blocks;
+  int j = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) t += red[k][il];
-    int dc = c;
-    if (jb.rowmap == 1) dc = geglu_row_unmap(c, jb.F);
-    if (dc >= 0 && dc < jb.dst_len) jb.dst[(long)b * jb.dst_bstride + dc] = t;
-  }
+  for (int i = 1; i < VBX_MR_MAX; i++)
+    if (i < mj.n && bx >= mj.job[i].block0) j = i;
+  const vbx_mr_job jb = mj.job[j];
+  mr_role(jb, bx - jb.block0, red);
 }
 __global__ void colsum_stage2(const float* __restrict__ scratch, int C, float* __restrict__ out, int out_len, int rowmap,
                               int F) {
@@ -1755,6 +1835,19 @@ extern "C" int vbx_adaln_proj_bwd(const float* temb, const void* w_bf16, const f
   return 0;
 }
 
+extern "C" long vbx_adaln_dtemb_all_scratch_floats(int L, int B, int Th, int J) { return (long)L * cdiv(J, ADA_PER_MAX) * B * Th; }
+extern "C" int vbx_adaln_dtemb_all(const void* w_f16, const float* dada, float* dtemb, float* scratch, int L, int B, int Th, int J,
+                                   void* stream) {
+  VBX_REQUIRE(w_f16 && dada && dtemb && scratch && L > 0 && B > 0 && J > 0 && Th % 8 == 0, "vbx_adaln_dtemb_all: bad args");
+  const int spl = cdiv(J, ADA_PER_MAX);
+  hipLaunchKernelGGL(adaln_dtemb_all_kernel, dim3(cdiv(Th / 8, 256), L * spl), dim3(256), 0, ST, (const u16*)w_f16, dada, scratch, B, Th, J,
+                     spl);
+  VBX_LAUNCH_CHECK();
+  const long cols = (long)B * Th;
+  hipLaunchKernelGGL(sum_rows_wide_kernel, dim3(cdiv(cols, 32)), dim3(1024), 0, ST, scratch, (long)L * spl, cols, dtemb, cols);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int vbx_sum_rows_f32(const float* in, long rows, long ld, float* out, long cols, int accumulate, void* stream) {
   VBX_REQUIRE(in && out && rows > 0 && cols > 0, "vbx_sum_rows_f32: bad args");
   hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, ST, in, rows, ld, out, cols, accumulate);
@@ -1790,6 +1883,29 @@ extern "C" int vbx_multi_reduce(const vbx_mr_jobs* jobs, void* stream) {
     blocks += j.job[i].batches * cdiv(j.job[i].cols, 64);
   }
   hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(1024), 0, ST, j);
+  VBX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vbx_layer_reduce(const vbx_skr_jobs* sjobs, const vbx_mr_jobs* mjobs, void* stream) {
+  VBX_REQUIRE(sjobs && sjobs->n > 0 && sjobs->n <= VBX_SKR_MAX && mjobs && mjobs->n > 0 && mjobs->n <= VBX_MR_MAX,
+              "vbx_layer_reduce: bad job counts");
+  vbx_skr_jobs sj = *sjobs;
+  vbx_mr_jobs mj = *mjobs;
+  int sb = 0, mb = 0;
+  for (int i = 0; i < sj.n; i++) {
+    VBX_REQUIRE(sj.job[i].slabs && sj.job[i].dst && sj.job[i].splits >= 1 && sj.job[i].M > 0 && sj.job[i].N > 0 && sj.job[i].N % 4 == 0,
+                "vbx_layer_reduce: bad split-K job %d (N must be a multiple of 4)", i);
+    sj.job[i].block0 = sb;
+    sb += cdiv((long)sj.job[i].M * sj.job[i].N / 4, 1024);
+  }
+  for (int i = 0; i < mj.n; i++) {
+    VBX_REQUIRE(mj.job[i].src && mj.job[i].dst && mj.job[i].rows > 0 && mj.job[i].cols > 0 && mj.job[i].batches > 0,
+                "vbx_layer_reduce: bad reduction job %d", i);
+    mj.job[i].block0 = mb;
+    mb += mj.job[i].batches * cdiv(mj.job[i].cols, 64);
+  }
+  hipLaunchKernelGGL(layer_reduce_kernel, dim3(sb + mb), dim3(1024), 0, ST, sj, mj, sb);
   VBX_LAUNCH_CHECK();
   return 0;
 }

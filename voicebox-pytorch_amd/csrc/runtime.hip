@@ -113,13 +113,14 @@ struct Acts {
   u16 *hf, *hfh;
   float *pred, *per_b;
   // backward scratch
-  float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
+  float *dx, *dq, *dk, *delta, *slabs, *npart, *npart2, *cpart, *dada, *dtemb, *cs_scratch, *cs_layers, *gpart, *tmp2d, *ada_scratch, *dpre, *de, *wpart,
       *tscratch;
   u16 *dxb, *dg, *dh1, *dhn, *dO, *dqkv, *deb, *dpb, *gl_dp, *demb;
   char* attn_scratch = nullptr;  // one-pass attention backward: chain flags + running dq sums (vbx_attn_bwd_scratch_bytes)
   u16* dxb2 = nullptr;  // bf16 dx of the attention half, so that FeedForward-out's dx operand survives to the layer's grouped wgrad launch
   float* gl_ds;
   size_t slab_floats;
+  size_t np_stride = 0, cp_stride = 0, cs_stride = 0, gp_stride = 0;  // floats per layer region of npart / npart2, cpart, cs_layers, gpart
   size_t bytes;
 };
 
@@ -281,20 +282,28 @@ void carve_acts(const vbx_model* m, Acts& a) {
     if (m->unet) upd(d.D, 2 * d.D, d.M);
     a.slab_floats = sf;
     a.slabs = c.take<float>(4 * sf);  // four regions: the layer's weight-gradient slabs stay live until its batched reduce
-    a.npart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // >= the LayerNorm backward's 16-row records
-    a.npart2 = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D);  // attention pre-norm partials (batched reduce)
-    a.cpart = c.take<float>((size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D);
+    // partial records of the layer's small gradients: L regions each (vbx_model.defer_reduce: every layer keeps its own until layer 0
+    // reduces them all; otherwise region 0 is reused).  Always carved: the arena layout must not depend on a per-call switch.
+    a.np_stride = (size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D;  // >= the LayerNorm backward's 16-row records
+    a.cp_stride = (size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D;
+    a.npart = c.take<float>(a.np_stride * d.L);
+    a.npart2 = c.take<float>(a.np_stride * d.L);  // attention pre-norm partials (batched reduce)
+    a.cpart = c.take<float>(a.cp_stride * d.L);
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
     if (cs < (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp) cs = (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp;
     a.cs_scratch = c.take<float>(cs);
+    a.cs_stride = (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp;
+    a.cs_layers = c.take<float>(a.cs_stride * d.L);
     {
       const int r1 = vbx_qknorm_rope_bwd_gpart_rows(d.B), r2 = d.B * vbx_attn_bwd_fused_tiles(d.Np);
-      a.gpart = c.take<float>((size_t)2 * (r1 > r2 ? r1 : r2) * d.H * 64);
+      a.gp_stride = (size_t)2 * (r1 > r2 ? r1 : r2) * d.H * 64;
+      a.gpart = c.take<float>(a.gp_stride * d.L);
     }
     a.tmp2d = c.take<float>(2 * d.D);
-    a.ada_scratch = c.take<float>((size_t)vbx_adaln_proj_bwd_scratch_floats(d.B, d.Th, 4 * d.D));
+    a.ada_scratch = c.take<float>(std::max((size_t)vbx_adaln_proj_bwd_scratch_floats(d.B, d.Th, 4 * d.D),
+                                           (size_t)vbx_adaln_dtemb_all_scratch_floats(d.L, d.B, d.Th, 4 * d.D)));
     a.dpre = c.take<float>((size_t)d.M0 * d.D);
     a.de = c.take<float>((size_t)d.M0 * d.D);
     a.deb = c.take<u16>((size_t)d.M0 * d.D);
@@ -759,6 +768,21 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const float* x_mid = a.xs[S * l + S - 1];  // input of the feed-forward block
 
   static const bool batched = !(getenv("VBX_BATCH_REDUCE") && atoi(getenv("VBX_BATCH_REDUCE")) == 0);  // 0: one launch per reduction (A/B)
+  // adaLN weight gradients in factor form: nothing of the projections' backward is left per layer (bias gradient: two jobs of the
+  // batched reduce; d(time_emb): one launch for all layers after layer 0) -- VBX_ADALN_BWD_ALL=0: the per-layer launch (A/B)
+  static const bool ada_all_env = !(getenv("VBX_ADALN_BWD_ALL") && atoi(getenv("VBX_ADALN_BWD_ALL")) == 0);
+  const bool ada_all = ada_all_env && batched && m->adaln_factors && !m->plain_norm;
+  // vbx_model.defer_reduce: this layer's partial records stay in its own region; layer 0 reduces every layer's (VBX_DEFER_REDUCE=0: A/B).
+  // GateLoop re-uses npart for its own immediate reductions and the u-net combiner cs_scratch: those models reduce per layer.
+  static const bool defer_env = !(getenv("VBX_DEFER_REDUCE") && atoi(getenv("VBX_DEFER_REDUCE")) == 0);
+  // The per-layer adaLN backward (materialised weight gradients) consumes dada_l right away: it needs the per-layer reduce too.
+  const bool defer = defer_env && batched && m->defer_reduce && !m->gateloop && !m->unet && (m->plain_norm || ada_all);
+  const int rr = defer ? l : 0;
+  float* const npart = a.npart + rr * a.np_stride;
+  float* const npart2 = a.npart2 + rr * a.np_stride;
+  float* const cpart = a.cpart + rr * a.cp_stride;
+  float* const gpart = a.gpart + rr * a.gp_stride;
+  float* const csl = defer ? a.cs_layers + rr * a.cs_stride : a.cs_scratch;  // GEGLU-backward column-sum slabs
   // the four split-K weight-gradient reductions of the layer are deferred into one launch (own slab region each)
   static const bool batch_wg = !(getenv("VBX_BATCH_WGRAD") && atoi(getenv("VBX_BATCH_WGRAD")) == 0) && !side_stream().ok;
   vbx_skr_jobs wj{};
@@ -776,7 +800,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   if (drop_on && m->ff_dropout > 0.f)  // the same mask on the gradient of the GEGLU output
     CK(vbx_dropout_rows(nullptr, a.dg, d.M, d.Fp, d.Fp, io->drop_seed, 2u * l + 1u, m->ff_dropout, stream));
   if (batched) {  // gated-GELU backward + FeedForward[0].bias partials in one pass (reduced below)
-    CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, a.cs_scratch, stream));
+    CK(vbx_geglu_bwd_colsum(y.h1, a.dg, a.dh1, M, d.Fp, csl, stream));
   } else {
     CK(vbx_geglu_bwd(y.h1, a.dg, a.dh1, M, d.Fp, stream));
     CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
@@ -786,17 +810,17 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
-    CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, dxb_attn, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_rmsnorm_bwd(x_mid, P + o[VBX_L_N2G], 0, a.dhn, a.dx, a.dx, dxb_attn, npart, cpart, d.B, d.Np, 0, d.Np, d.D, stream));
     if (!batched) {
-      CK(vbx_reduce_norm_partials(a.npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+      CK(vbx_reduce_norm_partials(npart, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
       CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N2G], d.D, 0, stream));
     }
   } else {
-    CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, dxb_attn, a.npart, a.cpart, d.B, d.Np, 0, d.Np, d.D,
+    CK(vbx_rmsnorm_bwd(x_mid, ada_l + 2 * d.D, 4 * d.D, a.dhn, a.dx, a.dx, dxb_attn, npart, cpart, d.B, d.Np, 0, d.Np, d.D,
                        stream));
-    if (!batched) CK(vbx_reduce_norm_partials(a.npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
+    if (!batched) CK(vbx_reduce_norm_partials(npart, dada_l + 2 * d.D, 4 * d.D, d.B, chunks, d.D, 0, stream));
   }
-  if (!batched) CK(vbx_reduce_col_partials(a.cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
+  if (!batched) CK(vbx_reduce_col_partials(cpart, Gd + o[VBX_L_FF2B], a.tscratch, d.B, chunks, d.D, stream));
   // ---- Attention
   // delta = rowsum(dO * O) of the attention backward rides in this GEMM's epilogue when the tile serving it has one (128 x 256 tile:
   // gemm_epi3.hpp::Epi3BF16Delta); otherwise the attention entry point runs its own pass over O and dO.
@@ -829,12 +853,12 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     ProfScope ps("bwd attention", st);
     CK(vbx_attn_bwd_fused_dropout(y.q16, y.k16, y.qb, y.kb, y.v, io ? io->attn_mask_p : nullptr, attn_out, 1, a.dO, y.lse, a.delta, y.qrn,
                                   y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr, m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos,
-                                  m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, a.gpart, d.B, d.H, d.Np, m->attn_scale,
+                                  m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv, 3 * d.I, gpart, d.B, d.H, d.Np, m->attn_scale,
                                   a.attn_scratch, drop_on ? y.dbr : nullptr, y.dbc, m->attn_dropout, stream));
     if (m->qk_norm && !batched) {
       const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
-      CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
-      CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
     }
   } else {
     if (y.dbr && drop_on)
@@ -845,30 +869,36 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
                       a.dqkv + 2 * d.I, 3 * d.I, d.B, d.H, d.Np, m->attn_scale, a.attn_scratch, stream));
     CK(vbx_qknorm_rope_bwd(a.dq, a.dk, y.q16, y.k16, y.qrn, y.krn, m->qk_norm ? P + o[VBX_L_QG] : nullptr,
                            m->qk_norm ? P + o[VBX_L_KG] : nullptr, m->rot_cos, m->rot_sin, m->qk_norm ? 8.0f : 0.0f, a.dqkv,
-                           3 * d.I, a.gpart, d.B, d.H, d.Np, vbx_attn_q_prescale(m->attn_scale), stream));
+                           3 * d.I, gpart, d.B, d.H, d.Np, vbx_attn_q_prescale(m->attn_scale), stream));
     if (m->qk_norm) {
       const int rows = vbx_qknorm_rope_bwd_gpart_rows(d.B);
-      CK(vbx_sum_rows_f32(a.gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
-      CK(vbx_sum_rows_f32(a.gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(gpart, rows, (long)d.H * 64, Gd + o[VBX_L_QG], (long)d.H * 64, 0, stream));
+      CK(vbx_sum_rows_f32(gpart + (size_t)rows * d.H * 64, rows, (long)d.H * 64, Gd + o[VBX_L_KG], (long)d.H * 64, 0, stream));
     }
   }
   { ProfScope ps("dgrad to_qkv", st); CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st)); }
   CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp, gs));
   if (wgg.n) { ProfScope ps("wgrad (4 GEMMs)", st); CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream)); }  // every operand is still live here (a.dxb: see dxb_attn)
-  if (wj.n) { ProfScope ps("wgrad slab reduce", st); CK(vbx_splitk_reduce_multi(&wj, stream)); }
+  // VBX_LAYER_REDUCE=1: the slab reduction rides in the layer's batched reduce launch below (vbx_layer_reduce, bit-identical).
+  // MEASURED (round 5, two interleaved runs per arm on one box): 9.95-10.02 vs 9.85-9.93 ms per step -- the 16 us of slab traffic now
+  // sit behind the norm backward instead of overlapping the drain of the weight-gradient GEMM.  A loser: OFF by default.
+  static const bool fuse_red_env = getenv("VBX_LAYER_REDUCE") && atoi(getenv("VBX_LAYER_REDUCE")) != 0;
+  const bool fuse_red = fuse_red_env && batched && wj.n > 0 && !defer;
+  if (wj.n && !fuse_red) { ProfScope ps("wgrad slab reduce", st); CK(vbx_splitk_reduce_multi(&wj, stream)); }
   CK(wgrad_join(st));  // the to_out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
-    CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    CK(vbx_rmsnorm_bwd(x_in, P + o[VBX_L_N1G], 0, a.dhn, a.dx, a.dx, a.dxb, npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
     if (!batched) {
-      CK(vbx_reduce_norm_partials(a.npart2, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
+      CK(vbx_reduce_norm_partials(npart2, a.tscratch, 2 * d.D, d.B, chunks, d.D, 0, stream));
       CK(vbx_sum_rows_f32(a.tscratch, d.B, 2 * d.D, Gd + o[VBX_L_N1G], d.D, 0, stream));
     }
   } else {
-    CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, a.npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
-    if (!batched) CK(vbx_reduce_norm_partials(a.npart2, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
+    CK(vbx_rmsnorm_bwd(x_in, ada_l, 4 * d.D, a.dhn, a.dx, a.dx, a.dxb, npart2, nullptr, d.B, d.Np, 0, d.Np, d.D, stream));
+    if (!batched) CK(vbx_reduce_norm_partials(npart2, dada_l, 4 * d.D, d.B, chunks, d.D, 0, stream));
   }
   if (batched) {
-    // ---- every small reduction of the layer in ONE launch (they cost ~0.5 ms per step as separate launches)
+    // ---- every small reduction of the layer in ONE launch (they cost ~0.5 ms per step as separate launches); deferred: layer 0
+    // issues the jobs of ALL layers, six layers per launch
     vbx_mr_jobs jb{};
     auto add = [&](const float* src, float* dst, int rows, int cols, long row_stride, int batches, long sbs, long dbs, int dst_len,
                    int rowmap, int F) {
@@ -877,21 +907,47 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
       j.src_bstride = sbs; j.dst_bstride = dbs; j.dst_len = dst_len; j.rowmap = rowmap; j.F = F;
     };
     const long rec = 2L * d.D;
-    if (m->plain_norm) {  // d(gamma) = first half of the records, summed over batch and chunks
-      add(a.npart, Gd + o[VBX_L_N2G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
-      add(a.npart2, Gd + o[VBX_L_N1G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
-    } else {              // per-batch d(gamma | beta) of the two adaLN norms -> dada_l [B][g1 b1 g2 b2]
-      add(a.npart, dada_l + 2 * d.D, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
-      add(a.npart2, dada_l, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
+    auto layer_jobs = [&](int ll, int region) {  // at most 8 jobs
+      const long* ol = m->off + VBX_NG + (long)ll * VBX_NL;
+      float* dada_ll = a.dada + (size_t)ll * d.B * 4 * d.D;
+      const float* np1 = a.npart + region * a.np_stride;
+      const float* np2 = a.npart2 + region * a.np_stride;
+      const float* cp = a.cpart + region * a.cp_stride;
+      const float* gp = a.gpart + region * a.gp_stride;
+      const float* cs = defer ? a.cs_layers + region * a.cs_stride : a.cs_scratch;
+      if (m->plain_norm) {  // d(gamma) = first half of the records, summed over batch and chunks
+        add(np1, Gd + ol[VBX_L_N2G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
+        add(np2, Gd + ol[VBX_L_N1G], d.B * chunks, d.D, rec, 1, 0, 0, d.D, 0, 0);
+      } else {              // per-batch d(gamma | beta) of the two adaLN norms -> dada_l [B][g1 b1 g2 b2]
+        add(np1, dada_ll + 2 * d.D, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
+        add(np2, dada_ll, chunks, 2 * d.D, rec, d.B, (long)chunks * rec, 4L * d.D, 2 * d.D, 0, 0);
+      }
+      if (ada_all) {  // factor form: the projections' bias gradient sum_b dada[b][j] is the same records summed over batch as well
+        add(np1, Gd + ol[VBX_L_G1B] + 2 * d.D, d.B * chunks, 2 * d.D, rec, 1, 0, 0, 2 * d.D, 0, 0);
+        add(np2, Gd + ol[VBX_L_G1B], d.B * chunks, 2 * d.D, rec, 1, 0, 0, 2 * d.D, 0, 0);
+      }
+      add(cp, Gd + ol[VBX_L_FF2B], d.B * chunks, d.D, d.D, 1, 0, 0, d.D, 0, 0);                               // FeedForward[3].bias
+      add(cs, Gd + ol[VBX_L_FF1B], vbx_geglu_bwd_colsum_slabs(), 2 * d.Fp, 2L * d.Fp, 1, 0, 0, 2 * d.F, 1, d.F);   // FeedForward[0].bias
+      if (fused_qk && m->qk_norm) {
+        const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
+        add(gp, Gd + ol[VBX_L_QG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
+        add(gp + (size_t)rows * d.H * 64, Gd + ol[VBX_L_KG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
+      }
+    };
+    if (!defer) {
+      layer_jobs(l, 0);
+      if (fuse_red) { ProfScope ps("layer reduce (slabs + partials)", st); CK(vbx_layer_reduce(&wj, &jb, stream)); }
+      else CK(vbx_multi_reduce(&jb, stream));
+    } else if (l == 0) {
+      ProfScope ps("partial-record reduce, all layers", st);
+      for (int ll = d.L - 1; ll >= 0; ll--) {
+        layer_jobs(ll, ll);
+        if (jb.n + 8 > VBX_MR_MAX || ll == 0) {
+          CK(vbx_multi_reduce(&jb, stream));
+          jb.n = 0;
+        }
+      }
     }
-    add(a.cpart, Gd + o[VBX_L_FF2B], d.B * chunks, d.D, d.D, 1, 0, 0, d.D, 0, 0);                               // FeedForward[3].bias
-    add(a.cs_scratch, Gd + o[VBX_L_FF1B], vbx_geglu_bwd_colsum_slabs(), 2 * d.Fp, 2L * d.Fp, 1, 0, 0, 2 * d.F, 1, d.F);   // FeedForward[0].bias
-    if (fused_qk && m->qk_norm) {
-      const int rows = d.B * vbx_attn_bwd_fused_tiles(d.Np);
-      add(a.gpart, Gd + o[VBX_L_QG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
-      add(a.gpart + (size_t)rows * d.H * 64, Gd + o[VBX_L_KG], rows, d.H * 64, d.H * 64L, 1, 0, 0, d.H * 64, 0, 0);
-    }
-    CK(vbx_multi_reduce(&jb, stream));
   }
   if (m->gateloop) {
     // ---- GateLoop: a.dx is the gradient of x_gl = LayerNorm(s) + x0; the residual branch stays in a.dx
@@ -924,6 +980,13 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   if (m->plain_norm) return 0;
   // ---- this layer's adaLN projections (their 4 weights / 4 biases are contiguous): dW, dbias, and d(time_emb) +=
   // (adaln_factors: the weight gradient dada_l^T . temb is not materialised -- include/vbx.h, vbx_adam_adaln_factors)
+  if (ada_all) {
+    if (l == 0) {  // the layers run L-1 .. 0: every dada_l is in place
+      ProfScope ps("adaLN d(time_emb), all layers", st);
+      CK(vbx_adaln_dtemb_all(w.adah, a.dada, a.dtemb, a.ada_scratch, d.L, d.B, d.Th, 4 * d.D, stream));
+    }
+    return 0;
+  }
   CK(vbx_adaln_proj_bwd(m->stack_only ? io->cond : a.temb, w.adah + (size_t)l * 4 * d.D * d.Th, dada_l,
                         m->adaln_factors ? nullptr : Gd + o[VBX_L_G1W], Gd + o[VBX_L_G1B], a.dtemb,
                         a.ada_scratch, d.B, d.Th, 4 * d.D, l == d.L - 1 ? 0 : 1, stream));

@@ -21,7 +21,7 @@ class VbxModel(C.Structure):
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
                 ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I),
-                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F), ("adaln_factors", I)]
+                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F), ("adaln_factors", I), ("defer_reduce", I)]
 
 
 class VbxIO(C.Structure):
@@ -544,10 +544,12 @@ class Engine:
         assert self.training
         assert not adaln_factors or self.supports_adaln_factors()
         self.m.adaln_factors = int(bool(adaln_factors))
+        self.m.defer_reduce = int(on_stage is None)  # nobody reads a gradient before the last stage: one reduce for all layers
         try:
             return self._backward(gflat, gscale, on_stage)
         finally:
             self.m.adaln_factors = 0
+            self.m.defer_reduce = 0
 
     def _backward(self, gflat, gscale, on_stage):
         self.m.grads = gflat.data_ptr()
