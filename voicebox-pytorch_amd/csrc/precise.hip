@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_f32_kernel(const float* __res
 // Attend.forward (attend.py:121-135) in fp32: softmax(scale q k^T + key mask) v, flash-style with a lane per query row.
 // Block = 256 threads = 256 queries of one (b, h); keys stream through LDS in tiles of 64, scores in register chunks of 16.
 constexpr int PA_KT = 64, PA_CH = 16;
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const uint8_t* __restrict__ mask,
                                                            float* __restrict__ o32, u16* __restrict__ o16, u16* __restrict__ ob,
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
   }
   float m = -1e30f, l = 0.f;
   // attention dropout (attend.py:131): keep bit (key % 32) of word key / 32 of this query's row (ops.hip::attn_dropout_bits_kernel)
-  const unsigned* brow = bits_rm ? bits_rm + ((long)bh * Np + (qok ? qi : 0)) * W2 : nullptr;
+  const unsigned* brow = DROP ? bits_rm + ((long)bh * Np + (qok ? qi : 0)) * W2 : nullptr;
   for (int k0 = 0; k0 < Np; k0 += PA_KT) {
     __syncthreads();
     for (int i = threadIdx.x; i < PA_KT * 16; i += 256) {
@@ -213,12 +214,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int d = 0; d < 64; d++) acc[d] *= alpha;
       static_assert(PA_CH == 16, "a chunk is one half of a keep-bit word");
-      const unsigned kbits = brow ? brow[(k0 + c0) >> 5] >> ((k0 + c0) & 31) : 0xFFFFu;
+      unsigned kbits = 0xFFFFu;
+      if (DROP) kbits = brow[(k0 + c0) >> 5] >> ((k0 + c0) & 31);
 #pragma unroll
       for (int j = 0; j < PA_CH; j++) {
         float p = valid_s[c0 + j] != 0.f ? exp2f(s[j] - mn) : 0.f;
         l += p;  // the normaliser is that of the undropped probabilities
-        if (brow) p = ((kbits >> j) & 1u) ? p * rkeep : 0.f;
+        if (DROP) p = ((kbits >> j) & 1u) ? p * rkeep : 0.f;
 #pragma unroll
         for (int d = 0; d < 64; d += 4) {
           const float4 vv = *reinterpret_cast<const float4*>(&Vs[c0 + j][d]);
@@ -317,7 +319,7 @@ extern "C" int vbx_attn_fwd_f32_dropout(const float* q, const float* k, const fl
                                         void* out_bf16, float* lse, int B, int H, int Np, float scale, const void* bits_rm, float p,
                                         void* stream) {
   VBX_REQUIRE(q && k && v && out32 && bits_rm && B > 0 && H > 0 && Np > 0 && p > 0.f && p < 1.f, "vbx_attn_fwd_f32_dropout: bad args");
-  hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16, (u16*)out_bf16,
+  hipLaunchKernelGGL(attn_fwd_f32_kernel<true>, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16, (u16*)out_bf16,
                      lse, H, Np, scale * 1.44269504088896340736f, (const unsigned*)bits_rm, vbx_dropout_bits_words(Np),
                      vbx_dropout_keep_scale(p));
   VBX_LAUNCH_CHECK();
@@ -326,7 +328,7 @@ extern "C" int vbx_attn_fwd_f32_dropout(const float* q, const float* k, const fl
 extern "C" int vbx_attn_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out32, void* out16,
                                 void* out_bf16, float* lse, int B, int H, int Np, float scale, void* stream) {
   VBX_REQUIRE(q && k && v && out32 && B > 0 && H > 0 && Np > 0, "vbx_attn_fwd_f32: bad args");
-  hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16,
+  hipLaunchKernelGGL(attn_fwd_f32_kernel<false>, dim3(cdiv(Np, 256), B * H), dim3(256), 0, ST, q, k, v, mask, out32, (u16*)out16,
                      (u16*)out_bf16, lse, H, Np, scale * 1.44269504088896340736f, (const unsigned*)nullptr, 0, 1.0f);
   VBX_LAUNCH_CHECK();
   return 0;

@@ -936,10 +936,10 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     };
     if (!defer) {
       layer_jobs(l, 0);
-      if (fuse_red) { ProfScope ps("layer reduce (slabs + partials)", st); CK(vbx_layer_reduce(&wj, &jb, stream)); }
+      if (fuse_red) { ProfScope ps("layer reduce (fused)", st); CK(vbx_layer_reduce(&wj, &jb, stream)); }
       else CK(vbx_multi_reduce(&jb, stream));
     } else if (l == 0) {
-      ProfScope ps("partial-record reduce, all layers", st);
+      ProfScope ps("partials reduce (all)", st);
       for (int ll = d.L - 1; ll >= 0; ll--) {
         layer_jobs(ll, ll);
         if (jb.n + 8 > VBX_MR_MAX || ll == 0) {
@@ -982,7 +982,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   // (adaln_factors: the weight gradient dada_l^T . temb is not materialised -- include/vbx.h, vbx_adam_adaln_factors)
   if (ada_all) {
     if (l == 0) {  // the layers run L-1 .. 0: every dada_l is in place
-      ProfScope ps("adaLN d(time_emb), all layers", st);
+      ProfScope ps("adaLN dtemb (all)", st);
       CK(vbx_adaln_dtemb_all(w.adah, a.dada, a.dtemb, a.ada_scratch, d.L, d.B, d.Th, 4 * d.D, stream));
     }
     return 0;
