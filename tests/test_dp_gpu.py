@@ -274,6 +274,52 @@ def test_adaln_factor_mode_equals_materialised_gradients():
             assert torch.equal(ga, gb), slot
 
 
+def test_deferred_reductions_equal_per_layer_reductions():
+    """vbx_model.defer_reduce (round 5): without a per-stage reader (no gradient exchange) the partial-record reductions of every layer
+    -- norm gamma / beta, bias column sums, qk-norm gammas -- run in two launches after layer 0 instead of one launch per layer, and
+    d(time_emb) of all layers in one launch.  Same per-tensor summation order: the gradient buffer must be BIT-identical to the one a
+    per-stage reader sees (on_stage given: every layer reduces before it returns), and each stage's range must be final when its
+    callback fires (checked against the end-of-backward values)."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+    from oracle import restate
+
+    cfg = restate.Cfg(dim=128, depth=4, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=5)
+    for k in state:
+        if ".to_gamma." in k or ".to_beta." in k:
+            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(hash(k) % 1000))
+    d = _draws(77, 3, 100, 128)
+    draws = {k: v for k, v in d.items() if k != "x1"}
+    vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=4, dim_head=64, heads=2, condition_on_text=False)
+    vb.load_state_dict(state, strict=False)
+    ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to(dev)), lr=1e-3, max_grad_norm=0.5)
+    out = {}
+    for factors in (True, False):
+        ts.gflat.fill_(7.0)
+        with rng_override(**draws):
+            ts._forward_backward(d["x1"].to(dev), None, None, on_stage=None, adaln_factors=factors)
+        torch.cuda.synchronize()
+        deferred = ts.gflat.clone()
+        seen = {}
+
+        def cb(i, rng):  # what a per-stage reader (the bucket reducer) would pick up
+            seen[i] = (rng, ts.gflat[rng[0]:rng[1]].clone())
+
+        ts.gflat.fill_(7.0)
+        with rng_override(**draws):
+            ts._forward_backward(d["x1"].to(dev), None, None, on_stage=cb, adaln_factors=factors)
+        torch.cuda.synchronize()
+        staged = ts.gflat.clone()
+        assert torch.equal(deferred, staged), float((deferred - staged).abs().max())
+        assert len(seen) == cfg.depth + 2
+        for i, ((lo, hi), snap) in seen.items():
+            assert torch.equal(snap, staged[lo:hi]), i  # final when the callback fired
+        out[factors] = staged
+    assert not torch.equal(out[True], out[False])  # (the factor form leaves the adaLN weight blocks at the sentinel)
+
+
 def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
     """wd > 0 (optimizer.py:10-35): AdamW with decoupled decay on the ndim >= 2 parameters only.  TrainStep(wd=...) must equal torch:
     the same gradients -> clip_grad_norm_(0.5) -> torch.optim.AdamW over get_optimizer's two parameter groups; and the trainer's
