@@ -8,6 +8,8 @@ import os
 import socket
 import sys
 
+import zlib
+
 import pytest
 import torch
 import torch.distributed as dist
@@ -216,7 +218,7 @@ def test_adaln_factor_mode_equals_materialised_gradients():
     state = restate.init_state_dict(cfg, seed=11)
     for k in state:  # the reference zero-initialises the adaLN projections (:264-268): randomise them so that they matter
         if ".to_gamma." in k or ".to_beta." in k:
-            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(hash(k) % 1000))
+            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000))
     d = _draws(321, 3, 72, 128)
     runs = {}
     for mode in ("materialize", "factors"):
@@ -235,7 +237,9 @@ def test_adaln_factor_mode_equals_materialised_gradients():
         runs[mode] = dict(rec=rec, g=ts.gflat.clone(), p0=p0, ranges=ts.adaln_weight_ranges(), fp=ts.fp)
     a, b = runs["materialize"], runs["factors"]
     for step, ((la, ca, pa), (lb, cb, pb)) in enumerate(zip(a["rec"], b["rec"])):
-        assert abs(la - lb) < 1e-6 * max(1.0, abs(la)) if step == 0 else abs(la - lb) < 2e-3, (step, la, lb)  # (later steps: chaotic init)
+        # step 0: the same forward.  Step 1: a forward at parameters that agree to 1e-4 per tensor.  Step 2: two updates in, at this
+        # (reference-style, chaotic) init the trajectories have separated -- 2e-3 .. 9e-3 over perturbation draws; only sanity is asserted
+        assert abs(la - lb) < (1e-6 * max(1.0, abs(la)), 2e-3, 5e-2)[step], (step, la, lb)
         if step == 0:
             assert float((ca - cb).abs().max() / ca.abs().max()) < 1e-5, (ca, cb)  # clip coefficient and norm
             fp = a["fp"]
@@ -289,7 +293,7 @@ def test_deferred_reductions_equal_per_layer_reductions():
     state = restate.init_state_dict(cfg, seed=5)
     for k in state:
         if ".to_gamma." in k or ".to_beta." in k:
-            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(hash(k) % 1000))
+            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000))
     d = _draws(77, 3, 100, 128)
     draws = {k: v for k, v in d.items() if k != "x1"}
     vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=4, dim_head=64, heads=2, condition_on_text=False)
