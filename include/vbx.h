@@ -362,6 +362,8 @@ int vbx_layernorm_bwd(const float* s, const float* w, const float* dy, float* ds
 typedef struct {
   const float* slabs;
   float* dst;
+  float* sq;  /* NULL, or vbx_splitk_reduce_blocks(M, N) floats: sq[b] = sum of squares of the values block b stored (a fixed summation
+                 order: the same bits on every run) -- the gradient-norm terms of this tensor without a second pass over it */
   int splits, M, N, dst_rows, dst_cols, dst_ld, rowmap, F, block0, pad_;
 } vbx_skr_job;
 typedef struct {
@@ -369,6 +371,7 @@ typedef struct {
   int n;
 } vbx_skr_jobs;
 int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream);
+int vbx_splitk_reduce_blocks(int M, int N); /* blocks (= sq partials) of one job */
 /* Several small column reductions in one launch: for job i, out[b][map(c)] = sum over r < rows of
  * src[b*src_bstride + r*row_stride + c], c < cols, b < batches; map = identity or the GEGLU row un-interleave (rowmap = 1, F), columns
  * mapping outside [0, dst_len) are dropped.  block0 is filled in by the library. */
@@ -425,7 +428,7 @@ int vbx_sumsq(const float* x, long n, float* out, float* scratch, void* stream);
  * mode the backward entry points leave that block of the gradient buffer UNWRITTEN and the optimizer works from the factors:
  *   vbx_sumsq_adaln_factors : the L * B * B terms (dada_l[b] . dada_l[b']) (temb[b] . temb[b']) whose sum over (b, b') is
  *                             |dada_l^T . temb|_F^2 -> out[(l * B + b) * B + b'];
- *   vbx_sumsq_ranges        : sum of squares over n <= 32 ranges [lo, hi) of x (host array of 2 n longs, multiples of 4 floats)
+ *   vbx_sumsq_ranges        : sum of squares over n <= 64 ranges [lo, hi) of x (host array of 2 n longs, multiples of 4 floats)
  *                             plus n_extra values already stored at scratch[1024 ..) -> out[0]; scratch >= 1024 + n_extra floats;
  *   vbx_adam_adaln_factors  : torch.optim.Adam (as vbx_adam_step) on the L blocks at flat offsets w_off[l] with the gradient
  *                             expanded on the fly, refreshing the fp16 operand copies dst_f16[l] ([J4][Th]; may be NULL).
@@ -504,6 +507,11 @@ typedef struct {
                              column sums, qk-norm gammas) in its own arena region and layer 0 reduces them all in two launches
                              instead of one launch per layer.  0 (default): each layer's small gradients are final when it returns.
                              Same per-tensor summation order either way. */
+  float* sq_partials;     /* NULL, or vbx_model_sq_partials(m, NULL) floats of device memory: the slab reduce of every layer's four
+                             weight-gradient matrices (to_qkv, to_out, FeedForward in / out) also leaves the sums of squares of what it
+                             stored, one float per block -- the gradient norm then needs no second pass over those tensors (their
+                             flat ranges: vbx_model_sq_partials).  Meaningful only when the norm is taken over THIS backward's
+                             gradient (no accumulation, no exchange in between). */
 } vbx_model;
 
 typedef struct {
@@ -538,6 +546,9 @@ int vbx_model_pack_weights(const vbx_model* m, void* stream);
  * temb [B][Th]; w_off[l] = flat offset of layer l's weight block, dst_f16[l] = its fp16 operand copy in the wpack arena (HOST arrays
  * of L entries each, either may be NULL) */
 int vbx_model_adaln_factors(const vbx_model* m, const float** dada, const float** temb, long* w_off, void** dst_f16);
+/* floats vbx_model.sq_partials must hold (0: this configuration does not serve it), and -- ranges != NULL -- the 4 * L flat ranges
+ * [lo, hi) of the gradient buffer they cover, in ascending order */
+long vbx_model_sq_partials(const vbx_model* m, long* ranges /* host [4 * L][2] or NULL */);
 /* segment table for vbx_adam_step_packed (see there) */
 int vbx_model_adam_segments(const vbx_model* m, long n_flat, vbx_adam_seg* out, int max_segs, long* total_blocks);
 int vbx_model_forward(const vbx_model* m, const vbx_io* io, void* stream);

@@ -324,6 +324,52 @@ def test_deferred_reductions_equal_per_layer_reductions():
     assert not torch.equal(out[True], out[False])  # (the factor form leaves the adaLN weight blocks at the sentinel)
 
 
+def test_gradient_norm_from_slab_reduce_partials(monkeypatch):
+    """The clip norm without a second pass over the big weight gradients (round 5): the slab reduce of every layer's to_qkv / to_out /
+    FeedForward weight gradients leaves per-block sums of squares (vbx_skr_job.sq, vbx_model.sq_partials); TrainStep adds them to the
+    factor terms and to a pass over the small tensors only.  Against the plain pass (VBX_SUMSQ_FOLD=0) from the same weights and draws:
+    the same norm and clip coefficient to fp32 rounding, identical gradients, parameters equal to rounding after the step -- and against
+    torch's own norm of the materialised gradient."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+    from voicebox_pytorch_amd.masks import rng_override
+    from oracle import restate
+
+    cfg = restate.Cfg(dim=128, depth=2, heads=2, dim_head=64)
+    state = restate.init_state_dict(cfg, seed=21)
+    for k in state:
+        if ".to_gamma." in k or ".to_beta." in k:
+            state[k] = state[k] + 0.05 * torch.randn(state[k].shape, generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000))
+    d = _draws(9, 3, 88, 128)
+    draws = {k: v for k, v in d.items() if k != "x1"}
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("VBX_SUMSQ_FOLD", fold)
+        vb = vbx.VoiceBox(dim=128, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+        vb.load_state_dict(state, strict=False)
+        ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb.to(dev)), lr=1e-3, max_grad_norm=0.5)
+        assert ts.adaln_factors_apply()
+        with rng_override(**draws):
+            ts.step(d["x1"].to(dev))
+        torch.cuda.synchronize()
+        assert bool(getattr(ts, "_sq_folded", False)) == (fold == "1")
+        res[fold] = (ts.coef.clone().cpu(), ts.gflat.clone(), ts.fp.flat.clone(), ts)
+    (ca, ga, pa, tsa), (cb, gb, pb, _) = res["1"], res["0"]
+    assert float((ca - cb).abs().max() / cb.abs().max()) < 2e-6, (ca, cb)
+    inside = torch.zeros_like(ga, dtype=torch.bool)
+    for lo, hi in tsa.adaln_weight_ranges():
+        inside[lo:hi] = True
+    assert torch.equal(ga[~inside], gb[~inside])
+    assert float((pa - pb).abs().max()) < 1e-6
+    # torch's norm of the full gradient: materialise the factor-form blocks (dada_l^T . temb) and take the norm on the host in fp64
+    eng = tsa._last_eng
+    dada, temb = eng.adaln_factor_tensors()
+    full = ga.double().cpu().clone()
+    for l, (lo, hi) in enumerate(tsa.adaln_weight_ranges()):
+        full[lo:hi] = (dada[l].double().t() @ temb.double()).reshape(-1).cpu()
+    assert abs(float(ca[1]) - float(full.norm())) < 2e-6 * float(full.norm()), (float(ca[1]), float(full.norm()))
+
+
 def test_adamw_weight_decay_matches_get_optimizer(tmp_path, golden):
     """wd > 0 (optimizer.py:10-35): AdamW with decoupled decay on the ndim >= 2 parameters only.  TrainStep(wd=...) must equal torch:
     the same gradients -> clip_grad_norm_(0.5) -> torch.optim.AdamW over get_optimizer's two parameter groups; and the trainer's

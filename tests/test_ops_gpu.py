@@ -872,7 +872,7 @@ def test_layer_reduce_equals_the_two_launches(L):
     import ctypes as C
 
     class SJob(C.Structure):
-        _fields_ = [("slabs", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int) for n in
+        _fields_ = [("slabs", C.c_void_p), ("dst", C.c_void_p), ("sq", C.c_void_p)] + [(n, C.c_int) for n in
                     ("splits", "M", "N", "dst_rows", "dst_cols", "dst_ld", "rowmap", "F", "block0", "pad_")]
 
     class SJobs(C.Structure):
@@ -893,6 +893,10 @@ def test_layer_reduce_equals_the_two_launches(L):
     x0 = torch.randn(130, 300, generator=g).to(dev)
     x1 = torch.randn(3, 37, 100, generator=g).to(dev)
 
+    lib0 = L.lib()
+    lib0.vbx_splitk_reduce_blocks.argtypes = [C.c_int, C.c_int]
+    sqs = [torch.full((lib0.vbx_splitk_reduce_blocks(M, N),), float("nan"), device=dev) for _, M, N, *_ in specs]
+
     def run(fused):
         outs = [torch.full((dr, dc), 7.0, device=dev) for _, _, _, dr, dc, _, _ in specs]
         o0, o1 = torch.full((300,), 7.0, device=dev), torch.full((3, 80), 7.0, device=dev)
@@ -901,6 +905,7 @@ def test_layer_reduce_equals_the_two_launches(L):
         for i, (sp, M, N, dr, dc, rm, F) in enumerate(specs):
             j = sj.job[i]
             j.slabs, j.dst, j.splits, j.M, j.N, j.dst_rows, j.dst_cols, j.dst_ld, j.rowmap, j.F = slabs[i].data_ptr(), outs[i].data_ptr(), sp, M, N, dr, dc, dc, rm, F
+            j.sq = None if fused else sqs[i].data_ptr()  # vbx_skr_job.sq: per-block sums of squares of what was stored (multi launch only)
         a, b = mj.job[0], mj.job[1]
         a.src, a.dst, a.rows, a.cols, a.row_stride, a.batches, a.dst_len = x0.data_ptr(), o0.data_ptr(), 130, 300, 300, 1, 300
         b.src, b.dst, b.rows, b.cols, b.row_stride, b.batches = x1.data_ptr(), o1.data_ptr(), 37, 64, 100, 3
@@ -922,6 +927,14 @@ def test_layer_reduce_equals_the_two_launches(L):
         assert torch.equal(a, b)
     assert rel_err(fus[0], slabs[0].double().sum(0)) < 1e-6 and rel_err(fus[3], x0.double().sum(0)) < 1e-6
     assert rel_err(fus[2], slabs[2].double().sum(0)[:, :1026]) < 1e-6  # ragged: unaligned row stride, columns past dst_cols dropped
+    # the gradient-norm partials: sum over blocks = sum of squares of exactly the stored values (dropped GEGLU rows / columns excluded),
+    # and the same bits on a second run
+    first = [q.clone() for q in sqs]
+    run(False)
+    for i, q in enumerate(sqs):
+        assert torch.equal(q, first[i])
+        want = float(sep[i].double().pow(2).sum())
+        assert abs(float(q.double().sum()) - want) < 1e-6 * want, (i, float(q.double().sum()), want)
 
 
 def test_geglu_bwd_and_colsum(L):

@@ -1157,7 +1157,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(vbx_skr_jobs j
   for (int i = 1; i < VBX_SKR_MAX; i++)
     if (i < jobs.n && (int)blockIdx.x >= jobs.job[i].block0) j = i;
   const vbx_skr_job jb = jobs.job[j];
-  skr_role(jb, ((long)(blockIdx.x - jb.block0) * 256 + threadIdx.x) * 4);  // N % 4 == 0: four columns of one row (reduce_roles.hpp)
+  const float sq = skr_role(jb, ((long)(blockIdx.x - jb.block0) * 256 + threadIdx.x) * 4);  // N % 4 == 0: four columns of one row
+  if (jb.sq) {  // block-uniform: the gradient-norm partial of this block (vbx_skr_job.sq)
+    __shared__ float wsum[4];
+    const float t = block_sum_fixed(sq, wsum);
+    if (threadIdx.x == 0) jb.sq[blockIdx.x - jb.block0] = t;
+  }
 }
 
 }  // namespace
@@ -1314,6 +1319,7 @@ extern "C" int vbx_splitk_reduce(const float* slabs, int splits, int M, int N, f
   return 0;
 }
 
+extern "C" int vbx_splitk_reduce_blocks(int M, int N) { return cdiv((long)M * N / 4, 256); }
 extern "C" int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream) {
   VBX_REQUIRE(jobs && jobs->n > 0 && jobs->n <= VBX_SKR_MAX, "vbx_splitk_reduce_multi: bad job count");
   vbx_skr_jobs j = *jobs;
@@ -1322,7 +1328,7 @@ extern "C" int vbx_splitk_reduce_multi(const vbx_skr_jobs* jobs, void* stream) {
     VBX_REQUIRE(j.job[i].slabs && j.job[i].dst && j.job[i].splits >= 1 && j.job[i].M > 0 && j.job[i].N > 0 && j.job[i].N % 4 == 0,
                 "vbx_splitk_reduce_multi: bad job %d (N must be a multiple of 4)", i);
     j.job[i].block0 = blocks;
-    blocks += cdiv((long)j.job[i].M * j.job[i].N / 4, 256);
+    blocks += vbx_splitk_reduce_blocks(j.job[i].M, j.job[i].N);
   }
   hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, j);
   VBX_LAUNCH_CHECK();

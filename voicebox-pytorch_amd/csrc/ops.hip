@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(1024) void layer_reduce_kernel(vbx_skr_jobs sj, vbx
     for (int i = 1; i < VBX_SKR_MAX; i++)
       if (i < sj.n && (int)blockIdx.x >= sj.job[i].block0) j = i;
     const vbx_skr_job jb = sj.job[j];
-    skr_role(jb, ((long)(blockIdx.x - jb.block0) * 1024 + threadIdx.x) * 4);
+    (void)skr_role(jb, ((long)(blockIdx.x - jb.block0) * 1024 + threadIdx.x) * 4);  // (no gradient-norm partials here: sq must be NULL)
     return;
   }
   const int bx = blockIdx.x - skr_blocks;
@@ -1431,14 +1431,14 @@ __global__ __launch_bounds__(256) void adaln_factor_sumsq_kernel(const float* __
 }
 // sum of squares over up to 32 ranges [lo, hi) of a flat buffer (every lo / hi a multiple of 4 floats, 16-byte aligned base):
 // the flat gradient buffer minus the adaLN weight blocks that stay in factor form
-struct SumsqRanges { long lo[32], pre[33]; int n; };  // pre[k] = float4 count of ranges 0..k-1
+struct SumsqRanges { long lo[64], pre[65]; int n; };  // pre[k] = float4 count of ranges 0..k-1
 __global__ __launch_bounds__(256) void sumsq_ranges_stage1(const float* __restrict__ x, const SumsqRanges rg, float* __restrict__ scratch) {
   // the virtual concatenation of the ranges is cut into gridDim.x contiguous chunks; the table sits in LDS (indexing a kernel-argument
   // array by a run-time value made the first version walk scratch memory: 79 us for 209 MB)
-  __shared__ long slo[32], spre[33];
+  __shared__ long slo[64], spre[65];
   __shared__ float red[4];
-  if (threadIdx.x < 32) slo[threadIdx.x] = rg.lo[threadIdx.x];
-  if (threadIdx.x < 33) spre[threadIdx.x] = rg.pre[threadIdx.x];
+  if (threadIdx.x < 64) slo[threadIdx.x] = rg.lo[threadIdx.x];
+  if (threadIdx.x < 65) spre[threadIdx.x] = rg.pre[threadIdx.x];
   __syncthreads();
   const int n = rg.n;
   const long n4 = spre[n];
@@ -1507,6 +1507,28 @@ __global__ void sumsq_stage2(const float* __restrict__ scratch, int nb, float* _
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+// out[0] = sum of a[0 .. na) and b[0 .. nb) (block partials, then the extra terms), a fixed summation order; one block of 1024
+__global__ __launch_bounds__(1024) void sumsq_stage2_two(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                         float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < na; i += 1024) s += a[i];
+  int i = threadIdx.x;
+  for (; i + 3072 < nb; i += 4096) {  // four loads in flight per lane
+    const float v0 = b[i], v1 = b[i + 1024], v2 = b[i + 2048], v3 = b[i + 3072];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; i < nb; i += 1024) s += b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += red[w];
+    out[0] = t;
+  }
 }
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float inv_world, float* __restrict__ coef) {
   // gradients in the buffer are SUMS over `world` ranks: g = buf * inv_world.
@@ -1894,8 +1916,9 @@ extern "C" int vbx_layer_reduce(const vbx_skr_jobs* sjobs, const vbx_mr_jobs* mj
   vbx_mr_jobs mj = *mjobs;
   int sb = 0, mb = 0;
   for (int i = 0; i < sj.n; i++) {
-    VBX_REQUIRE(sj.job[i].slabs && sj.job[i].dst && sj.job[i].splits >= 1 && sj.job[i].M > 0 && sj.job[i].N > 0 && sj.job[i].N % 4 == 0,
-                "vbx_layer_reduce: bad split-K job %d (N must be a multiple of 4)", i);
+    VBX_REQUIRE(sj.job[i].slabs && sj.job[i].dst && sj.job[i].splits >= 1 && sj.job[i].M > 0 && sj.job[i].N > 0 && sj.job[i].N % 4 == 0 &&
+                    !sj.job[i].sq,
+                "vbx_layer_reduce: bad split-K job %d (N must be a multiple of 4; sq partials are served by vbx_splitk_reduce_multi only)", i);
     sj.job[i].block0 = sb;
     sb += cdiv((long)sj.job[i].M * sj.job[i].N / 4, 1024);
   }
@@ -2058,11 +2081,12 @@ extern "C" int vbx_sumsq(const float* x, long n, float* out, float* scratch, voi
   VBX_LAUNCH_CHECK();
   return 0;
 }
-// sum of squares over n <= 32 ranges [lo_k, hi_k) of x (floats; multiples of 4) plus n_extra values already sitting in
-// scratch[1024 .. 1024 + n_extra) (the factor-form terms of vbx_model_sumsq_adaln_factors) -> out[0].  scratch >= 1024 + n_extra floats.
+// sum of squares over n <= 64 ranges [lo_k, hi_k) of x (floats; multiples of 4) plus n_extra values already sitting in
+// scratch[1024 .. 1024 + n_extra) (the factor-form terms of vbx_sumsq_adaln_factors, the slab-reduce partials of vbx_skr_job.sq)
+// -> out[0].  scratch >= 1024 + n_extra floats.
 extern "C" int vbx_sumsq_ranges(const float* x, const long* ranges /* host [2 n] */, int n, int n_extra, float* out, float* scratch,
                                 void* stream) {
-  VBX_REQUIRE(x && ranges && out && scratch && n > 0 && n <= 32 && n_extra >= 0 && ((size_t)x & 15) == 0, "vbx_sumsq_ranges: bad args");
+  VBX_REQUIRE(x && ranges && out && scratch && n > 0 && n <= 64 && n_extra >= 0 && ((size_t)x & 15) == 0, "vbx_sumsq_ranges: bad args");
   SumsqRanges rg;
   rg.n = n;
   rg.pre[0] = 0;
@@ -2075,13 +2099,7 @@ extern "C" int vbx_sumsq_ranges(const float* x, const long* ranges /* host [2 n]
   const int nb = grid_for(rg.pre[n] * 4, 1024);
   hipLaunchKernelGGL(sumsq_ranges_stage1, dim3(nb), dim3(256), 0, ST, x, rg, scratch);
   VBX_LAUNCH_CHECK();
-  if (n_extra > 0) {  // append the extra terms behind the block partials (stage 2 sums a contiguous run)
-    if (hipMemcpyAsync(scratch + nb, scratch + 1024, (size_t)n_extra * sizeof(float), hipMemcpyDeviceToDevice, ST) != hipSuccess) {
-      vbx_set_error("vbx_sumsq_ranges: copy of the extra terms failed");
-      return VBX_EINVAL;
-    }
-  }
-  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, ST, scratch, nb + n_extra, out);
+  hipLaunchKernelGGL(sumsq_stage2_two, dim3(1), dim3(1024), 0, ST, scratch, nb, scratch + 1024, n_extra, out);
   VBX_LAUNCH_CHECK();
   return 0;
 }

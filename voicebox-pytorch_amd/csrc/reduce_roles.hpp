@@ -3,14 +3,15 @@
 #pragma once
 #include "common.hpp"
 
-// split-K slab reduction of four columns of one row: i4 = flat index (multiple of 4) into the [M, N] result of job jb
-VBX_DEV void skr_role(const vbx_skr_job& jb, long i4) {
+// split-K slab reduction of four columns of one row: i4 = flat index (multiple of 4) into the [M, N] result of job jb.
+// Returns the sum of squares of the values it STORED (0 for dropped rows / columns): the gradient-norm term of this thread.
+VBX_DEV float skr_role(const vbx_skr_job& jb, long i4) {
   const long total = (long)jb.M * jb.N;
-  if (i4 >= total) return;
+  if (i4 >= total) return 0.f;
   const int r = (int)(i4 / jb.N), c = (int)(i4 - (long)r * jb.N);
   int dr = r;
   if (jb.rowmap == 1) dr = geglu_row_unmap(r, jb.F);
-  if (dr < 0 || dr >= jb.dst_rows) return;
+  if (dr < 0 || dr >= jb.dst_rows) return 0.f;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* sp = jb.slabs + i4;
   int k = 0;
@@ -26,13 +27,30 @@ VBX_DEV void skr_role(const vbx_skr_job& jb, long i4) {
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   float* o = jb.dst + (long)dr * jb.dst_ld + c;
+  float sq = 0.f;
   if (c + 3 < jb.dst_cols && (jb.dst_ld & 3) == 0) {
     *reinterpret_cast<float4*>(o) = s;
+    sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
   } else {
     const float t[4] = {s.x, s.y, s.z, s.w};
     for (int e = 0; e < 4; e++)
-      if (c + e < jb.dst_cols) o[e] = t[e];
+      if (c + e < jb.dst_cols) { o[e] = t[e]; sq += t[e] * t[e]; }
   }
+  return sq;
+}
+
+// Block sum in a FIXED order (wave butterfly, then the wave partials in index order): the same value on every run.  Every thread of
+// the block must call it; the result is valid in thread 0.  wsum: >= blockDim.x / 64 floats of LDS.
+VBX_DEV float block_sum_fixed(float v, float* wsum) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) wsum[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; w++) t += wsum[w];
+  return t;
 }
 
 // column reduction of job jb by a 1024-thread block (64 columns x 16 row lanes); local = block index inside the job

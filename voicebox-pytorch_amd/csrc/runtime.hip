@@ -463,7 +463,8 @@ int wgrad_join(hipStream_t st) {
 }
 // dW[I,J] = P[K,I]^T . Q[K,J]  -> grads (fp32, reference layout [dst_rows, dst_cols])
 int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, float* slabs, float* dst, int dst_rows,
-          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr, WgradGroup* grp = nullptr, int group_splits = 0) {
+          int dst_cols, int rowmap, int F, hipStream_t st, vbx_skr_jobs* defer = nullptr, WgradGroup* grp = nullptr, int group_splits = 0,
+          float* sq = nullptr /* vbx_skr_job.sq of the deferred reduction */) {
   vbx_gemm_desc g{};
   const bool grouped = grp && defer && J % 4 == 0 && defer->n < VBX_SKR_MAX && grp->n < 4;
   const int splits = (grouped && group_splits > 0) ? group_splits : wgrad_splits(I, J, K);
@@ -473,7 +474,7 @@ int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, fl
     grp->d[grp->n++] = g;
     vbx_skr_job& jb = defer->job[defer->n++];
     jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
-    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F;
+    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F; jb.sq = sq;
     return 0;
   }
   SideStream& ss = side_stream();
@@ -489,7 +490,7 @@ int wgrad(const u16* P, int ldp, const u16* Q, int ldq, int I, int J, long K, fl
   if (defer && J % 4 == 0 && defer->n < VBX_SKR_MAX) {  // reduced later, together with the layer's other weight gradients
     vbx_skr_job& jb = defer->job[defer->n++];
     jb.slabs = slabs; jb.dst = dst; jb.splits = splits; jb.M = I; jb.N = J; jb.dst_rows = dst_rows; jb.dst_cols = dst_cols;
-    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F;
+    jb.dst_ld = dst_cols; jb.rowmap = rowmap; jb.F = F; jb.sq = sq;
   } else {
     CK(vbx_splitk_reduce(slabs, splits, I, J, dst, dst_rows, dst_cols, dst_cols, rowmap, F, 0, run));
   }
@@ -746,6 +747,41 @@ static int backward_head_impl(const vbx_model* m, const vbx_io* io, const float*
   return 0;
 }
 
+// the four split-K weight-gradient reductions of a layer are deferred into one launch (own slab region each); VBX_BATCH_WGRAD=0: A/B
+static bool batch_wgrad_on() {
+  static const bool on = !(getenv("VBX_BATCH_WGRAD") && atoi(getenv("VBX_BATCH_WGRAD")) == 0) && !side_stream().ok;
+  return on;
+}
+// vbx_model.sq_partials: blocks of the layer's four deferred reductions in the order backward_layer_impl issues them
+struct SqLayout { long off[4], per_layer; };  // FeedForward-out, FeedForward-in, to_out, to_qkv
+static SqLayout sq_layout(const Dims& d) {
+  SqLayout q;
+  const long n[4] = {vbx_splitk_reduce_blocks(d.D, d.Fp), vbx_splitk_reduce_blocks(2 * d.Fp, d.D), vbx_splitk_reduce_blocks(d.D, d.I),
+                     vbx_splitk_reduce_blocks(3 * d.I, d.D)};
+  q.off[0] = 0;
+  for (int i = 1; i < 4; i++) q.off[i] = q.off[i - 1] + n[i - 1];
+  q.per_layer = q.off[3] + n[3];
+  return q;
+}
+extern "C" long vbx_model_sq_partials(const vbx_model* m, long* ranges) {
+  if (check_model(m) != 0) return 0;
+  if (!batch_wgrad_on()) return 0;
+  const Dims d = dims_of(m);
+  if (ranges) {
+    for (int l = 0; l < d.L; l++) {  // the flat layout holds them in this order (engine.py L_NAMES / VBX_L_*)
+      const long* o = m->off + VBX_NG + (long)l * VBX_NL;
+      const long lo[4] = {o[VBX_L_QKVW], o[VBX_L_OUTW], o[VBX_L_FF1W], o[VBX_L_FF2W]};
+      const long sz[4] = {3L * d.I * d.D, (long)d.D * d.I, 2L * d.F * d.D, (long)d.D * d.F};
+      for (int i = 0; i < 4; i++) {
+        if (i && lo[i] < lo[i - 1] + sz[i - 1]) return 0;  // an unexpected layout: do not serve it
+        ranges[(4 * l + i) * 2] = lo[i];
+        ranges[(4 * l + i) * 2 + 1] = lo[i] + sz[i];
+      }
+    }
+  }
+  return sq_layout(d).per_layer * d.L;
+}
+
 static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void* stream) {
   CK(check_model(m));
   VBX_REQUIRE(m->training && m->grads && l >= 0 && l < m->L, "vbx_model_backward_layer: bad layer / not training");
@@ -783,8 +819,10 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   float* const cpart = a.cpart + rr * a.cp_stride;
   float* const gpart = a.gpart + rr * a.gp_stride;
   float* const csl = defer ? a.cs_layers + rr * a.cs_stride : a.cs_scratch;  // GEGLU-backward column-sum slabs
-  // the four split-K weight-gradient reductions of the layer are deferred into one launch (own slab region each)
-  static const bool batch_wg = !(getenv("VBX_BATCH_WGRAD") && atoi(getenv("VBX_BATCH_WGRAD")) == 0) && !side_stream().ok;
+  const bool batch_wg = batch_wgrad_on();
+  const SqLayout sql = sq_layout(d);
+  float* const sqb = (m->sq_partials && batch_wg) ? m->sq_partials + (long)l * sql.per_layer : nullptr;
+  auto sq_at = [&](int i) { return sqb ? sqb + sql.off[i] : nullptr; };
   vbx_skr_jobs wj{};
   vbx_skr_jobs* wjp = batch_wg ? &wj : nullptr;
   WgradGroup wgg;
@@ -794,7 +832,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
   const size_t sfl = a.slab_floats;
   // ---- FeedForward
   { ProfScope ps("dgrad ff_out", st); CK(gemm_nn_bf16(a.dxb, d.D, w.layer[l].w2, d.Fp, M, d.Fp, d.D, a.dg, d.Fp, st)); }
-  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp, gs));
+  CK(wgrad(a.dxb, d.D, y.g, d.Fp, d.D, d.Fp, d.M, a.slabs, Gd + o[VBX_L_FF2W], d.D, d.F, 0, 0, st, wjp, wgp, gs, sq_at(0)));
   VBX_REQUIRE(io || !(m->ff_dropout > 0.f || m->attn_dropout > 0.f), "vbx_model_backward_layer: a model with dropout needs the forward's io");
   const bool drop_on = io && io->dropout != 0;
   if (drop_on && m->ff_dropout > 0.f)  // the same mask on the gradient of the GEGLU output
@@ -806,7 +844,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(vbx_colsum_bf16(a.dh1, M, 2 * d.Fp, 2 * d.Fp, Gd + o[VBX_L_FF1B], 2 * d.F, 1, d.F, a.cs_scratch, stream));
   }
   { ProfScope ps("dgrad ff_in", st); CK(gemm_nn_bf16(a.dh1, 2 * d.Fp, w.layer[l].w1, d.D, M, d.D, 2 * d.Fp, a.dhn, d.D, st)); }
-  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp, gs));
+  CK(wgrad(a.dh1, 2 * d.Fp, y.hn2, d.D, 2 * d.Fp, d.D, d.M, a.slabs + sfl, Gd + o[VBX_L_FF1W], 2 * d.F, d.D, 1, d.F, st, wjp, wgp, gs, sq_at(1)));
   // (the column sums of the incoming dx -- FeedForward[3].bias gradient -- ride along in the same pass)
   CK(wgrad_join(st));  // the FeedForward-out wgrad reads a.dxb, which the norm backward below overwrites
   if (m->plain_norm) {
@@ -847,7 +885,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     CK(rc);
   }
   const u16* attn_out = have_delta ? nullptr : y.oh;  // NULL: a.delta is already there
-  CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp, gs));
+  CK(wgrad(dxb_attn, d.D, y.o, d.I, d.D, d.I, d.M, a.slabs + 2 * sfl, Gd + o[VBX_L_OUTW], d.D, d.I, 0, 0, st, wjp, wgp, gs, sq_at(2)));
   static const bool fused_qk = !(getenv("VBX_ATTN_FUSED_QKBWD") && atoi(getenv("VBX_ATTN_FUSED_QKBWD")) == 0);  // 0: A/B
   if (fused_qk) {
     ProfScope ps("bwd attention", st);
@@ -877,7 +915,7 @@ static int backward_layer_impl(const vbx_model* m, const vbx_io* io, int l, void
     }
   }
   { ProfScope ps("dgrad to_qkv", st); CK(gemm_nn_bf16(a.dqkv, 3 * d.I, w.layer[l].qkv, d.D, M, d.D, 3 * d.I, a.dhn, d.D, st)); }
-  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp, gs));
+  CK(wgrad(a.dqkv, 3 * d.I, y.hn1, d.D, 3 * d.I, d.D, d.M, a.slabs + 3 * sfl, Gd + o[VBX_L_QKVW], 3 * d.I, d.D, 0, 0, st, wjp, wgp, gs, sq_at(3)));
   if (wgg.n) { ProfScope ps("wgrad (4 GEMMs)", st); CK(vbx_gemm_tn_splitk_grouped(wgg.d, wgg.n, stream)); }  // every operand is still live here (a.dxb: see dxb_attn)
   // VBX_LAYER_REDUCE=1: the slab reduction rides in the layer's batched reduce launch below (vbx_layer_reduce, bit-identical).
   // MEASURED (round 5, two interleaved runs per arm on one box): 9.95-10.02 vs 9.85-9.93 ms per step -- the 16 us of slab traffic now

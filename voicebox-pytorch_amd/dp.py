@@ -410,7 +410,7 @@ class TrainStep:
             self._stage_buf = red.stage_buf
         self._clip_adam(self._last_eng, lr)
 
-    def _forward_backward(self, x1, mask, cond_token_ids, on_stage, adaln_factors=False):
+    def _forward_backward(self, x1, mask, cond_token_ids, on_stage, adaln_factors=False, sq_fold=False):
         vb, w = self.vb, self.wrapper
         dev = self.fp.flat.device
         st = _lib.current_stream
@@ -457,7 +457,14 @@ class TrainStep:
             N = Nb
         eng = vb.engine(B, N, training=True)
         loss = eng.forward(wt, flow, cond_mask, times, attn_mask=mask, target=flow, loss_mask=loss_mask, text=text)
-        eng.backward(self.gflat, gscale=None, on_stage=on_stage, adaln_factors=adaln_factors)
+        sq = None
+        if sq_fold and adaln_factors and on_stage is None and eng.sq_partials_info()[0] > 0:
+            need = eng.sumsq_scratch_floats(True)
+            if self.scratch.numel() < need:
+                self.scratch = torch.zeros(need, device=dev)
+            sq = eng.sq_partials_ptr(self.scratch)
+        self._sq_folded = sq is not None  # the norm of THIS backward's big weight matrices is already in self.scratch
+        eng.backward(self.gflat, gscale=None, on_stage=on_stage, adaln_factors=adaln_factors, sq_partials=sq)
         self._last_eng = eng
         return loss
 
@@ -507,7 +514,7 @@ class TrainStep:
         if self.grad_mode == "shard" and red is not None and red.shard and red.active:
             return self._clip_adam_sharded(eng, lr, red)
         if adaln_factors:
-            eng.sumsq_with_adaln_factors(self.gflat, self.sumsq, self.scratch)
+            eng.sumsq_with_adaln_factors(self.gflat, self.sumsq, self.scratch, sq_fold=getattr(self, "_sq_folded", False))
         else:
             _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
@@ -533,7 +540,11 @@ class TrainStep:
         # --- backward with overlapped gradient exchange
         factors = self.adaln_factors_apply() and os.environ.get("VBX_FUSED_ADAM", "1") != "0"
         red = self._reducer(self.grad_comm_dtype, skip_adaln=factors and self.exchange)
-        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None, adaln_factors=factors)
+        # one GPU, factor form: the slab reduce also leaves the sums of squares of what it stores (no second pass over the big
+        # weight gradients for the clip norm); VBX_SUMSQ_FOLD=0: A/B
+        fold = factors and not self.exchange and os.environ.get("VBX_SUMSQ_FOLD", "1") != "0"
+        loss = self._forward_backward(x1, mask, cond_token_ids, on_stage=red.stage_done if self.exchange else None, adaln_factors=factors,
+                                      sq_fold=fold)
         if factors and self.exchange:  # the factors travel (one small all-gather) while the last buckets are still in flight
             self._exchange_adaln_factors(self._last_eng)
         red.finish()

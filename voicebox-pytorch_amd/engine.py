@@ -21,7 +21,7 @@ class VbxModel(C.Structure):
                 ("qk_norm", I), ("attn_scale", F), ("training", I), ("params", P), ("grads", P), ("off", P),
                 ("wpack", P), ("act", P), ("rot_cos", P), ("rot_sin", P), ("gateloop", I),
                 ("stack_only", I), ("E", I), ("V1", I), ("plain_norm", I), ("attn_dropout", F), ("ff_dropout", F), ("Din", I),
-                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F), ("adaln_factors", I), ("defer_reduce", I)]
+                ("precise", I), ("wpack3", P), ("pscratch", P), ("unet", I), ("skip_scale", F), ("adaln_factors", I), ("defer_reduce", I), ("sq_partials", P)]
 
 
 class VbxIO(C.Structure):
@@ -90,6 +90,8 @@ def _rt():
         l.vbx_model_adaln_table.restype = I
         l.vbx_model_adaln_factors.argtypes = [MP, C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), C.POINTER(P)]
         l.vbx_model_adaln_factors.restype = I
+        l.vbx_model_sq_partials.argtypes = [MP, C.POINTER(C.c_long)]
+        l.vbx_model_sq_partials.restype = C.c_long
         l.vbx_sumsq_adaln_factors.argtypes = [P, P, I, I, I, I, P, P]
         l.vbx_sumsq_adaln_factors.restype = I
         l.vbx_sumsq_ranges.argtypes = [P, C.POINTER(C.c_long), I, I, P, P, P]
@@ -332,27 +334,50 @@ class Engine:
         _, _, woff, _, J4, Th = self.adaln_factor_info()
         return sorted((int(o), int(o) + J4 * Th) for o in woff)
 
-    def sumsq_with_adaln_factors(self, gflat, out, scratch):
+    def sq_partials_info(self):
+        """(floats, [(lo, hi), ...]): size of the slab-reduce sum-of-squares partials (vbx_model.sq_partials) and the flat gradient
+        ranges they cover -- every layer's to_qkv / to_out / FeedForward weights; (0, []) when this configuration does not serve them."""
+        if getattr(self, "_sq_info", None) is None:
+            L = self.cfg["L"]
+            arr = (C.c_long * (8 * L))()
+            n = int(_rt().vbx_model_sq_partials(C.byref(self.m), arr))
+            self._sq_info = (n, sorted((int(arr[2 * i]), int(arr[2 * i + 1])) for i in range(4 * L)) if n > 0 else [])
+        return self._sq_info
+
+    def sumsq_scratch_floats(self, sq_fold=False):
+        """floats the scratch of sumsq_with_adaln_factors must hold: 1024 block partials + L * B * B factor terms (+ the slab partials)"""
+        return 1024 + self.cfg["L"] * self.B * self.B + (self.sq_partials_info()[0] if sq_fold else 0)
+
+    def sq_partials_ptr(self, scratch):
+        """where in `scratch` the backward must leave the slab partials for sumsq_with_adaln_factors(..., sq_fold=True)"""
+        return scratch.data_ptr() + 4 * (1024 + self.cfg["L"] * self.B * self.B)
+
+    def sumsq_with_adaln_factors(self, gflat, out, scratch, sq_fold=False):
         """out[0] = sum of squares of the gradient whose adaLN weight blocks are in factor form: the flat buffer minus those blocks
-        (never written in that mode) plus |dada_l^T . temb|_F^2 per layer from the factors.  scratch: >= 1024 + L * B * B floats."""
+        (never written in that mode) plus |dada_l^T . temb|_F^2 per layer from the factors.  scratch: >= 1024 + L * B * B floats.
+        sq_fold: the last backward ran with sq_partials = sq_partials_ptr(scratch) -- the big weight matrices' terms are already
+        there and only the small tensors are read again (sumsq_scratch_floats(True) floats of scratch)."""
         l = _rt()
         dada, temb, woff, dst, J4, Th = self.adaln_factor_info()
         L, n = self.cfg["L"], gflat.numel()
         st = _lib.current_stream()
         nterms = L * self.B * self.B  # (dada_l[b] . dada_l[b']) (temb[b] . temb[b']) for every (l, b, b')
-        assert scratch.numel() >= 1024 + nterms, "sumsq scratch too small for the factor terms"
+        nsq, covered = self.sq_partials_info() if sq_fold else (0, [])
+        assert scratch.numel() >= 1024 + nterms + nsq, "sumsq scratch too small for the factor terms"
         _check(l.vbx_sumsq_adaln_factors(dada, temb, L, self.B, J4, Th, scratch.data_ptr() + 4 * 1024, st), "vbx_sumsq_adaln_factors")
-        if getattr(self, "_rest_ranges", None) is None:
+        cache = self.__dict__.setdefault("_rest_ranges_by_mode", {})
+        if bool(nsq) not in cache:
             rest, cur = [], 0
-            for lo, hi in self.adaln_factor_ranges():
+            for lo, hi in sorted(list(self.adaln_factor_ranges()) + list(covered)):
                 if lo > cur:
                     rest += [cur, lo]
-                cur = hi
+                cur = max(cur, hi)
             if cur < n:
                 rest += [cur, n]
-            self._rest_ranges = ((C.c_long * len(rest))(*rest), len(rest) // 2)
-        arr, nr = self._rest_ranges
-        _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, nterms, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
+            assert len(rest) // 2 <= 64, "too many gradient ranges for vbx_sumsq_ranges"
+            cache[bool(nsq)] = ((C.c_long * len(rest))(*rest), len(rest) // 2)
+        arr, nr = cache[bool(nsq)]
+        _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, nterms + nsq, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
 
     # -- optimizer: Adam over the flat buffers that also refreshes this engine's packed operand copies
     def adam_step_packed(self, gflat, m, v, lr, beta1, beta2, eps, step, gscale, adaln_factors=False):
@@ -538,18 +563,22 @@ class Engine:
         return self.act[off:off + n].view(dtype).view(*shape)
 
     # -- backward, stage by stage; `on_stage(i, (lo, hi))` fires after the gradients in flat range [lo,hi) are final
-    def backward(self, gflat, gscale=None, on_stage=None, adaln_factors=False):
+    def backward(self, gflat, gscale=None, on_stage=None, adaln_factors=False, sq_partials=None):
         """adaln_factors=True: the adaLN projection WEIGHT gradients are not written into gflat -- they stay in factor form in this
-        arena (adaln_factor_info) until the next forward; the caller's optimizer / exchange must take them from there."""
+        arena (adaln_factor_info) until the next forward; the caller's optimizer / exchange must take them from there.
+        sq_partials: device address of sq_partials_info()[0] floats -- the slab reduce leaves the big weight matrices' sums of
+        squares there (the caller takes the gradient norm of THIS backward from them: no accumulation / exchange in between)."""
         assert self.training
         assert not adaln_factors or self.supports_adaln_factors()
         self.m.adaln_factors = int(bool(adaln_factors))
         self.m.defer_reduce = int(on_stage is None)  # nobody reads a gradient before the last stage: one reduce for all layers
+        self.m.sq_partials = sq_partials
         try:
             return self._backward(gflat, gscale, on_stage)
         finally:
             self.m.adaln_factors = 0
             self.m.defer_reduce = 0
+            self.m.sq_partials = None
 
     def _backward(self, gflat, gscale, on_stage):
         self.m.grads = gflat.data_ptr()
