@@ -428,3 +428,33 @@ def test_sampler_split_is_validated(monkeypatch):
     monkeypatch.delenv("VBX_SAMPLE_SPLIT")
     with pytest.raises(ValueError, match="split=4"):
         solver.MidpointSampler(None, 8, 16, 3, split=4)
+
+
+@pytest.mark.parametrize("depth,served", [(2, True), (12, True), (24, False)])
+def test_gradient_norm_range_plan(depth, served):
+    """Host side of the clip norm from slab-reduce partials (engine.Engine.sq_partials_info / sumsq_with_adaln_factors): what is read
+    again is the complement of the adaLN weight blocks and of every layer's four big weight matrices -- three gaps per layer plus the
+    head and the tail.  vbx_sumsq_ranges takes at most 64 ranges of 4-float-aligned bounds: a depth-24 model has 73 gaps and must fall
+    back to the plain pass (only the adaLN blocks left out: depth + 1 ranges) instead of failing."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.engine import Engine
+
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=depth, dim_head=64, heads=2, condition_on_text=False)
+    fp = vb.flat_params()
+    n = fp.flat.numel()
+    ada, big = [], []
+    for l in range(depth):
+        ada.append((fp.offsets[f"L{l}.G1W"], fp.offsets[f"L{l}.B2W"] + fp.slots[f"L{l}.B2W"].numel()))
+        for k in ("QKVW", "OUTW", "FF1W", "FF2W"):
+            big.append((fp.offsets[f"L{l}.{k}"], fp.offsets[f"L{l}.{k}"] + fp.slots[f"L{l}.{k}"].numel()))
+    plain = Engine.complement_ranges(n, ada)
+    fold = Engine.complement_ranges(n, ada + big)
+    assert len(plain) // 2 == depth + 1 <= Engine.SUMSQ_MAX_RANGES
+    assert len(fold) // 2 == 3 * depth + 1
+    assert (len(fold) // 2 <= Engine.SUMSQ_MAX_RANGES) == served
+    for rest, blocks in ((plain, ada), (fold, ada + big)):
+        assert all(v % 4 == 0 for v in rest)  # vbx_sumsq_ranges: 16-byte aligned bounds
+        covered = sum(hi - lo for lo, hi in blocks) + sum(rest[i + 1] - rest[i] for i in range(0, len(rest), 2))
+        assert covered == n and rest == sorted(rest)  # a partition of the buffer
+    assert Engine.complement_ranges(10, [(0, 10)]) == [] and Engine.complement_ranges(10, []) == [0, 10]
+    assert Engine.complement_ranges(12, [(4, 8), (2, 6)]) == [0, 2, 8, 12]  # overlapping, unsorted blocks

@@ -334,6 +334,20 @@ class Engine:
         _, _, woff, _, J4, Th = self.adaln_factor_info()
         return sorted((int(o), int(o) + J4 * Th) for o in woff)
 
+    @staticmethod
+    def complement_ranges(n, blocks):
+        """blocks: [lo, hi) ranges inside [0, n) in any order -> the gaps between them as a flat list [lo0, hi0, lo1, hi1, ...]"""
+        rest, cur = [], 0
+        for lo, hi in sorted(blocks):
+            if lo > cur:
+                rest += [cur, lo]
+            cur = max(cur, hi)
+        if cur < n:
+            rest += [cur, n]
+        return rest
+
+    SUMSQ_MAX_RANGES = 64  # vbx_sumsq_ranges
+
     def sq_partials_info(self):
         """(floats, [(lo, hi), ...]): size of the slab-reduce sum-of-squares partials (vbx_model.sq_partials) and the flat gradient
         ranges they cover -- every layer's to_qkv / to_out / FeedForward weights; (0, []) when this configuration does not serve them."""
@@ -341,7 +355,13 @@ class Engine:
             L = self.cfg["L"]
             arr = (C.c_long * (8 * L))()
             n = int(_rt().vbx_model_sq_partials(C.byref(self.m), arr))
-            self._sq_info = (n, sorted((int(arr[2 * i]), int(arr[2 * i + 1])) for i in range(4 * L)) if n > 0 else [])
+            cov = sorted((int(arr[2 * i]), int(arr[2 * i + 1])) for i in range(4 * L)) if n > 0 else []
+            if n > 0 and self.supports_adaln_factors():
+                # the remaining small tensors are read by ONE vbx_sumsq_ranges launch: a deep model has more gaps than it takes
+                gaps = self.complement_ranges(self.fp.flat.numel(), list(self.adaln_factor_ranges()) + cov)
+                if len(gaps) // 2 > self.SUMSQ_MAX_RANGES:
+                    n, cov = 0, []
+            self._sq_info = (n, cov)
         return self._sq_info
 
     def sumsq_scratch_floats(self, sq_fold=False):
@@ -367,14 +387,8 @@ class Engine:
         _check(l.vbx_sumsq_adaln_factors(dada, temb, L, self.B, J4, Th, scratch.data_ptr() + 4 * 1024, st), "vbx_sumsq_adaln_factors")
         cache = self.__dict__.setdefault("_rest_ranges_by_mode", {})
         if bool(nsq) not in cache:
-            rest, cur = [], 0
-            for lo, hi in sorted(list(self.adaln_factor_ranges()) + list(covered)):
-                if lo > cur:
-                    rest += [cur, lo]
-                cur = max(cur, hi)
-            if cur < n:
-                rest += [cur, n]
-            assert len(rest) // 2 <= 64, "too many gradient ranges for vbx_sumsq_ranges"
+            rest = self.complement_ranges(n, list(self.adaln_factor_ranges()) + list(covered))
+            assert len(rest) // 2 <= self.SUMSQ_MAX_RANGES, "too many gradient ranges for vbx_sumsq_ranges"
             cache[bool(nsq)] = ((C.c_long * len(rest))(*rest), len(rest) // 2)
         arr, nr = cache[bool(nsq)]
         _check(l.vbx_sumsq_ranges(gflat.data_ptr(), arr, nr, nterms + nsq, out.data_ptr(), scratch.data_ptr(), st), "vbx_sumsq_ranges")
