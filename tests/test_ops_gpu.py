@@ -342,7 +342,10 @@ def attn_inputs(Bsz, H, Np, seed, qnorm=8.0):
 @pytest.mark.parametrize("Bsz,H,Np,scale,masked", [(1, 2, 64, 10.0, False), (2, 2, 1040, 10.0, False),
                                                    (2, 3, 77, 10.0, True), (1, 2, 200, 0.125, True),
                                                    (2, 2, 1040, 10.0, True), (1, 2, 128, 10.0, False), (2, 2, 300, 10.0, True),
-                                                   (1, 3, 24, 10.0, False)])
+                                                   (1, 3, 24, 10.0, False),
+                                                   # ragged tail tiles of <= 16 query rows (the forward's 16 x 16 MFMA role, round 6)
+                                                   (2, 2, 144, 10.0, True), (1, 3, 130, 10.0, False), (2, 2, 264, 10.0, True),
+                                                   (1, 2, 16, 10.0, False), (1, 2, 1029, 10.0, True)])
 def test_attn_fwd_bwd(L, Bsz, H, Np, scale, masked, bwd_variant):
     """Attend.forward math path (attend.py:121-135) at the reference's logit scale (10 * q.k, |q|=|k|=8)."""
     q16, k16, v = attn_inputs(Bsz, H, Np, seed=Np + H, qnorm=8.0 if scale == 10.0 else None)

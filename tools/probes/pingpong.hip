@@ -1,0 +1,213 @@
+// Does an attention-forward-shaped instruction mix (D = 64: per wave and 64-key tile 16 MFMA 32x32x16 + ~160 VALU + 16 KB of LDS
+// reads) run faster when the two waves of a SIMD are forced into OPPOSITE phases (one in its matrix segment while the other is in
+// its softmax segment, s_barrier between segments) than when co-resident waves drift in phase?  All instructions inline asm.
+//   MODE 0  "free4":   256-thread workgroups, 4 per CU (4 waves / SIMD), each wave: M ; V ; one barrier per step   (= v3's shape)
+//   MODE 1  "inphase": 512-thread workgroups, 1 per CU (2 waves / SIMD), every wave: M ; barrier ; V ; barrier
+//   MODE 2  "pingpong": same, waves 4-7 run V ; barrier ; M ; barrier                                            (opposite phases)
+//   MODE 3  "pingpong x2": MODE 2 with 2 workgroups per CU (4 waves / SIMD, <= 128 VGPRs)
+//   MODE 4  "mixed1":  256-thread workgroups, 1 per CU (1 wave / SIMD): the V instructions spread into the MFMA gaps by hand
+//   MODE 5  "mixed2":  MODE 4 with 2 workgroups per CU
+// build: hipcc --offload-arch=gfx950 -O3 -o pingpong pingpong.hip ; run: ./pingpong
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define N_IT 512
+
+#define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define VMUL(x, c) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c))
+#define VSUB(x, c) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(c))
+#define VADD(x, y) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(y))
+#define VEXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define VMAX3(x, a, b) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
+#define VCVT(d, a, b) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+
+struct State {
+  f32x16 s0, s1, o0, o1;
+  f16x8 q[4];
+  unsigned p[16];
+  float m, l, alpha;
+};
+
+// matrix segment: 16 KB of fragment reads, 16 MFMAs (4 chains of 4), the O rescale (32 v_mul) in the gaps.  DB: two fragment
+// buffers (the next chain's reads in flight under this chain's MFMAs); !DB: one buffer, every chain waits for its own reads (v3).
+template <bool DB>
+__device__ __forceinline__ void seg_m(State& st, unsigned lds) {
+  const f16x8 p0 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[0]), p1 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[4]);
+  if (DB) {
+    f16x8 k[4], v[4];
+    RD128(k[0], lds, 0); RD128(k[1], lds, 1024); RD128(k[2], lds, 2048); RD128(k[3], lds, 3072);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    RD128(v[0], lds, 4096); RD128(v[1], lds, 5120); RD128(v[2], lds, 6144); RD128(v[3], lds, 7168);
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.s0, k[t], st.q[t]); VMUL(st.o0[2 * t], st.alpha); VMUL(st.o0[2 * t + 1], st.alpha); }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    RD128(k[0], lds, 8192); RD128(k[1], lds, 9216); RD128(k[2], lds, 10240); RD128(k[3], lds, 11264);
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.s1, v[t], st.q[t]); VMUL(st.o0[8 + 2 * t], st.alpha); VMUL(st.o0[9 + 2 * t], st.alpha); }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    RD128(v[0], lds, 12288); RD128(v[1], lds, 13312); RD128(v[2], lds, 14336); RD128(v[3], lds, 15360);
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.o0, k[t], (t & 1) ? p1 : p0); VMUL(st.o1[2 * t], st.alpha); VMUL(st.o1[2 * t + 1], st.alpha); }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.o1, v[t], (t & 1) ? p0 : p1); VMUL(st.o1[8 + 2 * t], st.alpha); VMUL(st.o1[9 + 2 * t], st.alpha); }
+  } else {
+    f16x8 k[4];
+    RD128(k[0], lds, 0); RD128(k[1], lds, 1024); RD128(k[2], lds, 2048); RD128(k[3], lds, 3072);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.s0, k[t], st.q[t]); VMUL(st.o0[2 * t], st.alpha); VMUL(st.o0[2 * t + 1], st.alpha); }
+    RD128(k[0], lds, 4096); RD128(k[1], lds, 5120); RD128(k[2], lds, 6144); RD128(k[3], lds, 7168);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.s1, k[t], st.q[t]); VMUL(st.o0[8 + 2 * t], st.alpha); VMUL(st.o0[9 + 2 * t], st.alpha); }
+    RD128(k[0], lds, 8192); RD128(k[1], lds, 9216); RD128(k[2], lds, 10240); RD128(k[3], lds, 11264);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.o0, k[t], (t & 1) ? p1 : p0); VMUL(st.o1[2 * t], st.alpha); VMUL(st.o1[2 * t + 1], st.alpha); }
+    RD128(k[0], lds, 12288); RD128(k[1], lds, 13312); RD128(k[2], lds, 14336); RD128(k[3], lds, 15360);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int t = 0; t < 4; t++) { MFMA(st.o1, k[t], (t & 1) ? p0 : p1); VMUL(st.o1[8 + 2 * t], st.alpha); VMUL(st.o1[9 + 2 * t], st.alpha); }
+  }
+}
+// softmax segment: 16 max3, 32 sub, 33 exp, 32 add, 16 cvt (+ a few)
+__device__ __forceinline__ void seg_v(State& st) {
+  float mx = st.m;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) { VMAX3(mx, st.s0[i], st.s0[i + 1]); VMAX3(mx, st.s1[i], st.s1[i + 1]); }
+  float a = st.m;
+  VSUB(a, mx); VEXP(a);
+  st.alpha = a; st.m = mx;
+  float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    VSUB(st.s0[i], mx); VEXP(st.s0[i]); VADD(sum0, st.s0[i]);
+    VSUB(st.s1[i], mx); VEXP(st.s1[i]); VADD(sum1, st.s1[i]);
+  }
+  VMUL(st.l, a); VADD(st.l, sum0); VADD(st.l, sum1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { VCVT(st.p[i], st.s0[2 * i], st.s0[2 * i + 1]); VCVT(st.p[8 + i], st.s1[2 * i], st.s1[2 * i + 1]); }
+}
+// one wave per SIMD: the same instructions, the softmax of the PREVIOUS tile spread by hand into this tile's MFMA gaps
+// (two S register sets: sA is being filled while sB is being exponentiated) -- about 10 VALU per MFMA.
+__device__ __forceinline__ void seg_mixed(State& st, f32x16& sb0, f32x16& sb1, unsigned lds) {
+  f16x8 k[4], v[4];
+  RD128(k[0], lds, 0); RD128(k[1], lds, 1024); RD128(k[2], lds, 2048); RD128(k[3], lds, 3072);
+  RD128(v[0], lds, 4096); RD128(v[1], lds, 5120); RD128(v[2], lds, 6144); RD128(v[3], lds, 7168);
+  float mx = st.m;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) { VMAX3(mx, sb0[i], sb0[i + 1]); VMAX3(mx, sb1[i], sb1[i + 1]); }
+  float a = st.m;
+  VSUB(a, mx); VEXP(a);
+  st.alpha = a; st.m = mx;
+  float sum0 = 0.f, sum1 = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    MFMA(st.s0, k[t], st.q[t]);
+#pragma unroll
+    for (int i = 4 * t; i < 4 * t + 4; i++) { VSUB(sb0[i], mx); VEXP(sb0[i]); VADD(sum0, sb0[i]); }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    MFMA(st.s1, v[t], st.q[t]);
+#pragma unroll
+    for (int i = 4 * t; i < 4 * t + 4; i++) { VSUB(sb1[i], mx); VEXP(sb1[i]); VADD(sum1, sb1[i]); }
+  }
+  RD128(k[0], lds, 8192); RD128(k[1], lds, 9216); RD128(k[2], lds, 10240); RD128(k[3], lds, 11264);
+  RD128(v[0], lds, 12288); RD128(v[1], lds, 13312); RD128(v[2], lds, 14336); RD128(v[3], lds, 15360);
+  VMUL(st.l, a); VADD(st.l, sum0); VADD(st.l, sum1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { VCVT(st.p[i], sb0[2 * i], sb0[2 * i + 1]); VCVT(st.p[8 + i], sb1[2 * i], sb1[2 * i + 1]); }
+#pragma unroll
+  for (int i = 0; i < 16; i++) { VMUL(st.o0[i], st.alpha); VMUL(st.o1[i], st.alpha); }
+  const f16x8 p0 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[0]), p1 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[4]);
+  const f16x8 p2 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[8]), p3 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[12]);
+  asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+  for (int t = 0; t < 4; t++) MFMA(st.o0, k[t], (t & 1) ? p1 : p0);
+#pragma unroll
+  for (int t = 0; t < 4; t++) MFMA(st.o1, v[t], (t & 1) ? p3 : p2);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MODE == 0 || MODE >= 4 ? 256 : 512, MODE == 0 ? 4 : (MODE == 3 ? 4 : (MODE == 5 ? 2 : (MODE == 4 ? 1 : 2))))
+void k(const unsigned* __restrict__ src, float* out, float seed) {
+  extern __shared__ char smem[];
+  for (int i = threadIdx.x; i < 16384 / 4 + 512; i += blockDim.x) ((unsigned*)smem)[i] = src[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lds = (unsigned)(size_t)smem + (lane & 31) * 32 + (lane >> 5) * 16;
+  State st;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { st.s0[i] = seed * i; st.s1[i] = seed - i; st.o0[i] = 0.f; st.o1[i] = 0.f; st.p[i] = src[lane + 64 * i]; }
+#pragma unroll
+  for (int t = 0; t < 4; t++) st.q[t] = *(const f16x8*)(src + 4 * (lane + 64 * t));
+  st.m = -1e30f; st.l = 0.f; st.alpha = 1.f;
+  if (MODE == 0) {
+    for (int it = 0; it < N_IT; it++) { seg_m<false>(st, lds); seg_v(st); __builtin_amdgcn_s_barrier(); }
+  } else if (MODE == 1) {
+    for (int it = 0; it < N_IT; it++) { seg_m<true>(st, lds); __builtin_amdgcn_s_barrier(); seg_v(st); __builtin_amdgcn_s_barrier(); }
+  } else if (MODE == 2 || MODE == 3) {
+    if (wave >= 4) { seg_v(st); __builtin_amdgcn_s_barrier(); }
+    for (int it = 0; it < N_IT; it++) { seg_m<MODE == 2>(st, lds); __builtin_amdgcn_s_barrier(); seg_v(st); __builtin_amdgcn_s_barrier(); }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+  } else {
+    f32x16 sb0 = st.o0, sb1 = st.o1;
+    for (int it = 0; it < N_IT; it += 2) {
+      seg_mixed(st, sb0, sb1, lds); __builtin_amdgcn_s_barrier();
+      { f32x16 t0 = st.s0, t1 = st.s1; st.s0 = sb0; st.s1 = sb1; seg_mixed(st, t0, t1, lds); sb0 = st.s0; sb1 = st.s1; st.s0 = t0; st.s1 = t1; }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float s = st.m + st.l;
+  for (int i = 0; i < 16; i++) s += st.s0[i] + st.s1[i] + st.o0[i] + st.o1[i] + (float)st.p[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run(const char* name, int wgs, int threads, int waves_per_simd, const unsigned* src, float* out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t sh = 16384 + 2048;
+  hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(wgs), dim3(threads), sh, 0, src, out, 0.37f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double ns_per_tile = best * 1e6 / (double)(N_IT * waves_per_simd);
+  printf("%-14s %5d x %3d threads, %d waves/SIMD: %8.1f us, %7.1f ns per wave-tile per SIMD (= %6.0f cycles at 2.0 GHz)\n", name, wgs,
+         threads, waves_per_simd, best * 1e3, ns_per_tile, ns_per_tile * 2.0);
+}
+int main() {
+  unsigned* src; float* out;
+  hipMalloc(&src, 1 << 20); hipMalloc(&out, 1024 * 1024 * 4);
+  unsigned* h = (unsigned*)malloc(1 << 20);
+  srand(1);
+  for (int i = 0; i < (1 << 18); i++) {  // random fp16 pairs in (-1, 1): sign random, exponent 0x30..0x3b
+    unsigned a = (rand() & 0x8000) | ((0x30 + rand() % 12) << 10) | (rand() & 0x3ff);
+    unsigned b = (rand() & 0x8000) | ((0x30 + rand() % 12) << 10) | (rand() & 0x3ff);
+    h[i] = a | (b << 16);
+  }
+  hipMemcpy(src, h, 1 << 20, hipMemcpyHostToDevice);
+  for (int pass = 0; pass < 2; pass++) {
+    run<0>("free4", 1024, 256, 4, src, out);
+    run<1>("inphase", 256, 512, 2, src, out);
+    run<2>("pingpong", 256, 512, 2, src, out);
+    run<3>("pingpong x2", 512, 512, 4, src, out);
+    run<4>("mixed1", 256, 256, 1, src, out);
+    run<5>("mixed2", 512, 256, 2, src, out);
+  }
+  return 0;
+}

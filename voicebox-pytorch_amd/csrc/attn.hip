@@ -512,6 +512,26 @@ VBX_DEV void dma_tile(char* dst, const u16* __restrict__ base, int row0, int row
   }
 }
 
+// One LDS-DMA piece (1 KiB per wave-instruction) with a SCALAR 64-bit base and a 32-bit per-lane byte offset: no vector ALU work per
+// piece.  m0 (the LDS destination of the wave) is compiler-reserved and not preserved around an asm statement, so it is saved,
+// written and restored inside the statement that uses it (cdna_hip_programming.md 5.7).  Base and destination must come from
+// scalar ALU code (an SGPR written by v_readfirstlane right before the statement would need five wait states).
+VBX_DEV void glds16_sbase(unsigned voff, const u16* __restrict__ sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+// max over the two half-waves (lane ^ 32) on the vector ALU.  Both results of the swap pass through an opaque asm before they are
+// combined: hipcc (ROCm 7.2) folds op(r[0], r[1]) of a permlane32_swap(x, x) to r[0] otherwise.
+VBX_DEV float xhalf_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  unsigned r0 = r[0], r1 = r[1];
+  asm volatile("" : "+v"(r0), "+v"(r1));
+  return fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+}
+
 template <int OFF>
 VBX_DEV f16x8 asm_read_b128(unsigned a) {
   f16x8 r;
