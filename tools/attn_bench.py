@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voicebox_pytorch_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, H, Np = 8, 16, int(os.environ.get("NP", 1040))  # frames + 16 register tokens
+B, H, Np = int(os.environ.get("BATCH", 8)), 16, int(os.environ.get("NP", 1040))  # frames + 16 register tokens
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cold = len(sys.argv) > 2 and sys.argv[2] == "cold"  # evict L2 + MALL between launches (per-kernel times then come from rocprofv3)
 scrub = torch.empty(1 << 28, dtype=torch.float32, device="cuda:0") if cold else None

@@ -190,6 +190,67 @@ void run(const char* name, int wgs, int threads, int waves_per_simd, const unsig
   printf("%-14s %5d x %3d threads, %d waves/SIMD: %8.1f us, %7.1f ns per wave-tile per SIMD (= %6.0f cycles at 2.0 GHz)\n", name, wgs,
          threads, waves_per_simd, best * 1e3, ns_per_tile, ns_per_tile * 2.0);
 }
+// ---- ablations of the free-running shape (MODE 0): which part of the step sets the time when 1..4 waves share a SIMD?
+template <int NOV, int NOLDS, int NOMFMA, int PERCU>
+__global__ __launch_bounds__(256, PERCU) void kabl(const unsigned* __restrict__ src, float* out, float seed) {
+  extern __shared__ char smem[];
+  for (int i = threadIdx.x; i < 16384 / 4 + 512; i += blockDim.x) ((unsigned*)smem)[i] = src[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned lds = (unsigned)(size_t)smem + (lane & 31) * 32 + (lane >> 5) * 16;
+  State st;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { st.s0[i] = seed * i; st.s1[i] = seed - i; st.o0[i] = 0.f; st.o1[i] = 0.f; st.p[i] = src[lane + 64 * i]; }
+#pragma unroll
+  for (int t = 0; t < 4; t++) st.q[t] = *(const f16x8*)(src + 4 * (lane + 64 * t));
+  st.m = -1e30f; st.l = 0.f; st.alpha = 1.f;
+  const f16x8 p0 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[0]), p1 = __builtin_bit_cast(f16x8, *(f32x4*)&st.p[4]);
+  for (int it = 0; it < N_IT; it++) {
+    f16x8 k[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (!NOLDS) {
+        RD128(k[0], lds, c * 4096); RD128(k[1], lds, c * 4096 + 1024); RD128(k[2], lds, c * 4096 + 2048); RD128(k[3], lds, c * 4096 + 3072);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+      } else {
+        asm volatile("" : "=v"(k[0]), "=v"(k[1]), "=v"(k[2]), "=v"(k[3]));
+      }
+      if (!NOMFMA) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (c == 0) MFMA(st.s0, k[t], st.q[t]);
+          if (c == 1) MFMA(st.s1, k[t], st.q[t]);
+          if (c == 2) MFMA(st.o0, k[t], (t & 1) ? p1 : p0);
+          if (c == 3) MFMA(st.o1, k[t], (t & 1) ? p0 : p1);
+        }
+      } else {
+        asm volatile("" :: "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+      }
+    }
+    if (!NOV) seg_v(st);
+    __builtin_amdgcn_s_barrier();
+  }
+  float s = st.m + st.l;
+  for (int i = 0; i < 16; i++) s += st.s0[i] + st.s1[i] + st.o0[i] + st.o1[i] + (float)st.p[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NOV, int NOLDS, int NOMFMA, int PERCU>
+void runabl(const unsigned* src, float* out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t sh = 16384 + 2048;
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kabl<NOV, NOLDS, NOMFMA, PERCU>), dim3(256 * PERCU), dim3(256), sh, 0, src, out, 0.37f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  printf("abl noV=%d noLDS=%d noMFMA=%d  %d waves/SIMD: %8.1f us, %7.1f ns per step (per wave-tile per SIMD %6.1f ns)\n", NOV, NOLDS, NOMFMA, PERCU,
+         best * 1e3, best * 1e6 / N_IT, best * 1e6 / N_IT / PERCU);
+}
 int main() {
   unsigned* src; float* out;
   hipMalloc(&src, 1 << 20); hipMalloc(&out, 1024 * 1024 * 4);
@@ -201,7 +262,14 @@ int main() {
     h[i] = a | (b << 16);
   }
   hipMemcpy(src, h, 1 << 20, hipMemcpyHostToDevice);
-  for (int pass = 0; pass < 2; pass++) {
+  runabl<0, 0, 0, 1>(src, out); runabl<0, 0, 0, 2>(src, out); runabl<0, 0, 0, 3>(src, out); runabl<0, 0, 0, 4>(src, out);
+  runabl<1, 0, 0, 1>(src, out); runabl<1, 0, 0, 2>(src, out); runabl<1, 0, 0, 4>(src, out);
+  runabl<0, 1, 0, 1>(src, out); runabl<0, 1, 0, 2>(src, out); runabl<0, 1, 0, 4>(src, out);
+  runabl<0, 0, 1, 1>(src, out); runabl<0, 0, 1, 2>(src, out); runabl<0, 0, 1, 4>(src, out);
+  runabl<1, 1, 0, 1>(src, out); runabl<1, 1, 0, 4>(src, out);
+  runabl<0, 1, 1, 1>(src, out); runabl<0, 1, 1, 4>(src, out);
+  runabl<1, 0, 1, 1>(src, out); runabl<1, 0, 1, 4>(src, out);
+  for (int pass = 0; pass < 1; pass++) {
     run<0>("free4", 1024, 256, 4, src, out);
     run<1>("inphase", 256, 512, 2, src, out);
     run<2>("pingpong", 256, 512, 2, src, out);

@@ -798,6 +798,59 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v3_drop(const u16* __r
 }
 #undef VBX_FWD_DROP
 
+#ifdef VBX_ATTN_DIAG  // tools/attn_ablation.sh: timing ablations of the forward step, separate instantiations of the same body
+#define VBX_ABL_KERNEL(N)                                                                                                        \
+  __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_v3_abl##N(const u16* __restrict__ q16, const u16* __restrict__ k16,  \
+                                                                      const u16* __restrict__ vv, const uint8_t* __restrict__ mask, \
+                                                                      u16* __restrict__ out, u16* __restrict__ outb,           \
+                                                                      float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap)
+#define VBX_FWD_ABL 1
+VBX_ABL_KERNEL(1) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 6
+VBX_ABL_KERNEL(6) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 8
+VBX_ABL_KERNEL(8) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 14
+VBX_ABL_KERNEL(14) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 49
+VBX_ABL_KERNEL(49) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 64
+VBX_ABL_KERNEL(64) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 384
+VBX_ABL_KERNEL(384) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 63
+VBX_ABL_KERNEL(63) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#define VBX_FWD_ABL 447
+VBX_ABL_KERNEL(447) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
+#endif
+
 // ---- Round-4 experiments on the forward, measured at the benchmark grid (8 x 16 heads x 1040 rows, stand-alone, same box) and removed:
 //  * "v4": 256-row workgroups, a wave owning TWO 32-query blocks whose chains are interleaved in one instruction stream (S of block B
 //    beside the softmax of block A, P.V of A beside the softmax of B; K / V^T fragments read once for both; 3-slot ring with counted
@@ -1678,6 +1731,24 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
   static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
   static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
+#ifdef VBX_ATTN_DIAG
+  if (getenv("VBX_FWD_ABL3") && atoi(getenv("VBX_FWD_ABL3")) != 0) {
+    const int a3 = atoi(getenv("VBX_FWD_ABL3"));
+#define VBX_ABL_LAUNCH(N)                                                                                                  \
+  case N:                                                                                                                  \
+    hipLaunchKernelGGL(attn_fwd_kernel_v3_abl##N, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16,     \
+                       (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);     \
+    break;
+    switch (a3) {
+      VBX_ABL_LAUNCH(1) VBX_ABL_LAUNCH(6) VBX_ABL_LAUNCH(8) VBX_ABL_LAUNCH(14) VBX_ABL_LAUNCH(49) VBX_ABL_LAUNCH(64)
+      VBX_ABL_LAUNCH(384) VBX_ABL_LAUNCH(63) VBX_ABL_LAUNCH(447)
+      default: VBX_REQUIRE(false, "VBX_FWD_ABL3: no such ablation build");
+    }
+#undef VBX_ABL_LAUNCH
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   if (v3 && !legacy && !abl && !abl2) {
     hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
                        (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);

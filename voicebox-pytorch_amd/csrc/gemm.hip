@@ -930,6 +930,9 @@ struct EpiGEGLU {
   }
 };
 
+#ifndef VBX_EPIQKV_ABL
+#define VBX_EPIQKV_ABL 0  // diagnostic builds only (tools/kdim_gemm_ablation.sh): 1 no stores, 2 no 1/|x|, 4 no rotary / gamma loads
+#endif
 // to_qkv + MultiheadRMSNorm + rotary, written head-major (voicebox_pytorch.py:320-328).
 struct EpiQKV {
   int Np, H;
@@ -958,6 +961,7 @@ struct EpiQKV {
         float t[8];
         load8(Cs, row, cc, t);
         const long o = (((long)b * H + hbase + (cc >> 3)) * Np + n) * 64 + (cc & 7) * 8;
+        if ((VBX_EPIQKV_ABL & 1) && t[0] != 123.456f) continue;
         if (v) *reinterpret_cast<uint4*>(v + o) = pack8_bf16(t);
         if (v16) *reinterpret_cast<uint4*>(v16 + o) = pack8_f16_sat(t);
       }
@@ -966,15 +970,48 @@ struct EpiQKV {
     // q / k: a thread owns the rotary pair of 8-wide chunks (d0..d0+7, d0+32..d0+39) of one (row, head), so rotate_half
     // needs no cross-lane traffic and the 64-wide sum of squares is a 4-lane quad reduction (DPP, no LDS permutes).
     // 8 threads per row (2 heads x 4 chunk pairs), 32 rows per pass.
-    for (int it = 0; it < rows / 32; it++) {
-      const int row = it * 32 + (tid >> 3), hj = tid & 7;
-      const int gr = m0 + row;
-      const bool valid = gr < M;
-      int b, n;
-      split_row(valid ? gr : mb, b, n);
-      const int hl = hj >> 2, j = hj & 3;  // head inside the 128-column tile, chunk pair
-      const int head = hbase + hl;
-      const int d0 = j * 8;
+    // Round 6: everything a pass reads from global memory is requested BEFORE the first pass computes -- the head's gamma chunk
+    // (the same for every pass) and the rotary rows of all passes of this call.  Written pass by pass, every pass was
+    // gamma loads -> s_waitcnt vmcnt(0) -> rotary loads -> s_waitcnt vmcnt(0) -> stores, and on gfx950 vmcnt also counts the previous
+    // pass's STORES: two exposed round trips behind a store drain per pass, 22 of the 64 us of this GEMM (VBX_GEMM_ABL=32).
+    const int hj = tid & 7;
+    const int hl = hj >> 2, j = hj & 3;  // head inside the 128-column tile, chunk pair
+    const int head = hbase + hl;
+    const int d0 = j * 8;
+    const bool isq = which == 0;
+    const float* gsel = isq ? qg : kg;
+    u16* dst = isq ? q16 : k16;
+    u16* bcopy = isq ? qb : kb;
+    float* rn = isq ? qrn : krn;
+    float glo[8], ghi[8];
+    gload8(gsel ? gsel + head * 64 + d0 : nullptr, qk_scale > 0.f, glo);
+    gload8(gsel ? gsel + head * 64 + 32 + d0 : nullptr, qk_scale > 0.f, ghi);
+    constexpr int MAXP = 2;  // passes whose loads are in flight together (the 128-wide tiles stage 64 rows per call)
+    const int npass_all = rows >> 5;
+    for (int it0 = 0; it0 < npass_all; it0 += MAXP) {
+    const int npass = min(MAXP, npass_all - it0);
+    int pb[MAXP], pn[MAXP];
+    bool pv[MAXP];
+    float cs[MAXP][8], sn[MAXP][8];
+#pragma unroll
+    for (int it = 0; it < MAXP; it++) {
+      const int gr = m0 + (it0 + it) * 32 + (tid >> 3);
+      pv[it] = it < npass && gr < M;
+      split_row(pv[it] ? gr : mb, pb[it], pn[it]);
+      gload8(rc + (long)pn[it] * 32 + d0, it < npass && !(VBX_EPIQKV_ABL & 4), cs[it]);
+      gload8(rs + (long)pn[it] * 32 + d0, it < npass && !(VBX_EPIQKV_ABL & 4), sn[it]);
+    }
+    retire8(glo);
+    retire8(ghi);
+#pragma unroll
+    for (int it = 0; it < MAXP; it++) {
+      retire8(cs[it]);
+      retire8(sn[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < MAXP; it++) {
+      if (it >= npass) break;
+      const int row = (it0 + it) * 32 + (tid >> 3);
       float lo[8], hi[8];
       load8(Cs, row, hl * 8 + j, lo);
       load8(Cs, row, hl * 8 + j + 4, hi);
@@ -987,42 +1024,37 @@ struct EpiQKV {
       // the raw v_rsq moved the chaotic random-init depth-12 loss from 1.0e-3 to 3.9e-3 off the reference
       // (tests/test_model_gpu.py::test_cfg4_depth12_parity); with one Newton step the test passes again, and neither variant is
       // measurably faster (16-interval sample 80.6 vs 80.6 ms in the same run).  The IEEE sequence stays.
-      const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      const float rinv = (VBX_EPIQKV_ABL & 2) ? ss : 1.0f / fmaxf(sqrtf(ss), 1e-12f);
       if (qk_scale > 0.f) {
-        const float* gam = (which == 0 ? qg : kg) + head * 64 + d0;
         const float rs_ = rinv * qk_scale;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          lo[i] = lo[i] * rs_ * gam[i];
-          hi[i] = hi[i] * rs_ * gam[32 + i];
+          lo[i] = lo[i] * rs_ * glo[i];
+          hi[i] = hi[i] * rs_ * ghi[i];
         }
       }
       // rotate_half (voicebox_pytorch.py:193-199): out[d] = t[d] cos - t[d+32] sin (d < 32), out[d+32] = t[d+32] cos + t[d] sin
-      const float* cp = rc + (long)n * 32 + d0;
-      const float* sp = rs + (long)n * 32 + d0;
       float olo[8], ohi[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        olo[i] = lo[i] * cp[i] - hi[i] * sp[i];
-        ohi[i] = hi[i] * cp[i] + lo[i] * sp[i];
+        olo[i] = lo[i] * cs[it][i] - hi[i] * sn[it][i];
+        ohi[i] = hi[i] * cs[it][i] + lo[i] * sn[it][i];
       }
-      if (valid) {
-        const long o = (((long)b * H + head) * Np + n) * 64 + d0;
-        u16* dst = (which == 0 ? q16 : k16);
-        u16* bcopy = (which == 0 ? qb : kb);
+      if ((VBX_EPIQKV_ABL & 1) ? (pv[it] && olo[0] == 123.456f) : pv[it]) {
+        const long o = (((long)pb[it] * H + head) * Np + pn[it]) * 64 + d0;
         if (bcopy) {
           *reinterpret_cast<uint4*>(bcopy + o) = pack8_bf16(olo);
           *reinterpret_cast<uint4*>(bcopy + o + 32) = pack8_bf16(ohi);
         }
-        if (which == 0) {
+        if (isq) {
 #pragma unroll
           for (int i = 0; i < 8; i++) { olo[i] *= qps; ohi[i] *= qps; }
         }
         *reinterpret_cast<uint4*>(dst + o) = pack8_f16(olo);
         *reinterpret_cast<uint4*>(dst + o + 32) = pack8_f16(ohi);
-        float* rn = (which == 0 ? qrn : krn);
-        if (rn && j == 0) rn[((long)b * H + head) * Np + n] = rinv;
+        if (rn && j == 0) rn[((long)pb[it] * H + head) * Np + pn[it]] = rinv;
       }
+    }
     }
   }
 };
