@@ -162,15 +162,18 @@ struct QKBwd {
   float* gpart;         // [B][tiles][H][64] partial gamma gradients of this tensor (qk-norm only)
   float xh_inv;         // 1 / (the factor xh carries): 1 / (scale * log2 e) for the pre-scaled q16, 1 for k16
 };
+// `staged`: the wave's rows already sit in wst in the layout below, scaled (the ragged tail roles of round 6 sum four waves' partial
+// blocks there); acc / scale are then ignored.
 VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratch */, const f32x16 (&acc)[2], float scale,
                                const QKBwd& f, bool active, int b, int h, int H, int tile, int ntiles, int row0, int Np, int lane,
-                               int wave) {
+                               int wave, bool staged = false) {
   const long bh = (long)b * H + h;
   float gacc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) gacc[i] = 0.f;
   if (active) {
     const int rl = lane & 31, hi = lane >> 5;
+    if (!staged) {
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
@@ -179,6 +182,7 @@ VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratc
         *reinterpret_cast<float4*>(wst + rl * 256 + ((c ^ (rl & 15)) << 4)) =
             make_float4(acc[db][4 * g4] * scale, acc[db][4 * g4 + 1] * scale, acc[db][4 * g4 + 2] * scale, acc[db][4 * g4 + 3] * scale);
       }
+    }
     __builtin_amdgcn_wave_barrier();
     const int sub = lane & 7, d0 = sub * 8, dp0 = d0 ^ 32;
     const float sgn = d0 < 32 ? 1.f : -1.f;  // transpose of rotate_half
