@@ -323,3 +323,107 @@ def test_adaln_factor_exchange_equals_allreduce_of_the_products():
     assert finite and gaps_ok and covered == rest
     assert gerr < 1e-6 and perr < 1e-6, (gerr, perr)
     assert wireB < 0.1 * wireA, (wireA, wireB)  # here the factor blocks are 97 % of the buffer; at dim 512 / depth 12 they are 49 %
+
+
+def _wide_worker(rank, world, port, out):
+    """One rank of the world-8 / world-3 exchange test: the REAL flat layout of the dim-64 model (stage ranges, adaLN weight blocks),
+    rank-seeded gradients and factors; replicated + factor exchange, then shard mode."""
+    import contextlib
+    import io
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import GradBucketReducer, gather_adaln_factors
+
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False)
+    fp = vb.flat_params()
+    n, ranges = fp.numel, fp.stage_ranges
+    ada = sorted((fp.offsets[f"L{l}.G1W"], fp.offsets[f"L{l}.B2W"] + fp.slots[f"L{l}.B2W"].numel()) for l in range(fp.depth))
+    L, B, J4 = fp.depth, 3, 4 * 64
+    Th = (ada[0][1] - ada[0][0]) // J4
+    assert J4 * Th == ada[0][1] - ada[0][0]
+
+    def local(r):  # rank r's gradient buffer and factors (any rank can rebuild any other's: the expected sums need no collective)
+        gen = torch.Generator().manual_seed(100 + r)
+        return torch.randn(n, generator=gen), torch.randn(L, B, J4, generator=gen), torch.randn(B, Th, generator=gen)
+
+    g_local, dada, temb = local(rank)
+    everyone = [local(r) for r in range(world)]
+    want = torch.stack([e[0] for e in everyone]).sum(0)
+    want_blocks = {l: sum(e[1][l].t() @ e[2] for e in everyone).flatten() for l in range(L)}
+    bucket = 4 * (n // 5)  # several buckets, boundaries at stage ends
+    # A: replicated exchange, the adaLN weight blocks as factors
+    gA = g_local.clone()
+    for lo, hi in ada:
+        gA[lo:hi] = float("nan")  # never written in factor mode
+    redA = GradBucketReducer(gA, ranges, bucket_bytes=bucket, skip_ranges=ada)
+    for i, rng in enumerate(ranges):
+        redA.stage_done(i, rng)
+    dada_all, temb_all, fwire = gather_adaln_factors(dada, temb)
+    redA.finish()
+    order = sorted(range(L), key=lambda l: fp.offsets[f"L{l}.G1W"])  # ada[i] belongs to layer order[i]
+    for (lo, hi), l in zip(ada, order):
+        gA[lo:hi] = (dada_all[l].t() @ temb_all).flatten()
+    errA = 0.0
+    inside = torch.zeros(n, dtype=torch.bool)
+    for (lo, hi), l in zip(ada, order):
+        inside[lo:hi] = True
+        errA = max(errA, float((gA[lo:hi] - want_blocks[l]).abs().max() / want_blocks[l].abs().max()))
+    errA = max(errA, float((gA[~inside] - want[~inside]).abs().max() / want.abs().max()))
+    touches = any(lo < b and a < hi for lo, hi in redA.buckets_launched for a, b in ada)
+    # B: shard mode on the whole buffer
+    gB = g_local.clone()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        redB = GradBucketReducer(gB, ranges, bucket_bytes=bucket, shard=True)
+        for i, rng in enumerate(ranges):
+            redB.stage_done(i, rng)
+        redB.finish()
+    own_err = max(float((gB[lo:hi] - want[lo:hi]).abs().max()) for lo, hi in redB.owned if hi > lo)
+    p = torch.full((n,), float("nan"))
+    for lo, hi in redB.owned:
+        p[lo:hi] = want[lo:hi] * 0.5  # "the owners' update"
+    redB.all_gather(p)
+    gathered_ok = bool(torch.allclose(p, want * 0.5, rtol=1e-6, atol=1e-6))
+    sizes = torch.tensor([float(sum(hi - lo for lo, hi in redB.owned))])
+    alls = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(alls, sizes)
+    even = all((hi - lo) % world == 0 for lo, hi in redB.buckets_launched)
+    if rank == 0:
+        out.put((errA, touches, len(redA.buckets_launched), own_err / float(want.abs().max()), gathered_ok,
+                 int(sum(float(a) for a in alls)), n, even, redB.uneven_logged, "does not divide by world size" in buf.getvalue(),
+                 redA.wire_floats + fwire, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8, 3])
+def test_exchange_at_world_8_and_uneven_world_3(world):
+    """the exchange arithmetic that the first 8-GPU run will execute, on gloo with the dim-64 model's real flat
+    layout.  World 8: bucket boundaries and chunk_of at W = 8 (every bucket divides evenly: flat slots are multiples of 64 floats),
+    the bucketed all-reduce with the adaLN weight blocks skipped + the factor all-gather reproduces sum_r g_r outside the blocks and
+    sum_r dada_r^T . temb_r inside, shard mode's owned chunks hold the all-reduce's sums, partition the buffer exactly once over the
+    ranks and the parameter all-gather restores every chunk.  World 3: buckets do not divide by 3 -- shard mode takes the all-reduce +
+    per-chunk-broadcast fallback, says so once on rank 0, and still delivers the same sums / partition / gather."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    errA, touches, nb, own_err, gathered_ok, covered, n, even, uneven_logged, said_so, wire, total = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert errA < 1e-5, errA          # fp32 sums of `world` terms in another order
+    assert not touches and nb >= 3    # no bucket touches a factor block; the stage order produced several buckets
+    assert own_err < 1e-5 and gathered_ok
+    assert covered == n               # the owned chunks of all ranks partition the buffer
+    if world == 8:
+        assert even and not uneven_logged
+    else:
+        assert not even and uneven_logged and said_so
+    assert wire < 0.75 * total        # the factor blocks never travel as products

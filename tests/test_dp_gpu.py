@@ -4,6 +4,7 @@ bucketed async all-reduce on a side stream, clip + fused Adam -- is the one benc
 
 Checked on rank 0: the reduced flat gradient equals the mean of the two shards' gradients computed locally one after the
 other (HIP kernels are deterministic -> equality up to one fp32 add), and both ranks end with identical parameters."""
+import math
 import os
 import socket
 import sys
@@ -200,6 +201,28 @@ def test_train_step_shard_mode_equals_allreduce_mode_world2_on_one_gpu():
 
     d = float(np.abs(p_shard - res["allreduce"][5]).max())
     assert d < 2e-7, d  # one Adam step of size ~lr = 1e-3: the clip coefficient differs in the last fp32 bits only
+
+
+def test_factor_mode_falls_back_to_materialised_gradients_above_batch_64():
+    """the one-GPU factor-form gradient norm (vbx_sumsq_adaln_factors: B x B Gram terms) serves local batches up to 64.
+    TrainStep's default adaln_grads="auto" must train a batch of 65 (materialised gradients) instead of raising after the backward,
+    a batch of 64 still runs in factor form with a scratch sized for its 64 x 64 terms, and an explicit "factors" request says so."""
+    import voicebox_pytorch_amd as vbx
+    from voicebox_pytorch_amd.dp import TrainStep
+
+    vb = vbx.VoiceBox(dim=64, num_cond_tokens=5, depth=2, dim_head=64, heads=2, condition_on_text=False).to(dev)
+    ts = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb), lr=1e-3, max_grad_norm=0.5)
+    assert ts.adaln_factors_apply() and ts.adaln_factors_apply(batch=64) and not ts.adaln_factors_apply(batch=65)
+    g = torch.Generator().manual_seed(5)
+    for B in (65, 64, 65):
+        p0 = ts.fp.flat.clone()
+        loss = ts.step(torch.randn(B, 24, 64, generator=g).to(dev))
+        torch.cuda.synchronize()
+        assert math.isfinite(float(loss)) and bool(torch.isfinite(ts.fp.flat).all())
+        assert float((ts.fp.flat - p0).abs().max()) > 0  # the step moved the parameters
+    ts2 = TrainStep(vbx.ConditionalFlowMatcherWrapper(voicebox=vb), lr=1e-3, max_grad_norm=0.5, adaln_grads="factors")
+    with pytest.raises(AssertionError):
+        ts2.step(torch.randn(65, 24, 64, generator=g).to(dev))
 
 
 def test_adaln_factor_mode_equals_materialised_gradients():

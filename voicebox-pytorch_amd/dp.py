@@ -328,15 +328,22 @@ class TrainStep:
         self.acc_pending = True
         return loss
 
-    def adaln_factors_apply(self):
-        """True when step() keeps the adaLN weight gradients in factor form (see __init__)."""
+    FACTOR_MAX_BATCH = 64  # vbx_sumsq_adaln_factors (one GPU: B x B Gram terms per layer) serves local batches up to this size
+
+    def adaln_factors_apply(self, batch=None):
+        """True when step() keeps the adaLN weight gradients in factor form (see __init__).  `batch`: the local batch size of the
+        step being decided; on ONE GPU the factor-form gradient norm is a B x B Gram sum whose kernel serves B <= 64, so a larger
+        batch falls back to the materialised gradient in "auto" mode (it used to raise after the backward)."""
         if self.adaln_grads == "materialize" or self.grad_mode == "shard":
             return False
         if self.adaln_grads == "auto" and os.environ.get("VBX_ADALN_FACTORS", "1") == "0":
             return False
         c = self.vb._cfg
         ok = not c.get("plain_norm") and not c.get("stack_only") and c["L"] <= 32 and self.fp.flat.is_cuda
-        assert ok or self.adaln_grads == "auto", "adaln_grads='factors' needs a VoiceBox with adaptive norms (depth <= 32) on a GPU"
+        if batch is not None and not self.exchange and batch > self.FACTOR_MAX_BATCH:
+            ok = False
+        assert ok or self.adaln_grads == "auto", ("adaln_grads='factors' needs a VoiceBox with adaptive norms (depth <= 32) on a GPU"
+                                                  " and, on one GPU, a batch of at most 64")
         return bool(ok)
 
     def adaln_weight_ranges(self):
@@ -514,7 +521,10 @@ class TrainStep:
         if self.grad_mode == "shard" and red is not None and red.shard and red.active:
             return self._clip_adam_sharded(eng, lr, red)
         if adaln_factors:
-            eng.sumsq_with_adaln_factors(self.gflat, self.sumsq, self.scratch, sq_fold=getattr(self, "_sq_folded", False))
+            folded = getattr(self, "_sq_folded", False)
+            if not folded and self.scratch.numel() < eng.sumsq_scratch_floats(False):  # (folded: sized before the backward wrote into it)
+                self.scratch = torch.zeros(eng.sumsq_scratch_floats(False), device=self.scratch.device)
+            eng.sumsq_with_adaln_factors(self.gflat, self.sumsq, self.scratch, sq_fold=folded)
         else:
             _lib.call("vbx_sumsq", self.gflat, n, self.sumsq, self.scratch, st())
         _lib.call("vbx_clip_coef", self.sumsq, float(self.max_grad_norm or 0.0), 1.0 / self.world, self.coef, st())
@@ -538,7 +548,7 @@ class TrainStep:
         """x1: (B_local, frames, dim) on this rank's GPU (cond_token_ids (B_local, tokens) for a text-conditioned model).
         Returns the (un-synchronised) local loss tensor."""
         # --- backward with overlapped gradient exchange
-        factors = self.adaln_factors_apply() and os.environ.get("VBX_FUSED_ADAM", "1") != "0"
+        factors = self.adaln_factors_apply(batch=int(x1.shape[0])) and os.environ.get("VBX_FUSED_ADAM", "1") != "0"
         red = self._reducer(self.grad_comm_dtype, skip_adaln=factors and self.exchange)
         # one GPU, factor form: the slab reduce also leaves the sums of squares of what it stores (no second pass over the big
         # weight gradients for the clip norm); VBX_SUMSQ_FOLD=0: A/B
