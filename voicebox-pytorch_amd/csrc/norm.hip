@@ -71,6 +71,91 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   }
 }
 
+// Round 6: the lean row kernel.  The round-1..5 kernel above issues ~600 instructions per row (64-bit per-lane addresses, a 64-bit
+// division, six ds_bpermute round trips for the wave sum, compare/select clamps per element, repacking of the conversion results):
+// 8320 rows x 600 / 1024 SIMDs x ~4 cycles = 9.7 us -- the launch was INSTRUCTION-bound at 3.2 TB/s, not memory-bound (found by
+// giving a wave more rows with the next row prefetched: time grew with rows per wave).  Here: the row is addressed by a scalar base
+// (grid = (rows of a batch / 4, B): no division, wave-uniform pointers), D == 256 * NC exactly (no per-chunk guards), the wave sum
+// runs on DPP + four v_readlane, conversions take adjacent pairs, and the fp16 saturation is decided once per wave (a ballot on
+// max |y| > 65504; NaN never raises it and converts to NaN on the fast path, as before).  Same arithmetic, same results.
+template <int CTRL>
+VBX_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+VBX_DEV float wave_sum_dpp(float v) {  // every lane ends with the sum over the 64 lanes
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8  -> every lane of a 16-lane row holds the row's sum
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+VBX_DEV unsigned cvt2_bf16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, b2));
+}
+VBX_DEV unsigned cvt2_f16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, h2));
+}
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_lean_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, long gb_stride, u16* __restrict__ y,
+                                                                u16* __restrict__ y16, int Np, int n0, int rpb, float* __restrict__ y32) {
+  constexpr int D = 256 * NC;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, j = blockIdx.x * 4 + wave;
+  if (j >= rpb) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Np + n0 + j) * D);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
+  const float4* b4 = reinterpret_cast<const float4*>(beta + (long)b * gb_stride);
+  float4 v[NC], g[NC], bt[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    v[i] = xr[lane + 64 * i];
+    g[i] = g4[lane + 64 * i];
+    bt[i] = beta ? b4[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+  ss = wave_sum_dpp(ss);
+  const float r = sqrtf((float)D) / fmaxf(sqrtf(ss), 1e-12f);
+  const long ri = (long)b * rpb + j;
+  float4 o[NC];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    o[i] = make_float4(v[i].x * r * g[i].x + bt[i].x, v[i].y * r * g[i].y + bt[i].y, v[i].z * r * g[i].z + bt[i].z,
+                       v[i].w * r * g[i].w + bt[i].w);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[i].x), fabsf(o[i].y)), fmaxf(fabsf(o[i].z), fabsf(o[i].w))));
+  }
+  if (y) {
+    uint2* yr = reinterpret_cast<uint2*>(y + ri * D);
+#pragma unroll
+    for (int i = 0; i < NC; i++) yr[lane + 64 * i] = make_uint2(cvt2_bf16(o[i].x, o[i].y), cvt2_bf16(o[i].z, o[i].w));
+  }
+  if (y16) {
+    uint2* yr16 = reinterpret_cast<uint2*>(y16 + ri * D);
+    if (__builtin_amdgcn_ballot_w64(amax > 65504.0f) == 0) {  // nothing to clamp in this row (NaN compares false and converts to NaN)
+#pragma unroll
+      for (int i = 0; i < NC; i++) yr16[lane + 64 * i] = make_uint2(cvt2_f16(o[i].x, o[i].y), cvt2_f16(o[i].z, o[i].w));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NC; i++) yr16[lane + 64 * i] = make_uint2(pack_f16x2_sat(o[i].x, o[i].y), pack_f16x2_sat(o[i].z, o[i].w));
+    }
+  }
+  if (y32) {
+#pragma unroll
+    for (int i = 0; i < NC; i++) reinterpret_cast<float4*>(y32 + ri * D)[lane + 64 * i] = o[i];
+  }
+}
+
 // ---------------------------------------------------------------- backward
 // u = x/|x| ; y = sqrt(D) u*gamma + beta
 // dgamma[b] += sqrt(D) u*dy ; dbeta[b] += dy ; du = sqrt(D) gamma*dy ; dx = (du - u (u.du)) / |x|
@@ -167,6 +252,101 @@ __global__ __launch_bounds__(64 * NB_WAVES) void rmsnorm_bwd_kernel(const float*
       r4[(wave * 3 + 1) * D4 + c] = ab[i];
       r4[(wave * 3 + 2) * D4 + c] = ac[i];
     }
+  }
+  __syncthreads();
+  float4* p4 = reinterpret_cast<float4*>(part + ((long)b * chunks + chunk) * 2 * D);
+  float4* c4 = cpart ? reinterpret_cast<float4*>(cpart + ((long)b * chunks + chunk) * D) : nullptr;
+  for (int idx = threadIdx.x; idx < 3 * D4; idx += 64 * NB_WAVES) {
+    const int which = idx / D4, c = idx - which * D4;
+    if (which == 2 && !c4) continue;
+    float4 s = r4[(0 * 3 + which) * D4 + c];
+#pragma unroll
+    for (int w = 1; w < NB_WAVES; w++) {
+      const float4 t = r4[(w * 3 + which) * D4 + c];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (which < 2) p4[which * D4 + c] = s;
+    else c4[c] = s;
+  }
+}
+
+// Round 6: the lean form of the backward row kernel for D == 256 * NC: scalar row bases (no per-lane 64-bit addresses), no per-chunk
+// guards, gamma loaded once per workgroup, the incoming dx requested together with x and dy (one memory round trip per row instead
+// of three dependent ones), DPP wave sums.  Same arithmetic and partial-record layout as rmsnorm_bwd_kernel<8, 16, NC>.
+template <int NC>
+__global__ __launch_bounds__(512) void rmsnorm_bwd_lean_kernel(const float* __restrict__ x, const float* __restrict__ gamma, long gb_stride,
+                                                                const u16* __restrict__ dy, const float* __restrict__ dx_in,
+                                                                float* __restrict__ dx_out, u16* __restrict__ dxb, float* __restrict__ part,
+                                                                float* __restrict__ cpart, int Np, int n0, int rpb) {
+  constexpr int D = 256 * NC, D4 = D / 4, NB_WAVES = 8, RB_ROWS = 16;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [8][3][D]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
+  const float sqrtD = sqrtf((float)D);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma + (long)b * gb_stride);
+  float4 g[NC], ag[NC], ab[NC], ac[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    g[i] = g4[lane + 64 * i];
+    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); ac[i] = make_float4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < RB_ROWS / NB_WAVES; k++) {
+    const int j = chunk * RB_ROWS + wave + NB_WAVES * k;
+    if (j >= rpb) break;
+    const long xrow = ((long)b * Np + n0 + j) * D;
+    const long drow = ((long)b * rpb + j) * D;
+    const float4* xr = reinterpret_cast<const float4*>(x + xrow);
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + drow);
+    const float4* din = reinterpret_cast<const float4*>(dx_in + xrow);
+    float4 xv[NC], dv[NC], a[NC];
+    uint2 praw[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      xv[i] = xr[lane + 64 * i];
+      praw[i] = dyr[lane + 64 * i];
+      a[i] = dx_in ? din[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++) ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+    ss = wave_sum_dpp(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      dv[i] = make_float4(bf16_to_f32((u16)(praw[i].x & 0xffff)), bf16_to_f32((u16)(praw[i].x >> 16)),
+                          bf16_to_f32((u16)(praw[i].y & 0xffff)), bf16_to_f32((u16)(praw[i].y >> 16)));
+      xv[i].x *= inv; xv[i].y *= inv; xv[i].z *= inv; xv[i].w *= inv;
+      ag[i].x += sqrtD * xv[i].x * dv[i].x; ag[i].y += sqrtD * xv[i].y * dv[i].y;
+      ag[i].z += sqrtD * xv[i].z * dv[i].z; ag[i].w += sqrtD * xv[i].w * dv[i].w;
+      ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+      dv[i].x *= sqrtD * g[i].x; dv[i].y *= sqrtD * g[i].y; dv[i].z *= sqrtD * g[i].z; dv[i].w *= sqrtD * g[i].w;
+      dot += xv[i].x * dv[i].x + xv[i].y * dv[i].y + xv[i].z * dv[i].z + xv[i].w * dv[i].w;
+    }
+    dot = wave_sum_dpp(dot);
+    float4* dout = reinterpret_cast<float4*>(dx_out + xrow);
+    uint2* dbo = reinterpret_cast<uint2*>(dxb + xrow);
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      float4 o = make_float4((dv[i].x - xv[i].x * dot) * inv, (dv[i].y - xv[i].y * dot) * inv,
+                             (dv[i].z - xv[i].z * dot) * inv, (dv[i].w - xv[i].w * dot) * inv);
+      if (dx_in) {
+        o.x += a[i].x; o.y += a[i].y; o.z += a[i].z; o.w += a[i].w;
+        ac[i].x += a[i].x; ac[i].y += a[i].y; ac[i].z += a[i].z; ac[i].w += a[i].w;
+      }
+      dout[lane + 64 * i] = o;
+      if (dxb) dbo[lane + 64 * i] = make_uint2(cvt2_bf16(o.x, o.y), cvt2_bf16(o.z, o.w));
+    }
+  }
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const int c = lane + 64 * i;
+    r4[(wave * 3 + 0) * D4 + c] = ag[i];
+    r4[(wave * 3 + 1) * D4 + c] = ab[i];
+    r4[(wave * 3 + 2) * D4 + c] = ac[i];
   }
   __syncthreads();
   float4* p4 = reinterpret_cast<float4*>(part + ((long)b * chunks + chunk) * 2 * D);
@@ -344,6 +524,19 @@ static int rmsnorm_fwd_launch(const float* x, const float* gamma, const float* b
 #define VBX_RF_LAUNCH1(NC_)                                                                                                      \
   hipLaunchKernelGGL((rmsnorm_fwd_kernel<1, NC_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride, \
                      (u16*)y_bf16, (u16*)y_f16, B, Np, n0, rows_per_batch, D, y_f32)
+  static const bool lean = !(getenv("VBX_RMS_LEAN") && atoi(getenv("VBX_RMS_LEAN")) == 0);  // 0: A/B against the generic kernel
+  if (lean && (D == 512 || D == 1024 || D == 2048)) {
+    const dim3 lgrid(cdiv(rows_per_batch, 4), B);
+#define VBX_RF_LAUNCHL(NC_)                                                                                                          \
+  hipLaunchKernelGGL((rmsnorm_fwd_lean_kernel<NC_>), lgrid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gb_stride, (u16*)y_bf16, \
+                     (u16*)y_f16, Np, n0, rows_per_batch, y_f32)
+    if (D == 512) VBX_RF_LAUNCHL(2);
+    else if (D == 1024) VBX_RF_LAUNCHL(4);
+    else VBX_RF_LAUNCHL(8);
+#undef VBX_RF_LAUNCHL
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
   if (rpw == 2) VBX_NC_DISPATCH(D, VBX_RF_LAUNCH2);
   else VBX_NC_DISPATCH(D, VBX_RF_LAUNCH1);
 #undef VBX_RF_LAUNCH1
@@ -384,6 +577,25 @@ extern "C" int vbx_rmsnorm_bwd(const float* x, const float* gamma, long gb_strid
   VBX_REQUIRE(!colpart || dx_in, "vbx_rmsnorm_bwd: column sums need dx_in");
   const bool eight = (size_t)8 * 3 * D * sizeof(float) <= 160 * 1024;
   const size_t lds = (size_t)(eight ? 8 : 4) * 3 * D * sizeof(float);
+  static const bool lean = !(getenv("VBX_RMS_LEAN") && atoi(getenv("VBX_RMS_LEAN")) == 0);  // 0: A/B against the generic kernel
+  if (lean && rb_rows() == 16 && (D == 512 || D == 1024)) {  // (D = 2048: the [8][3][D] reduction buffer exceeds the LDS, generic path)
+#define VBX_RB_LAUNCHL(NC_)                                                                                                          \
+  do {                                                                                                                               \
+    static bool attr_ = false;                                                                                                       \
+    if (!attr_) {                                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_lean_kernel<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                                                         \
+      attr_ = true;                                                                                                                  \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((rmsnorm_bwd_lean_kernel<NC_>), grid, dim3(512), lds, (hipStream_t)stream, x, gamma, gb_stride,                 \
+                       (const u16*)dy_bf16, dx_in, dx_out, (u16*)dxb_bf16, part, colpart, Np, n0, rows_per_batch);                   \
+  } while (0)
+    if (D == 512) VBX_RB_LAUNCHL(2);
+    else VBX_RB_LAUNCHL(4);
+#undef VBX_RB_LAUNCHL
+    VBX_LAUNCH_CHECK();
+    return 0;
+  }
 #define VBX_RB_LAUNCH_NC(W, R, NC_)                                                                                             \
   do {                                                                                                                         \
     static bool attr_ = false;                                                                                                 \
