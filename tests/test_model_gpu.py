@@ -31,9 +31,16 @@ dev = "cuda"
 # model rms 1.33e-3 / 1.35e-3 (mean |d| 0.92e-3 / 0.90e-3, max 4.6e-3 / 5.2e-3); 16 seeds of config 4 rms 4.05e-3 / 3.40e-3 (mean |d|
 # 2.87e-3 / 2.66e-3, max 12.5e-3 / 9.1e-3) -- i.e. the fast path (fp16 forward operands) sits at ~2x the fp32 noise floor of 1.7e-3, and
 # the two trees, whose q operands are rounded differently, are the same distribution.  The constants are those RMS values rounded up.
+# ROUND 6: the 16-seed operand-class ablation (tools/precision_ablation16.py -> profiles/r06_precision_ablation.txt:
+# the CPU oracle with ONE operand class rounded to fp16 at a time, same 16 seeds) settles where the factor 2 over the fp32 floor comes
+# from: nowhere in particular.  Rounding ANY single class except (P, v) already lands at RMS 2.6 - 4.2e-3 (all classes together: 3.3e-3,
+# the fp32 restatement: 1.8e-3), and hi + lo splits of the top classes (to_qkv operands; + q-hat / k-hat; P + v) change nothing (4.3 /
+# 4.2 / 3.3e-3) -- there is no operand whose extra precision would buy the floor back at <= 8 % of the step.  So the constants are
+# frozen at this tree's measured statistics x 1.25: config 4, 16 seeds: mean |d| 2.78e-3, RMS 3.59e-3, max 8.32e-3 (round 5's tree:
+# 2.66 / 3.40 / 9.1; the kernels of round 6 changed fp32 summation orders -- another draw of the same distribution).
 INIT_RMS_SMALL = 1.4e-3   # dim 64, depth 2, N ~ 100
-INIT_RMS_D12 = 4.0e-3     # dim 512 / 1024, depth 12, N = 1024
-FOUR_SIGMA_SMALL, FOUR_SIGMA_D12 = 4 * INIT_RMS_SMALL, 4 * INIT_RMS_D12
+INIT_MEAN_D12, INIT_RMS_D12, INIT_MAX_D12 = 3.5e-3, 4.5e-3, 1.2e-2  # dim 512 / 1024, depth 12, N = 1024
+FOUR_SIGMA_SMALL, FOUR_SIGMA_D12 = 4 * INIT_RMS_SMALL, INIT_MAX_D12
 EMU_RMS_SMALL = 1.0e-4    # dim 64: rms of (fast path - fp32 CPU oracle with the SAME operand roundings emulated): measured 0.82e-4 / 0.85e-4
 
 
@@ -93,7 +100,9 @@ def emulated_oracle_grads(cfg, state, x1, x0, times, frac, rand, mask=None):
 # oracle with this path's fp16 operand roundings emulated: <= 2.4 % with none, 20 - 42 % through one, ~150 % through two -- there the
 # gradient is dominated by the operand rounding of ANY reduced-precision implementation (it is not a conditioning property of this
 # code), so only the classes with 0 / 1 softmaxes are asserted; `small_wc` (trained-regime logits) holds EVERY tensor at 3 %.
-REF_GRAD_CLASS0, REF_GRAD_CLASS1 = 0.10, 0.6  # class 0: 2.3 % (round 3's q rounding) / 6.5 % (round 5's) on this one realisation
+# SANITY bounds on one chaotic realisation (measured x 1.5: class 0 worst 6.5 %, class 1 worst 59 %), not parity statements -- the tight,
+# realisation-independent twins are the emulated-precision oracle below (every tensor) and the *_wc goldens (every tensor at 3 %).
+REF_GRAD_CLASS0, REF_GRAD_CLASS1 = 0.10, 0.9
 
 
 def softmaxes_downstream(name, depth):
@@ -142,7 +151,7 @@ def test_small_golden_loss_and_grads(golden):
             print(f"relative grad errors vs REFERENCE, {c} softmax(es) between tensor and loss:", mask_key, [(k, round(v, 4)) for v, k in es[:4]])
         worst0 = max(v for k, v in rerrs.items() if cls[k] == 0)
         worst1 = max(v for k, v in rerrs.items() if cls[k] == 1)
-        assert worst0 < REF_GRAD_CLASS0 and worst1 < REF_GRAD_CLASS1, (worst0, worst1)
+        assert worst0 < REF_GRAD_CLASS0 and worst1 < REF_GRAD_CLASS1, ("sanity bound on a chaotic realisation (parity: the emulated-precision oracle below)", worst0, worst1)
         # gradients vs the emulated-precision oracle: every tensor, bf16-GEMM tolerance
         eloss, egrads = emulated_oracle_grads(cfg, g["state"], g["x1"], g["x0"], g["times"], g["frac"], g["rand"], mask)
         # (48 + 24 seeds of this statistic: test_small_reference_init_loss_statistics -- rms 0.8e-4, max 2.7e-4)
@@ -186,7 +195,8 @@ def test_small_golden_eval_and_sample(golden):
             # (b) against the fp32 reference: this random-init, qk-normed net has logits of std ~80 and its flow
             # field is ill-conditioned in its input -- 2 big midpoint steps turn a 2% per-evaluation error
             # (fp16 operands) into ~9% (the emulated CPU oracle shows the same 9.3%); 4 steps: ~4%.
-            assert rel(s, g[key]) < 0.12, (key, use_graph, rel(s, g[key]))  # measured 0.092 / 0.053; benign network: 5e-4 (below)
+            # sanity bound (measured 0.093 / 0.054 x 1.3), not a parity statement: the parity checks are (a) above and the benign network below (5e-4)
+            assert rel(s, g[key]) < 0.12, ("sanity bound on a chaotic flow", key, use_graph, rel(s, g[key]))
             print("sample", key, "graph" if use_graph else "eager", "vs emulated", rel(s, emu), "vs reference", rel(s, g[key]))
     # the captured graph must replay identically
     with rng_override(y0=g["y0"]):
@@ -950,7 +960,7 @@ def test_reference_init_loss_statistics(golden):
         print("   fast path by seed", [round(d, 5) for d in fast])
         # n seeds of a heavy-tailed zero-mean variable with the stated RMS: mean |d| (~0.75 RMS) below the RMS itself, the sample RMS
         # within +35 % (3 standard errors at n = 16), no seed beyond 4 sigma
-        assert fm <= INIT_RMS_D12 and fr <= 1.35 * INIT_RMS_D12 and fx <= FOUR_SIGMA_D12, (tag, fm, fr, fx)
+        assert fm <= INIT_MEAN_D12 and fr <= INIT_RMS_D12 and fx <= INIT_MAX_D12, (tag, fm, fr, fx)
         if precise:
             pm, pr, px = _stats(precise)
             print(f"   precise mode mean|d| {pm:.2e} rms {pr:.2e} max {px:.2e}; by seed", [round(d, 5) for d in precise])
