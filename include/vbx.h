@@ -143,22 +143,18 @@ int vbx_attn_fwd(const void* q16, const void* k16, const void* v16 /* fp16 */, c
                  float* lse, int B, int H, int Np, float scale, void* stream);
 /* backward (autograd of attend.py:121-135).  dout bf16 [B,Np,H*64]; qb,kb bf16 copies of q,k; delta fp32 [B,H,Np] scratch;
  * dq,dk fp32 [B,H,Np,64]; dv is written bf16 token-major at dv[(b*Np+n)*dv_ld + h*64 + d].
- * Two kernels serve it.  The two-body kernel (default): dq and dk/dv bodies in one launch, S / dP evaluated in both.  The ONE-PASS
- * kernel (vbx_attn_bwd_select(2) or VBX_ATTN_BWD_ONEPASS=1; needs `scratch`): every S / dP block evaluated once, dq summed over the
- * key blocks of a head by an ordered, deterministic chain of workgroups through the scratch -- bit-identical dk / dv, measured slower
- * on MI355X so far, kept selectable.  The one-pass kernel needs an EXCLUSIVE device: its workgroups wait on
- * each other through device memory, and a wait that exceeds the spin limit (a preempted or time-sliced GPU) traps -- the HIP context
- * of the process is lost (every stream, cached graph and communicator), by design rather than returning a partial dq.  An A/B tool,
- * not a production path; the default kernels have no inter-workgroup waits.
- * scratch: vbx_attn_bwd_scratch_bytes(B,H,Np) bytes of device memory (256-byte aligned), or NULL (two-body only).
- * vbx_attn_bwd_select: 0 automatic (= two-body), 1 two-body, 2 one-pass (error without scratch; under stream capture the two-body
- * kernel runs, because the chain's flags carry a per-launch epoch passed by value), 3 two-body WITHOUT round 5's fold of the softmax
- * statistics into the MFMA accumulator (csrc/attn_bwd_fold.inc; round 3's bodies: results bit-identical to the one-pass kernel's,
- * ~25 % slower; also VBX_ATTN_BWD_FOLD=0).  The folded bodies evaluate P = exp2(-(L - q.k)) with L added inside the matrix pipe;
- * they differ from 3 by fp32 rounding of the exponent only. */
+ * One kernel family serves it: the TWO-BODY kernel -- dq and dk/dv bodies in one launch, S / dP evaluated in both, no inter-workgroup
+ * waits, deterministic.  By default its softmax statistics are folded into the MFMA accumulator (csrc/attn_bwd_fold.inc: P = exp2(-(L - q.k))
+ * with L added inside the matrix pipe); vbx_attn_bwd_select(3) / VBX_ATTN_BWD_FOLD=0 runs the same bodies without the fold (round 3's
+ * arithmetic -- what attention dropout always uses); the two differ by fp32 rounding of the exponent only.  Tail tiles of <= 16 rows
+ * (Np % 128 <= 16: the register tokens) run a 16 x 16 MFMA role with their ring rows split over the waves (csrc/attn_bwd_ragged.inc).
+ * Round 3's ONE-PASS chain kernel (select 2: S / dP once, dq summed by an ordered chain of workgroups through device memory) was correct
+ * and 30 - 60 % slower; it was removed in round 6 (docs/history.md): vbx_attn_bwd_select(2) returns VBX_EUNSUPPORTED and
+ * vbx_attn_bwd_scratch_bytes() 0.  `scratch` stays in the signatures for ABI stability and is ignored (pass NULL).
+ * vbx_attn_bwd_select: 0 automatic (= 1), 1 folded two-body, 3 unfolded two-body. */
 size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np);
 int vbx_attn_bwd_select(int variant);
-int vbx_attn_bwd_variant(void); /* 1 two-body, 2 one-pass: which kernel the current selection runs (callers size `scratch` by it) */
+int vbx_attn_bwd_variant(void); /* always 1 (two-body) since round 6 */
 int vbx_attn_bwd(const void* q16, const void* k16, const void* qb, const void* kb, const void* v,
                  const uint8_t* mask, const void* out /* forward output [B,Np,H*64]; NULL: `delta` already holds rowsum(dO * O)
                                                          (vbx_gemm_desc.delta) and the pass that computes it is skipped */, int out_is_f16,

@@ -334,15 +334,13 @@ def test_duration_predictor_host_logic(golden):
                                                                 condition_on_text=False), duration_predictor=dp)
 
 
-@pytest.mark.parametrize("which", ["gemm3", "gemm4", "epi_stage", "attn_bwd1"])
+@pytest.mark.parametrize("which", ["gemm3", "gemm4", "epi_stage"])
 def test_gemm_tile_lds_layout_emulation(tmp_path, which):
     """csrc/gemm3_layout.hpp / gemm4_layout.hpp (LDS-DMA source permutation, fragment read addresses, transposed-accumulator
     column map of the 256 x 256 and 128 x 256 GEMM tiles; gemm3's K-contiguous layout is also the one-round 64-deep tile's)
     replayed on the host against a plain GEMM, plus bank-conflict freedom of every fragment read and the DS-immediate identities
     the kernels rely on; csrc/epi_stage_layout.hpp (the row-staged epilogues' transposing LDS image): every (row, chunk) comes back
-    once and in order, writes at most 2-way, reads conflict free; csrc/attn_bwd1_layout.hpp (one-pass attention backward): the per-XCD
-    work queues cover every (head, key block) once with predecessors first, the transposing dS^T image round-trips through the
-    hardware transpose read into the operand order the Kb^T fragments use, the XOR address identities hold."""
+    once and in order, writes at most 2-way, reads conflict free."""
     import subprocess
 
     exe = str(tmp_path / f"{which}_layout_check")

@@ -307,14 +307,17 @@ def test_rmsnorm_fwd_bwd(L, Bsz, Np, n0, rpb, D, adaptive):
 
 # ----------------------------------------------------------------------------- attention
 def attn_scratch(L, Bsz, H, Np):
-    """Scratch of the one-pass attention backward (poisoned: the kernel must not depend on its contents)."""
-    return torch.full((L.lib().vbx_attn_bwd_scratch_bytes(Bsz, H, Np),), 0xFF, dtype=torch.uint8, device=dev)
+    """The `scratch` argument of vbx_attn_bwd*: no kernel uses it since round 6 (vbx_attn_bwd_scratch_bytes() == 0); kept in the ABI."""
+    assert L.lib().vbx_attn_bwd_scratch_bytes(Bsz, H, Np) == 0
+    return None
 
 
-@pytest.fixture(params=[2, 1], ids=["onepass", "twobody"])
+@pytest.fixture(params=[3, 1], ids=["unfolded", "folded"])
 def bwd_variant(request, L):
-    """Both attention-backward kernels behind vbx_attn_bwd / vbx_attn_bwd_fused: the one-pass chain kernel (round 3, default when
-    scratch is given) and the two-body kernel of round 2."""
+    """Both attention-backward kernels behind vbx_attn_bwd / vbx_attn_bwd_fused: the two-body kernel with the softmax statistics folded
+    into the MFMA accumulator (round 5, default) and the same bodies without the fold (select 3; also what attention dropout runs on).
+    The one-pass chain kernel of round 3 (select 2) was removed in round 6: selecting it is an error."""
+    assert L.lib().vbx_attn_bwd_select(2) != 0
     L.lib().vbx_attn_bwd_select(request.param)
     yield request.param
     L.lib().vbx_attn_bwd_select(0)
@@ -649,36 +652,6 @@ def _bwd_fused(L, c, variant, scratch=None):
     return d, gp, scratch
 
 
-def _chain_bookkeeping_ok(scratch, Bsz, H, Np):
-    """Sync words of the one-pass kernel after a launch: no spin timed out, and every XCD queue was drained (each of the 8 queue heads
-    was advanced past its item count -- a queue nobody served would leave that XCD's heads without gradients)."""
-    w = scratch[:64].view(torch.int32).cpu()
-    n_kb, BH = (Np + 127) // 128, Bsz * H
-    assert int(w[8]) == 0, "a chain member timed out waiting for its predecessor"
-    for x in range(8):
-        heads = len(range(x, BH, 8))
-        assert int(w[x]) >= heads * n_kb, (x, int(w[x]), heads * n_kb)
-
-
-@pytest.mark.parametrize("Bsz,H,Np,masked", [(8, 16, 1040, False), (2, 16, 1040, True), (3, 5, 520, False), (1, 2, 130, False)])
-def test_attn_bwd_onepass_equals_two_body(L, Bsz, H, Np, masked):
-    """The one-pass backward (every S / dP block evaluated once, dq summed by the ordered chain of a head's key-block workgroups)
-    against the two-body kernel of round 2 on the same inputs -- including the BENCHMARK GRID B = 8, H = 16, Np = 1040 (1152 chain
-    items on 512 persistent workgroups).  dv / dk come out of the same arithmetic in the same order: bit-identical.  dq sums the same
-    bf16-rounded dS blocks in a different association: equal up to the bf16 rounding of the output."""
-    c = _bwd_case(L, Bsz, H, Np, seed=Np + Bsz, masked=masked)
-    d1, g1, _ = _bwd_fused(L, c, 3)  # 3 = the two-body kernel WITHOUT round 5's fold (same exponent arithmetic as the one-pass kernel)
-    d2, g2, scratch = _bwd_fused(L, c, 2)
-    I = H * 64
-    _chain_bookkeeping_ok(scratch, Bsz, H, Np)
-    assert torch.isfinite(d2.float()).all()
-    assert torch.equal(d1[:, 2 * I:], d2[:, 2 * I:]), "dv"
-    assert torch.equal(d1[:, I:2 * I], d2[:, I:2 * I]), "dk"
-    assert rel_err(d2[:, :I].float(), d1[:, :I].float()) < 6e-3, rel_err(d2[:, :I].float(), d1[:, :I].float())
-    assert torch.equal(g1[1], g2[1]), "k gamma partials"
-    assert rel_err(g2[0].sum(0), g1[0].sum(0)) < 2e-3
-
-
 @pytest.mark.parametrize("Bsz,H,Np,masked", [(8, 16, 1040, False), (2, 4, 1040, True), (3, 5, 520, False), (1, 2, 130, True), (1, 2, 24, False)])
 def test_attn_bwd_folded_statistics_equal_the_unfolded_bodies(L, Bsz, H, Np, masked):
     """Round 5's default backward (csrc/attn_bwd_fold.inc: L and delta enter as the C operand of the S / dP MFMA chains, negated
@@ -697,44 +670,6 @@ def test_attn_bwd_folded_statistics_equal_the_unfolded_bodies(L, Bsz, H, Np, mas
         e = rel_err(d1[:, blk * I:(blk + 1) * I].float(), d3[:, blk * I:(blk + 1) * I].float())
         assert e < 6e-3, (name, e)
     assert rel_err(g1.sum(1), g3.sum(1)) < 2e-3
-
-
-@pytest.mark.parametrize("Np", [130, 200])
-def test_attn_bwd_onepass_early_consumer_over_repeated_launches(L, Np):
-    """Regression for a hand-off race found on hardware (round 3): with two key blocks per head the chain's last member has 2 / 72 keys
-    and reaches its first flag long before the head's first member has produced anything -- and, launched repeatedly on the SAME scratch
-    memory, its first (L1-bypassing) flag read could return the value the PREVIOUS launch had left in that word, so it consumed a tile
-    that was not there yet (22 of 32 launches wrong).  Flags now carry a per-launch epoch.  32 launches on one re-poisoned scratch
-    buffer: every result must be finite, equal to the two-body kernel's, and identical from launch to launch."""
-    c = _bwd_case(L, 1, 2, Np, seed=Np)
-    d1, g1, _ = _bwd_fused(L, c, 3)  # the unfolded two-body kernel: bit-identical dk / dv
-    I = 2 * 64
-    scratch = attn_scratch(L, 1, 2, Np)
-    first = None
-    for rep in range(32):
-        scratch.fill_(0xFF if rep % 2 == 0 else 0x5A)
-        d2, g2, _ = _bwd_fused(L, c, 2, scratch=scratch)
-        assert torch.isfinite(d2.float()).all(), rep
-        assert torch.equal(d1[:, I:], d2[:, I:]), rep
-        assert rel_err(d2[:, :I].float(), d1[:, :I].float()) < 6e-3, rep
-        if first is None:
-            first = (d2.clone(), g2.clone())
-        assert torch.equal(d2, first[0]) and torch.equal(g2, first[1]), rep
-    _chain_bookkeeping_ok(scratch, 1, 2, Np)
-
-
-def test_attn_bwd_onepass_is_deterministic_and_ignores_scratch_contents(L):
-    """Two launches of the one-pass backward on the same inputs give bit-identical d(qkv) and gamma partials although the chain
-    members run in whatever order the hardware schedules them (the ORDER of the additions is fixed by the chain, not by timing) and the
-    scratch holds different garbage each time."""
-    c = _bwd_case(L, 4, 16, 1040, seed=77)
-    n = L.lib().vbx_attn_bwd_scratch_bytes(4, 16, 1040)
-    outs = []
-    for fill in (0x00, 0xFF, 0x5A):
-        d, gp, _ = _bwd_fused(L, c, 2, scratch=torch.full((n,), fill, dtype=torch.uint8, device=dev))
-        outs.append((d.clone(), gp.clone()))
-    for d, gp in outs[1:]:
-        assert torch.equal(d, outs[0][0]) and torch.equal(gp, outs[0][1])
 
 
 # ----------------------------------------------------------------------------- small ops

@@ -25,7 +25,7 @@ dq = torch.zeros(B, H, Np, 64, device=dev); dk = torch.zeros(B, H, Np, 64, devic
 dv = torch.zeros(B, Np, H * 64, dtype=torch.bfloat16, device=dev)
 
 
-scratch = torch.empty(L.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)  # one-pass backward (VBX_ATTN_BWD_ONEPASS=0: two-body)
+scratch = None  # (no kernel needs scratch since round 6)
 
 
 def fwd():

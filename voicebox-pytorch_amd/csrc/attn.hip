@@ -11,7 +11,6 @@
 // and the P^T accumulator registers are already the B operand of the next MFMA (slot s of half hi <->
 // key (s&3) + 8*(s>>2) + 4*hi inside each 16-key group; the V^T fragment uses the same key order).
 #include "common.hpp"
-#include "attn_bwd1_layout.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -32,70 +31,7 @@ VBX_DEV int attn_swz(int row) {
   const int p = row >> 1;
   return ((p & 1) << 2) | ((p >> 1) & 3);
 }
-VBX_DEV int swz_off2(int row, int chunk) { return row * 128 + ((chunk ^ attn_swz(row)) << 4); }  // LDS-DMA forward kernels
-// register-staged kernels (legacy forward, both backward kernels) keep the row&7 key: their transposed reads reach rows
-// +8 through one address and an immediate (key(row+8) == key(row)); measured with the new key there: backward 217 -> 234 us
-VBX_DEV int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-// cooperative (256 threads) load of a [64][64] 16-bit tile: 2 x 16 B per thread.
-struct Stage2 {
-  uint4 v[2];
-};
-VBX_DEV void tile_g2r(Stage2& s, const u16* __restrict__ base, long row_stride, int row0, int row_lim, bool zero_oob, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, ch = c & 7;
-    int gr = row0 + row;
-    const bool oob = gr >= row_lim;
-    if (oob) gr = row_lim - 1;
-    uint4 v = *reinterpret_cast<const uint4*>(base + (long)gr * row_stride + ch * 8);
-    if (oob && zero_oob) v = make_uint4(0u, 0u, 0u, 0u);
-    s.v[i] = v;
-  }
-}
-VBX_DEV void tile_r2s(const Stage2& s, char* tile, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int c = tid + 256 * i;
-    *reinterpret_cast<uint4*>(tile + swz_off(c >> 3, c & 7)) = s.v[i];
-  }
-}
-
-// Same, with rows at or past row_lim stored as zeros.  The select sits HERE, where the staged registers are consumed anyway:
-// applied at load time (tile_g2r's zero_oob) it reads the loaded value at once, i.e. hipcc waits vmcnt(0) right after issuing
-// the prefetch and the whole global-load latency is exposed in every iteration instead of hiding behind the tile's MFMAs.
-VBX_DEV void tile_r2s_zero_oob(const Stage2& s, char* tile, int row0, int row_lim, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int c = tid + 256 * i;
-    uint4 v = s.v[i];
-    if (row0 + (c >> 3) >= row_lim) v = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(tile + swz_off(c >> 3, c & 7)) = v;
-  }
-}
-
-// K-contiguous fragment: row (lane&31) of the 32-row block, 8 elements at d = 16*t + 8*hi.
-template <class V8>
-VBX_DEV V8 row_frag(const char* tile, int blk32, int t, int lane) {
-  const int row = blk32 * 32 + (lane & 31);
-  return *reinterpret_cast<const V8*>(tile + swz_off(row, 2 * t + (lane >> 5)));
-}
-
-// Transposed fragment (hardware transpose read): operand X^T[i = d_local][kk = slot], for the 16 rows
-// [rbase, rbase+16) of the tile and the 32 columns [d0, d0+32).  Slot s of lane-half hi is row
-// rbase + (s&3) + 8*(s>>2) + 4*hi.
-VBX_DEV bf16x8 tr_frag(const char* tile, int rbase, int d0, int lane) {
-  const int G = lane >> 4, a = lane & 15;
-  const int row = rbase + 4 * (G >> 1) + (a >> 2);
-  const int d = d0 + (G & 1) * 16 + 4 * (a & 3);
-  const char* p = tile + swz_off(row, d >> 3) + (d & 7) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 8 * 128));  // row+8 keeps row&7
-  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, r);
-}
-
+VBX_DEV int swz_off2(int row, int chunk) { return row * 128 + ((chunk ^ attn_swz(row)) << 4); }
 VBX_DEV bf16x8 pack_frag(const f32x16& p, int t2) {
   bf16x8 r;
 #pragma unroll
@@ -335,162 +271,8 @@ __device__ unsigned long long* g_attn_trace = nullptr;
 #define ATTN_TRACE_END(TAG)
 #endif
 
-// ============================================================================ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
-                                                          const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
-                                                          u16* __restrict__ out, u16* __restrict__ outb,
-                                                          float* __restrict__ lse, int H, int Np, float scale2, int abl, int BH, int xmap) {
-  // abl: timing ablations (tools only, results wrong): 1 no K/V staging after tile 0, 2 no softmax math, 4 no P.V, 8 no Q.K
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K tile | V tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const AttnCoord co = attn_coord(H, Np, BH, xmap);
-  if (!co.ok) return;
-  const int h = co.h, b = co.b;
-  const long bh = (long)b * H + h;
-  const u16* kbase = k16 + bh * Np * 64;
-  const u16* vbase = vv + bh * Np * 64;
-  const int q0 = co.tile * 128 + wave * 32;
-  const bool active = q0 < Np;
-  const int q = q0 + (lane & 31);
-  const int qc = min(q, Np - 1);
-
-  f16x8 qf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = NEG_INF, l_run = 0.f;
-
-  const int ntiles = (Np + 63) / 64;
-  Stage2 sk, sv;
-  tile_g2r(sk, kbase, 64, 0, Np, false, tid);
-  tile_g2r(sv, vbase, 64, 0, Np, false, tid);
-  tile_r2s(sk, smem, tid);
-  tile_r2s(sv, smem + TILE16, tid);
-  __syncthreads();
-
-  for (int kt = 0; kt < ntiles; kt++) {
-    const char* Kt = smem + (kt & 1) * 2 * TILE16;
-    const char* Vt = Kt + TILE16;
-    const bool more = kt + 1 < ntiles;
-    if (more && !(abl & 1)) {
-      tile_g2r(sk, kbase, 64, (kt + 1) * 64, Np, false, tid);
-      tile_g2r(sv, vbase, 64, (kt + 1) * 64, Np, false, tid);
-    }
-    if (active) {
-      const int k0 = kt * 64;
-      const int nblk = (Np - k0 > 32) ? 2 : 1;  // the tail tile may hold <= 32 valid keys
-      f32x16 s[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[kb][i] = 0.f;
-        if (kb < nblk && !(abl & 8)) {
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Kt, kb, t, lane), qf[t], s[kb], 0, 0, 0);
-        }
-      }
-      const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
-      if (need_mask) {
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const int kg = k0 + kb * 32 + acc_row(r, hi);
-            bool ok = kg < Np;
-            if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
-            if (!ok) s[kb][r] = NEG_INF;
-          }
-      }
-      if (!(abl & 2)) {
-      float mx = NEG_INF;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * scale2);
-      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = fast_exp2(m_run - m_use);
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float p = fast_exp2(fmaf(s[kb][r], scale2, -m_use));
-          s[kb][r] = p;
-          psum += p;
-        }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++) {
-        if (kb < nblk && !(abl & 4)) {
-#pragma unroll
-          for (int t2 = 0; t2 < 2; t2++) {
-            const f16x8 pf = pack_frag_f16_fast(s[kb], t2);
-#pragma unroll
-            for (int db = 0; db < 2; db++)
-              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                  __builtin_bit_cast(f16x8, tr_frag(Vt, kb * 32 + 16 * t2, db * 32, lane)), pf, o[db], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (more && !(abl & 1)) {
-      char* Kn = smem + ((kt + 1) & 1) * 2 * TILE16;
-      tile_r2s(sk, Kn, tid);
-      tile_r2s(sv, Kn + TILE16, tid);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue.  O^T sits in registers as (lane = query, 4 consecutive d per register group): storing that
-  // directly is 16 8-byte stores per lane to 128-byte-strided rows -- store-ISSUE bound (27 us of the 83 us kernel were
-  // fixed cost).  Stage each wave's 32x64 tile through LDS ([q][d], 16-byte chunks XOR-swizzled by q&7) and write
-  // whole 128-byte rows with 16-byte stores: 4 per lane per output, fully coalesced.
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-  if (active && hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
-  char* ost = smem + wave * 8192;  // 32 rows x 128 B fp16 | 32 rows x 128 B bf16 (the K/V ring is dead after the loop's last barrier)
-  if (active) {
-    const int ql = lane & 31;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int d = db * 32 + 8 * g4 + 4 * hi;
-        const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
-                    v3 = o[db][4 * g4 + 3] * inv;
-        const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
-        *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
-        if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (active) {
-    // wave-private staging: only this wave's lanes touch ost, the DS queue is in order -> no block barrier needed
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      const int qq = q0 + row;
-      if (qq < Np) {
-        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
-        const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
-        *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
-        if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
-      }
-    }
-  }
-}
-
+// (Rounds 1-2's forward kernels -- the register-staged double buffer and the 3-slot / 3-per-CU LDS-DMA form "v2" -- were removed in
+//  round 6; their measurements are in docs/history.md.  The helpers of the LDS-DMA ring they introduced follow.)
 
 // ============================================================================ forward, v2: LDS-DMA ring
 // K|V tiles (16 KiB per 64 keys) arrive by global_load_lds into a 3-slot ring (48 KiB -> 3 workgroups per CU) with two
@@ -498,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const u16* __restrict_
 // so the 16-byte XOR swizzle is applied to the per-lane SOURCE address (slot s holds logical chunk (s&7)^(row&7)).
 // Fragment reads are inline asm (a compiler-visible ds_read would make hipcc drain vmcnt(0) while DMAs are in flight)
 // with the ring slot / key block folded into the DS immediate.
-constexpr int ANST = 3;
 constexpr int ASTAGE = 2 * TILE16;
 
 VBX_DEV unsigned lds_addr32(const char* p) { return (unsigned)(size_t)LDS_PTR(char, p); }
@@ -546,234 +327,6 @@ template <int OFF>
 VBX_DEV void asm_read_tr(s16x4& lo, s16x4& hi, unsigned a, unsigned a8) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(OFF) : "memory");
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a8), "i"(OFF) : "memory");
-}
-
-template <int abl>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel_v2(const u16* __restrict__ q16, const u16* __restrict__ k16,
-                                                             const u16* __restrict__ vv, const uint8_t* __restrict__ mask,
-                                                             u16* __restrict__ out, u16* __restrict__ outb,
-                                                             float* __restrict__ lse, int H, int Np, float scale2, int BH, int xmap) {
-  // abl (tools only, wrong results): 1 no per-tile barrier, 2 no exp, 4 no P.V MFMAs, 8 no Q.K MFMAs, 16 no K|V DMA after the prologue
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // ring: [slot][K tile | V tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const AttnCoord co = attn_coord(H, Np, BH, xmap);
-  if (!co.ok) return;
-  const int h = co.h, b = co.b;
-  const long bh = (long)b * H + h;
-  const u16* kbase = k16 + bh * Np * 64;
-  const u16* vbase = vv + bh * Np * 64;
-  const int q0 = co.tile * 128 + wave * 32;
-  const bool active = q0 < Np;
-  const int q = q0 + (lane & 31);
-  const int qc = min(q, Np - 1);
-  const int ntiles = (Np + 63) / 64;
-  long clk0 = 0, wclk0 = 0;
-  if (abl == 64) { clk0 = clock64(); wclk0 = wall_clock64(); }
-
-#pragma unroll
-  for (int s = 0; s < ANST - 1; s++)
-    if (s < ntiles) {
-      dma_tile(smem + s * ASTAGE, kbase, s * 64, Np, tid);
-      dma_tile(smem + s * ASTAGE + TILE16, vbase, s * 64, Np, tid);
-    }
-
-  f16x8 qf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
-  // Retire the Q loads HERE.  Left pending, hipcc's waitcnt pass cannot count the (conditional) DMA issues younger than
-  // them and puts `s_waitcnt vmcnt(0)` in front of the first Q.K MFMA of EVERY tile -- which drains the two K|V tiles
-  // just put in flight and turns the 3-slot ring into a synchronous load per tile.
-#pragma unroll
-  for (int t = 0; t < 4; t++) asm volatile("" ::"v"(qf[t]));
-
-  // lane-constant LDS addresses (slot 0, key block 0): K rows for the four d-steps; V transpose reads for the two d-halves
-  unsigned ka[4], va[2], va8[2];  // va8: rows +8 (the swizzle key differs there; +16 / +32 rows keep it)
-  {
-    const int row = lane & 31;
-#pragma unroll
-    for (int t = 0; t < 4; t++) ka[t] = lds_addr32(smem + swz_off2(row, 2 * t + hi));
-    const int G = lane >> 4, a16 = lane & 15;
-    const int vrow = 4 * (G >> 1) + (a16 >> 2);
-#pragma unroll
-    for (int db = 0; db < 2; db++) {
-      const int d = db * 32 + (G & 1) * 16 + 4 * (a16 & 3);
-      va[db] = lds_addr32(smem + TILE16 + swz_off2(vrow, d >> 3) + (d & 7) * 2);
-      va8[db] = lds_addr32(smem + TILE16 + swz_off2(vrow + 8, d >> 3) + (d & 7) * 2);
-    }
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = NEG_INF, l_run = 0.f;
-
-  auto step = [&](auto stg_c, int kt) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + ANST - 1) % ANST;
-    constexpr int SO = STG * ASTAGE;
-    if (ntiles - 1 - kt >= ANST - 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(abl & 1)) __builtin_amdgcn_s_barrier();
-    if (kt + ANST - 1 < ntiles && !(abl & 16)) {
-      dma_tile(smem + NXT * ASTAGE, kbase, (kt + ANST - 1) * 64, Np, tid);
-      dma_tile(smem + NXT * ASTAGE + TILE16, vbase, (kt + ANST - 1) * 64, Np, tid);
-    }
-    if (!active) return;
-    const int k0 = kt * 64;
-    const bool two = (Np - k0 > 32);  // the tail tile may hold <= 32 valid keys
-    f32x16 s[2];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { s[0][i] = 0.f; s[1][i] = 0.f; }
-    {
-      f16x8 kf0[4], kf1[4];
-      kf0[0] = asm_read_b128<SO>(ka[0]); kf0[1] = asm_read_b128<SO>(ka[1]);
-      kf0[2] = asm_read_b128<SO>(ka[2]); kf0[3] = asm_read_b128<SO>(ka[3]);
-      kf1[0] = asm_read_b128<SO + 4096>(ka[0]); kf1[1] = asm_read_b128<SO + 4096>(ka[1]);
-      kf1[2] = asm_read_b128<SO + 4096>(ka[2]); kf1[3] = asm_read_b128<SO + 4096>(ka[3]);
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (!(abl & 8))
-#pragma unroll
-      for (int t = 0; t < 4; t++) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[t], qf[t], s[0], 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (two && !(abl & 8)) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[t], qf[t], s[1], 0, 0, 0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
-    // V^T fragments of the whole tile are requested NOW: they land while the softmax below keeps the VALU busy
-    // (issued after the softmax they cost an exposed LDS round trip in front of each P.V block)
-    s16x4 vl[2][4], vh[2][4];
-    asm_read_tr<SO>(vl[0][0], vh[0][0], va[0], va8[0]);
-    asm_read_tr<SO>(vl[0][1], vh[0][1], va[1], va8[1]);
-    asm_read_tr<SO + 2048>(vl[0][2], vh[0][2], va[0], va8[0]);
-    asm_read_tr<SO + 2048>(vl[0][3], vh[0][3], va[1], va8[1]);
-    asm_read_tr<SO + 4096>(vl[1][0], vh[1][0], va[0], va8[0]);
-    asm_read_tr<SO + 4096>(vl[1][1], vh[1][1], va[1], va8[1]);
-    asm_read_tr<SO + 4096 + 2048>(vl[1][2], vh[1][2], va[0], va8[0]);
-    asm_read_tr<SO + 4096 + 2048>(vl[1][3], vh[1][3], va[1], va8[1]);
-    const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
-    if (need_mask) {
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int kg = k0 + kb * 32 + acc_row(r, hi);
-          bool ok = kg < Np;
-          if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
-          if (!ok) s[kb][r] = NEG_INF;
-        }
-    }
-    float mx = NEG_INF;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale2);
-    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-    const float alpha = fast_exp2(m_run - m_use);
-    // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): two logits per VALU instruction
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 sc2 = {scale2, scale2}, mneg = {-m_use, -m_use};
-    f2 ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f2 sv = {s[kb][r], s[kb][r + 1]};
-        const f2 e = __builtin_elementwise_fma(sv, sc2, mneg);
-        const f2 p = (abl & 2) ? e : (f2){fast_exp2(e.x), fast_exp2(e.y)};
-        s[kb][r] = p.x;
-        s[kb][r + 1] = p.y;
-        ps2 += p;
-      }
-    l_run = l_run * alpha + (ps2.x + ps2.y);
-    m_run = m_new;
-    {
-      const f2 a2 = {alpha, alpha};
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        f2 t0 = {o[0][i], o[0][i + 1]}, t1 = {o[1][i], o[1][i + 1]};
-        t0 *= a2;
-        t1 *= a2;
-        o[0][i] = t0.x; o[0][i + 1] = t0.y;
-        o[1][i] = t1.x; o[1][i + 1] = t1.y;
-      }
-    }
-    // O^T += V^T . P^T : per 32-key block, 2 sixteen-key groups x 2 d-halves
-    const f16x8 p00 = pack_frag_f16_fast(s[0], 0), p01 = pack_frag_f16_fast(s[0], 1);
-    const f16x8 p10 = pack_frag_f16_fast(s[1], 0), p11 = pack_frag_f16_fast(s[1], 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f16x8 vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const s16x8 t = {vl[kb][j][0], vl[kb][j][1], vl[kb][j][2], vl[kb][j][3], vh[kb][j][0], vh[kb][j][1], vh[kb][j][2], vh[kb][j][3]};
-        vf[kb][j] = __builtin_bit_cast(f16x8, t);
-      }
-    __builtin_amdgcn_s_setprio(1);
-    if (!(abl & 4)) {
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], p00, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], p00, o[1], 0, 0, 0);
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][2], p01, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][3], p01, o[1], 0, 0, 0);
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], p10, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], p10, o[1], 0, 0, 0);
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][2], p11, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][3], p11, o[1], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  for (int kt = 0; kt < ntiles; kt += 3) {
-    step(std::integral_constant<int, 0>{}, kt);
-    if (kt + 1 < ntiles) step(std::integral_constant<int, 1>{}, kt + 1);
-    if (kt + 2 < ntiles) step(std::integral_constant<int, 2>{}, kt + 2);
-  }
-  __syncthreads();  // every wave is done with the ring before it becomes epilogue staging space
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
-  if (active && hi == 0 && q < Np) lse[bh * Np + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) : 1e30f;
-  char* ost = smem + wave * 8192;
-  if (active) {
-    const int ql = lane & 31;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int d = db * 32 + 8 * g4 + 4 * hi;
-        const float v0 = o[db][4 * g4 + 0] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
-                    v3 = o[db][4 * g4 + 3] * inv;
-        const int off = ql * 128 + ((((d >> 3) ^ (ql & 7))) << 4) + (d & 7) * 2;
-        *reinterpret_cast<uint2*>(ost + off) = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
-        if (outb) *reinterpret_cast<uint2*>(ost + 4096 + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (active) {
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      const int qq = q0 + row;
-      if (qq < Np) {
-        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
-        const long go = ((long)b * Np + qq) * (H * 64) + h * 64 + ch * 8;
-        *reinterpret_cast<uint4*>(out + go) = *reinterpret_cast<const uint4*>(ost + off);
-        if (outb) *reinterpret_cast<uint4*>(outb + go) = *reinterpret_cast<const uint4*>(ost + 4096 + off);
-      }
-    }
-  }
-  if (abl == 64 && tid == 0 && co.tile == 0) {  // shader-clock probe: cycles and 100 MHz ticks this workgroup lived
-    lse[bh * Np + 0] = (float)(clock64() - clk0);
-    lse[bh * Np + 1] = (float)(wall_clock64() - wclk0);
-  }
 }
 
 // ============================================================================ forward, v3: 4 workgroups per CU
@@ -882,9 +435,8 @@ VBX_ABL_KERNEL(447) { extern __shared__ __attribute__((aligned(16))) char smem[]
 //  launch they replace.  Kept as a separate streaming pass at 4 TB/s.)
 template <bool O_F16>
 __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ dout, float* __restrict__ delta, int H,
-                                  int Np, long total_chunks, unsigned* __restrict__ sync, int nsync) {
+                                  int Np, long total_chunks) {
   const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one 8-element chunk per thread
-  if (c < nsync) sync[c] = 0u;  // queue heads / error word of the one-pass backward that follows on this stream
   const long cc = min(c, total_chunks - 1);
   const uint4 a = *reinterpret_cast<const uint4*>(o + cc * 8);
   const uint4 g = *reinterpret_cast<const uint4*>(dout + cc * 8);
@@ -910,279 +462,7 @@ __global__ void attn_delta_kernel(const u16* __restrict__ o, const u16* __restri
   }
 }
 
-// ============================================================================ backward: dq
-// grid as forward.  LDS per buffer: K16 | Kb | V tiles.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restrict__ q16, const u16* __restrict__ k16,
-                                                             const u16* __restrict__ kb16, const u16* __restrict__ vv,
-                                                             const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             float* __restrict__ dq, int H, int Np, float scale2,
-                                                             float scale, int BH, int xmap, QKBwd fq) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const AttnCoord co = attn_coord(H, Np, BH, xmap);
-  if (!co.ok) return;
-  const int h = co.h, b = co.b;
-  const long bh = (long)b * H + h;
-  const u16* kbase = k16 + bh * Np * 64;
-  const u16* kbbase = kb16 + bh * Np * 64;
-  const u16* vbase = vv + bh * Np * 64;
-  const int q0 = co.tile * 128 + wave * 32;
-  const bool active = q0 < Np;
-  const int q = q0 + (lane & 31);
-  const int qc = min(q, Np - 1);
-
-  f16x8 qf[4];
-  bf16x8 dof[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    qf[t] = *reinterpret_cast<const f16x8*>(q16 + (bh * Np + qc) * 64 + 16 * t + 8 * hi);
-    dof[t] = *reinterpret_cast<const bf16x8*>(dout + ((long)b * Np + qc) * (H * 64) + h * 64 + 16 * t + 8 * hi);
-  }
-  const float L2 = lse[bh * Np + qc];
-  const float dlt = delta[bh * Np + qc];
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-
-  const int ntiles = (Np + 63) / 64;
-  Stage2 sk, skb, sv;
-  tile_g2r(sk, kbase, 64, 0, Np, false, tid);
-  tile_g2r(skb, kbbase, 64, 0, Np, false, tid);
-  tile_g2r(sv, vbase, 64, 0, Np, false, tid);
-  // Retire the per-lane fragment loads HERE.  Left alone, hipcc sinks them to just before the loop without a wait; the waits
-  // then land inside the loop body (vmcnt(3..0) in front of the first MFMAs that read dof[]) where, from the second iteration
-  // on, they stall on the NEXT tile's prefetch instead -- one exposed global-load latency per key tile.
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    asm volatile("" ::"v"(qf[t]));
-    asm volatile("" ::"v"(dof[t]));
-  }
-  asm volatile("" ::"v"(L2), "v"(dlt));
-  tile_r2s(sk, smem, tid);
-  tile_r2s(skb, smem + TILE16, tid);
-  tile_r2s(sv, smem + 2 * TILE16, tid);
-  __syncthreads();
-
-  for (int kt = 0; kt < ntiles; kt++) {
-    const char* Kt = smem + (kt & 1) * 3 * TILE16;
-    const char* Kbt = Kt + TILE16;
-    const char* Vt = Kt + 2 * TILE16;
-    const bool more = kt + 1 < ntiles;
-    if (more) {
-      tile_g2r(sk, kbase, 64, (kt + 1) * 64, Np, false, tid);
-      tile_g2r(skb, kbbase, 64, (kt + 1) * 64, Np, false, tid);
-      tile_g2r(sv, vbase, 64, (kt + 1) * 64, Np, false, tid);
-    }
-    if (active) {
-      const int k0 = kt * 64;
-      const int nblk = (Np - k0 > 32) ? 2 : 1;
-      const bool need_mask = (mask != nullptr) || (k0 + 64 > Np);
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++) {
-        if (kb < nblk) {
-          f32x16 s, dp;
-#pragma unroll
-          for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Kt, kb, t, lane), qf[t], s, 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<bf16x8>(Vt, kb, t, lane), dof[t], dp, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            float p = fast_exp2(fmaf(s[r], scale2, -L2));
-            if (need_mask) {
-              const int kg = k0 + kb * 32 + acc_row(r, hi);
-              bool ok = kg < Np;
-              if (ok && mask) ok = mask[(long)b * Np + kg] != 0;
-              if (!ok) p = 0.f;
-            }
-            s[r] = p * (dp[r] - dlt);
-          }
-#pragma unroll
-          for (int t2 = 0; t2 < 2; t2++) {
-            const bf16x8 dsf = pack_frag(s, t2);
-#pragma unroll
-            for (int db = 0; db < 2; db++)
-              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kbt, kb * 32 + 16 * t2, db * 32, lane), dsf, acc[db], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (more) {
-      char* Kn = smem + ((kt + 1) & 1) * 3 * TILE16;
-      tile_r2s(sk, Kn, tid);
-      tile_r2s(skb, Kn + TILE16, tid);
-      tile_r2s(sv, Kn + 2 * TILE16, tid);
-    }
-    __syncthreads();
-  }
-
-  // the tile ring is dead after the loop's last barrier: each wave stages its 32x64 fp32 block in its own 8 KiB
-  if (fq.dqkv) {  // fused rotary + qk-norm backward -> bf16 d(qkv); the red scratch sits behind the four 8 KiB wave blocks
-    store_rows_qknorm(smem + wave * 8192, reinterpret_cast<float*>(smem + 4 * 8192), acc, scale, fq, active, b, h, H, co.tile,
-                      (Np + 127) >> 7, q0, Np, lane, wave);
-    return;
-  }
-  if (active) store_rows_f32(smem + wave * 8192, acc, scale, dq + bh * Np * 64, q0, Np, lane);
-}
-
-// ============================================================================ backward: dk, dv
-// WG owns 128 keys (4 waves x 32), loops over 64-row q tiles.  LDS per buffer: Q16 | Qb | dO tiles + L2[64] + delta[64].
-constexpr int DKV_BUF = 3 * TILE16 + 512;
-
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const u16* __restrict__ q16, const u16* __restrict__ qb16,
-                                                               const u16* __restrict__ k16, const u16* __restrict__ vv,
-                                                               const uint8_t* __restrict__ mask, const u16* __restrict__ dout,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dk, u16* __restrict__ dv, int dv_ld, int H,
-                                                               int Np, float scale2, float scale, int BH, int xmap, QKBwd fk) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const AttnCoord co = attn_coord(H, Np, BH, xmap);
-  if (!co.ok) return;
-  const int h = co.h, b = co.b;
-  const long bh = (long)b * H + h;
-  const u16* qbase = q16 + bh * Np * 64;
-  const u16* qbbase = qb16 + bh * Np * 64;
-  const u16* dobase = dout + (long)b * Np * (H * 64) + h * 64;
-  const int key0 = co.tile * 128 + wave * 32;
-  const bool active = key0 < Np;
-  const int key = key0 + (lane & 31);
-  const int keyc = min(key, Np - 1);
-  bool kvalid = key < Np;
-  if (kvalid && mask) kvalid = mask[(long)b * Np + key] != 0;
-
-  f16x8 kf[4];
-  bf16x8 vf[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    kf[t] = *reinterpret_cast<const f16x8*>(k16 + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
-    vf[t] = *reinterpret_cast<const bf16x8*>(vv + (bh * Np + keyc) * 64 + 16 * t + 8 * hi);
-  }
-  f32x16 adk[2], adv[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { adk[0][i] = 0.f; adk[1][i] = 0.f; adv[0][i] = 0.f; adv[1][i] = 0.f; }
-
-  const int ntiles = (Np + 63) / 64;
-  Stage2 sq, sqb, sdo;
-  float sl = 0.f;  // staged L2 (tid<64) / delta (64<=tid<128)
-  auto stage_stats = [&](int qt) {
-    if (tid < 128) {
-      const int n = qt * 64 + (tid & 63);
-      if (tid < 64) sl = (n < Np) ? lse[bh * Np + n] : 1e30f;
-      else sl = (n < Np) ? delta[bh * Np + n] : 0.f;
-    }
-  };
-  tile_g2r(sq, qbase, 64, 0, Np, false, tid);
-  tile_g2r(sqb, qbbase, 64, 0, Np, false, tid);
-  tile_g2r(sdo, dobase, H * 64, 0, Np, false, tid);  // rows past Np are zeroed when the tile is stored (tile_r2s_zero_oob)
-  stage_stats(0);
-#pragma unroll
-  for (int t = 0; t < 4; t++) {  // retire the per-lane fragment loads before the loop (see attn_bwd_dq_kernel)
-    asm volatile("" ::"v"(kf[t]));
-    asm volatile("" ::"v"(vf[t]));
-  }
-  tile_r2s(sq, smem, tid);
-  tile_r2s(sqb, smem + TILE16, tid);
-  tile_r2s_zero_oob(sdo, smem + 2 * TILE16, 0, Np, tid);
-  if (tid < 128) reinterpret_cast<float*>(smem + 3 * TILE16)[tid] = sl;
-  __syncthreads();
-
-  for (int qt = 0; qt < ntiles; qt++) {
-    const char* Qt = smem + (qt & 1) * DKV_BUF;
-    const char* Qbt = Qt + TILE16;
-    const char* dOt = Qt + 2 * TILE16;
-    const float* stats = reinterpret_cast<const float*>(Qt + 3 * TILE16);
-    const bool more = qt + 1 < ntiles;
-    if (more) {
-      tile_g2r(sq, qbase, 64, (qt + 1) * 64, Np, false, tid);
-      tile_g2r(sqb, qbbase, 64, (qt + 1) * 64, Np, false, tid);
-      tile_g2r(sdo, dobase, H * 64, (qt + 1) * 64, Np, false, tid);
-      stage_stats(qt + 1);
-    }
-    if (active) {
-      const int nblk = (Np - qt * 64 > 32) ? 2 : 1;
-#pragma unroll
-      for (int qb = 0; qb < 2; qb++) {
-        if (qb < nblk) {
-          f32x16 s, dp;
-#pragma unroll
-          for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
-          // S[q][key] = Q . K^T ; dP[q][key] = dO . V^T   (A = tile rows, B = per-lane key fragments)
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(row_frag<f16x8>(Qt, qb, t, lane), kf[t], s, 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<bf16x8>(dOt, qb, t, lane), vf[t], dp, 0, 0, 0);
-#pragma unroll
-          for (int g4 = 0; g4 < 4; g4++) {
-            const int ql = qb * 32 + 8 * g4 + 4 * hi;
-            const float4 l4 = *reinterpret_cast<const float4*>(stats + ql);
-            const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + ql);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int r = 4 * g4 + j;
-              float p = fast_exp2(fmaf(s[r], scale2, -lv[j]));
-              if (!kvalid) p = 0.f;
-              s[r] = p;
-              dp[r] = p * (dp[r] - dv4[j]);
-            }
-          }
-#pragma unroll
-          for (int t2 = 0; t2 < 2; t2++) {
-            const bf16x8 pf = pack_frag(s, t2);
-            const bf16x8 dsf = pack_frag(dp, t2);
-#pragma unroll
-            for (int db = 0; db < 2; db++) {
-              adv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOt, qb * 32 + 16 * t2, db * 32, lane), pf, adv[db], 0, 0, 0);
-              adk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qbt, qb * 32 + 16 * t2, db * 32, lane), dsf, adk[db], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    if (more) {
-      char* Qn = smem + ((qt + 1) & 1) * DKV_BUF;
-      tile_r2s(sq, Qn, tid);
-      tile_r2s(sqb, Qn + TILE16, tid);
-      tile_r2s_zero_oob(sdo, Qn + 2 * TILE16, (qt + 1) * 64, Np, tid);
-      if (tid < 128) reinterpret_cast<float*>(Qn + 3 * TILE16)[tid] = sl;
-    }
-    __syncthreads();
-  }
-
-  if (fk.dqkv)  // fused rotary + qk-norm backward of dk (all waves: it ends with workgroup barriers)
-    store_rows_qknorm(smem + wave * 12288, reinterpret_cast<float*>(smem + 4 * 12288), adk, scale, fk, active, b, h, H, co.tile,
-                      (Np + 127) >> 7, key0, Np, lane, wave);
-  if (active) {
-    char* wst = smem + wave * 12288;  // 8 KiB fp32 dk block | 4 KiB bf16 dv block (ring is dead after the last barrier)
-    if (!fk.dqkv) store_rows_f32(wst, adk, scale, dk + bh * Np * 64, key0, Np, lane);
-    char* vst = wst + 8192;
-    const int kl = lane & 31;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int d = db * 32 + 8 * g4 + 4 * hi;
-        *reinterpret_cast<uint2*>(vst + kl * 128 + (((d >> 3) ^ (kl & 7)) << 4) + (d & 7) * 2) =
-            make_uint2(pack_bf16x2(adv[db][4 * g4 + 0], adv[db][4 * g4 + 1]), pack_bf16x2(adv[db][4 * g4 + 2], adv[db][4 * g4 + 3]));
-      }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      if (key0 + row < Np)
-        *reinterpret_cast<uint4*>(dv + ((long)b * Np + key0 + row) * dv_ld + h * 64 + ch * 8) =
-            *reinterpret_cast<const uint4*>(vst + row * 128 + ((ch ^ (row & 7)) << 4));
-    }
-  }
-}
+// (Round 1's register-staged backward kernels, attn_bwd_dq_kernel / attn_bwd_dkdv_kernel, were removed in round 6: docs/history.md.)
 
 // ---- Round-2 experiment, removed after measurement: "v2" backward kernels with 8 waves = two groups of four that work on
 // alternate 32-row blocks of the streamed operand, one barrier interval apart (phase A: softmax VALU + the LDS fragment reads of
@@ -1694,15 +974,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel_dma(const AttnBwdArgs 
                                  a.Np, a.scale2, a.scale, a.BH, a.xmap, a.fk, a.bits_cm, a.W2, a.rkeep);
 }
 
-#include "attn_bwd1.inc"
 #include "attn_bwd_fold.inc"
 
 }  // namespace
 
 #ifdef VBX_ATTN_TRACE
-extern "C" int vbx_debug_attn_bwd1_trace(void* buf) {  // diagnostic build only: buf = [512][96][9] u64, null to stop
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_b1_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
 extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf = [2][8192][4] u64 (forward | backward launches, by blockIdx), null to stop
   return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
@@ -1731,10 +1007,6 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
     VBX_LAUNCH_CHECK();
     return 0;
   }
-  static const int abl = getenv("VBX_ATTN_ABL") ? atoi(getenv("VBX_ATTN_ABL")) : 0;
-  static const bool legacy = getenv("VBX_ATTN_LEGACY") != nullptr;  // A/B: register-staged double buffer
-  static const int abl2 = getenv("VBX_ATTN_ABL2") ? atoi(getenv("VBX_ATTN_ABL2")) : 0;
-  static const int v3 = getenv("VBX_ATTN_V3") ? atoi(getenv("VBX_ATTN_V3")) : 1;  // 0: A/B against the 3-slot / 3-per-CU v2
 #ifdef VBX_ATTN_DIAG
   if (getenv("VBX_FWD_ABL3") && atoi(getenv("VBX_FWD_ABL3")) != 0) {
     const int a3 = atoi(getenv("VBX_FWD_ABL3"));
@@ -1753,33 +1025,8 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
     return 0;
   }
 #endif
-  if (v3 && !legacy && !abl && !abl2) {
-    hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);
-    VBX_LAUNCH_CHECK();
-    return 0;
-  }
-  if (legacy || abl)
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * TILE16, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
-                       (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, abl, BH, xmap);
-  else
-  {
-#define VBX_FWD2(A)                                                                                                   \
-  hipLaunchKernelGGL(attn_fwd_kernel_v2<A>, grid, dim3(256), ANST * ASTAGE, (hipStream_t)stream, (const u16*)q16,     \
-                     (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap)
-    switch (abl2) {  // timing ablations are separate instantiations: the production kernel carries no switches
-      case 0: VBX_FWD2(0); break;
-      case 1: VBX_FWD2(1); break;
-      case 2: VBX_FWD2(2); break;
-      case 12: VBX_FWD2(12); break;
-      case 14: VBX_FWD2(14); break;
-      case 15: VBX_FWD2(15); break;
-      case 16: VBX_FWD2(16); break;
-      case 64: VBX_FWD2(64); break;
-      default: VBX_FWD2(31); break;
-    }
-#undef VBX_FWD2
-  }
+  hipLaunchKernelGGL(attn_fwd_kernel_v3, grid, dim3(256), A3ST * ASTAGE, (hipStream_t)stream, (const u16*)q16, (const u16*)k16,
+                     (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);
   VBX_LAUNCH_CHECK();
   return 0;
 }
@@ -1794,34 +1041,24 @@ extern "C" int vbx_attn_fwd_dropout(const void* q16, const void* k16, const void
   return attn_fwd_impl(q16, k16, v, mask, out, out_bf16, lse, B, H, Np, scale, bits_rm, p, stream);
 }
 
-// Backward variant: 0 = automatic, 1 = the two-body kernel (round 2), 2 = the one-pass chain kernel (round 3; needs scratch).
-// Automatic = two-body: measured on MI355X at the benchmark grid the one-pass kernel is correct and deterministic but SLOWER
-// (232 - 259 us against 180 - 198 us stand-alone, train step 11.5 against 10.2 ms; step-level time line in DESIGN.md section 8).
-// VBX_ATTN_BWD_ONEPASS=1 presets 2 (A/B); vbx_attn_bwd_select() switches at run time (tests, tools).
-static int g_attn_bwd_variant = (getenv("VBX_ATTN_BWD_ONEPASS") && atoi(getenv("VBX_ATTN_BWD_ONEPASS")) != 0) ? 2 : 0;
+// Backward variant: 0 / 1 = the two-body kernel with the softmax statistics folded into the MFMA accumulator (round 5, default),
+// 3 = the same two bodies without the fold (round 3's arithmetic; also what attention dropout runs on).  Variant 2 was round 3's ONE-PASS
+// chain kernel (every S / dP block evaluated once, dq summed over key blocks by an ordered chain of workgroups through device
+// memory): correct, deterministic and 30 - 60 % slower on MI355X (232 - 262 us against 180 - 198 us; docs/history.md has its step-level
+// time line and the stale-flag finding) -- removed in round 6.  vbx_attn_bwd_select(2) now returns VBX_EUNSUPPORTED,
+// vbx_attn_bwd_scratch_bytes() 0 (no kernel needs scratch; the `scratch` arguments stay in the ABI and are ignored).
+static int g_attn_bwd_variant = 0;
 extern "C" int vbx_attn_bwd_select(int variant) {
-  VBX_REQUIRE(variant >= 0 && variant <= 3, "vbx_attn_bwd_select: 0 auto, 1 two-body, 2 one-pass, 3 two-body without the MFMA fold");
+  if (variant == 2) {
+    vbx_set_error("vbx_attn_bwd_select: the one-pass kernel (2) was removed in round 6; 0 / 1 folded two-body, 3 unfolded two-body");
+    return VBX_EUNSUPPORTED;
+  }
+  VBX_REQUIRE(variant >= 0 && variant <= 3, "vbx_attn_bwd_select: 0 auto, 1 two-body (folded), 3 two-body without the MFMA fold");
   g_attn_bwd_variant = variant;
   return 0;
 }
-extern "C" int vbx_attn_bwd_variant(void) { return g_attn_bwd_variant == 2 ? 2 : 1; }  // the kernel vbx_attn_bwd runs when given scratch
-static inline size_t b1_sync_words(int B, int H, int Np) { return (size_t)B1_SYNC_HDR + (size_t)B * H * cdiv(Np, 64) * 4; }
-static inline size_t b1_acc_floats(int B, int H, int Np) { return (size_t)B * H * cdiv(Np, 64) * 4096; }
-extern "C" size_t vbx_attn_bwd_scratch_bytes(int B, int H, int Np) {
-  if (B <= 0 || H <= 0 || Np <= 0) return 0;
-  return ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255) + b1_acc_floats(B, H, Np) * sizeof(float);
-}
-static int attn_xcds() {  // XCC ids the one-pass kernel folds its queues over: 8 on an SPX MI355X (256 CUs), fewer in partitioned modes
-  static int nx = 0;
-  if (!nx) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    nx = cus / 32;
-    if (nx < 1) nx = 1;
-    if (nx > 8) nx = 8;
-  }
-  return nx;
-}
+extern "C" int vbx_attn_bwd_variant(void) { return 1; }
+extern "C" size_t vbx_attn_bwd_scratch_bytes(int, int, int) { return 0; }
 
 struct AttnDrop {  // training-time attention dropout: keep bits in both orientations (vbx_attn_dropout_bits) and the drop probability
   const unsigned *rm = nullptr, *cm = nullptr;
@@ -1835,20 +1072,8 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
   static bool attr = false;
   const bool dropout = drop.rm != nullptr;
   VBX_REQUIRE(!dropout || (drop.cm && drop.p > 0.f && drop.p < 1.f), "vbx_attn_bwd_dropout: needs both keep-bit arrays and p in (0, 1)");
-  bool onepass = scratch && g_attn_bwd_variant == 2 && !dropout;  // dropout runs on the two-body kernel
-  VBX_REQUIRE(g_attn_bwd_variant != 2 || scratch || dropout, "vbx_attn_bwd: the one-pass kernel needs vbx_attn_bwd_scratch_bytes() of scratch");
-  if (!out) onepass = false;  // the delta pass also resets the one-pass kernel's queue heads: without it the two-body kernel runs
-  if (onepass) {  // its flags carry a per-launch epoch passed by value: a captured launch would replay a stale one
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) onepass = false;
-  }
-  unsigned* sync = onepass ? (unsigned*)scratch : nullptr;
-  int nsync = onepass ? B1_SYNC_HDR : 0;  // queue heads + error word; the flags are epoch-tagged and never reset
-
+  (void)scratch;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_dma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel_fold), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_DMA_LDS);
@@ -1859,64 +1084,26 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     // delta was written by the to_out dgrad's epilogue (vbx_gemm_desc.delta): no pass of its own
   } else if (out_is_f16)
     hipLaunchKernelGGL(attn_delta_kernel<true>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
-                       delta, H, Np, chunks, sync, nsync);
+                       delta, H, Np, chunks);
   else
     hipLaunchKernelGGL(attn_delta_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
-                       delta, H, Np, chunks, sync, nsync);
+                       delta, H, Np, chunks);
   VBX_LAUNCH_CHECK();
-  if (onepass) {
-    AttnBwd1Args g;
-    g.q16 = (const u16*)q16; g.k16 = (const u16*)k16; g.qb16 = (const u16*)qb; g.kb16 = (const u16*)kb; g.vv = (const u16*)v;
-    g.dout = (const u16*)dout; g.mask = mask; g.lse = lse; g.delta = delta; g.dq = dq; g.dk = dk; g.dv = (u16*)dv;
-    g.sync = (unsigned*)scratch;
-    g.dqacc = (float*)((char*)scratch + ((b1_sync_words(B, H, Np) * sizeof(unsigned) + 255) & ~(size_t)255));
-        static unsigned launch_epoch = 0;
-    g.epoch = (++launch_epoch) & 0xFFFFFFu;
-    g.dv_ld = dv_ld; g.H = H; g.Np = Np; g.BH = B * H; g.nx = attn_xcds(); g.scale2 = QK_UNIT; g.scale = scale; g.fq = fq; g.fk = fk;
-    // 512 persistent workgroups = two per CU: each pulls (head, key block) items from the queue of the XCD it runs on
-    hipLaunchKernelGGL(attn_bwd1_kernel, dim3(512), dim3(256), B1_LDS, st, g);
-    VBX_LAUNCH_CHECK();
-    return 0;
-  }
   static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
-  // VBX_ATTN_BWD_DMA: 0 = round-1 kernels (register-staged tiles, two launches); 1 / 2 = only dq / only dk,dv on the LDS-DMA ring
-  // (separate launches); 3 = both on the ring, separate launches; 4 = both in ONE launch.
-  static const int bwd_dma_env = getenv("VBX_ATTN_BWD_DMA") ? atoi(getenv("VBX_ATTN_BWD_DMA")) : 4;
-  const int bwd_dma = dropout ? 4 : bwd_dma_env;
   AttnBwdArgs a;
   a.bits_rm = drop.rm; a.bits_cm = drop.cm; a.W2 = vbx_dropout_bits_words(Np); a.rkeep = dropout ? vbx_dropout_keep_scale(drop.p) : 1.f;
   a.q16 = (const u16*)q16; a.k16 = (const u16*)k16; a.qb16 = (const u16*)qb; a.kb16 = (const u16*)kb; a.vv = (const u16*)v;
   a.dout = (const u16*)dout; a.mask = mask; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = (u16*)dv; a.dv_ld = dv_ld;
   a.H = H; a.Np = Np; a.BH = BH; a.xmap = xmap; a.grid_one = (int)grid.x; a.scale2 = QK_UNIT; a.scale = scale; a.fq = fq; a.fk = fk;
-  if (bwd_dma == 4) {
-    a.role = 0;
-    // VBX_ATTN_BWD_FOLD=0: A/B against round 3's bodies (statistics subtracted by VALU instead of folded into the MFMA accumulator)
-    static const bool fold_env = !(getenv("VBX_ATTN_BWD_FOLD") && atoi(getenv("VBX_ATTN_BWD_FOLD")) == 0);
-    const bool fold = fold_env && g_attn_bwd_variant != 3;  // vbx_attn_bwd_select(3): round 3's bodies (bit-identical to the one-pass kernel)
-    if (dropout) hipLaunchKernelGGL(attn_bwd_kernel_dma<true>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
-    else if (fold) hipLaunchKernelGGL(attn_bwd_kernel_fold, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
-    else hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
-    VBX_LAUNCH_CHECK();
-    return 0;
-  }
-  if (bwd_dma & 1) {
-    a.role = 1;
-    hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, grid, dim3(256), BWD_DMA_LDS, st, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 6 * TILE16, st, (const u16*)q16, (const u16*)k16, (const u16*)kb,
-                       (const u16*)v, mask, (const u16*)dout, lse, delta, dq, H, Np, QK_UNIT, scale, BH, xmap, fq);
-  }
-  VBX_LAUNCH_CHECK();
-  if (bwd_dma & 2) {
-    a.role = 2;
-    hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, grid, dim3(256), BWD_DMA_LDS, st, a);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * DKV_BUF, st, (const u16*)q16, (const u16*)qb,
-                       (const u16*)k16, (const u16*)v, mask, (const u16*)dout, lse, delta, dk, (u16*)dv, dv_ld, H, Np,
-                       QK_UNIT, scale, BH, xmap, fk);
-  }
+  a.role = 0;  // both bodies in ONE launch
+  // VBX_ATTN_BWD_FOLD=0: A/B against round 3's bodies (statistics subtracted by VALU instead of folded into the MFMA accumulator)
+  static const bool fold_env = !(getenv("VBX_ATTN_BWD_FOLD") && atoi(getenv("VBX_ATTN_BWD_FOLD")) == 0);
+  const bool fold = fold_env && g_attn_bwd_variant != 3;
+  if (dropout) hipLaunchKernelGGL(attn_bwd_kernel_dma<true>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+  else if (fold) hipLaunchKernelGGL(attn_bwd_kernel_fold, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel_dma<false>, dim3(2 * grid.x), dim3(256), BWD_DMA_LDS, st, a);
   VBX_LAUNCH_CHECK();
   return 0;
 }

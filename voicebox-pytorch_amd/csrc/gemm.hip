@@ -35,75 +35,9 @@ extern "C" int vbx_debug_gemm2_trace(void* buf) {  // buf = [workgroups][5] u64,
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int KS_STRIDE = 272;               // bytes per k-row of a K-strided tile (128 bf16 + 16 B pad)
-constexpr int TILE_BYTES = BK * KS_STRIDE;   // 17408 (a K-contiguous tile needs 16384)
 constexpr int CS_LD = 132;                   // floats per row of the staged C tile
-constexpr int GEMM_LDS = 4 * TILE_BYTES;     // 69632 >= 128*132*4
-static_assert(GEMM_LDS >= BM * CS_LD * 4, "C staging must fit");
 
-struct Staged {
-  uint4 v[4];
-};
-
-// global -> registers.  MODE 0: tile [128 outer][64 k] (k contiguous).  MODE 1: tile [64 k][128 outer].
-template <int MODE>
-VBX_DEV void g2r(Staged& st, const u16* __restrict__ X, long ld, int o0, int olim, int k0, int kend, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int c = tid + 256 * i;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (MODE == 0) {
-      const int row = c >> 3, ch = c & 7;
-      const int go = o0 + row, gk = k0 + ch * 8;
-      if (go < olim && gk < kend) v = *reinterpret_cast<const uint4*>(X + (long)go * ld + gk);
-    } else {
-      const int kr = c >> 4, ch = c & 15;
-      const int gk = k0 + kr, go = o0 + ch * 8;
-      if (gk < kend && go < olim) v = *reinterpret_cast<const uint4*>(X + (long)gk * ld + go);
-    }
-    st.v[i] = v;
-  }
-}
-
-template <int MODE>
-VBX_DEV void r2s(const Staged& st, char* tile, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int c = tid + 256 * i;
-    int off;
-    if (MODE == 0) {
-      const int row = c >> 3, ch = c & 7;
-      off = row * 128 + ((ch ^ (row & 7)) << 4);
-    } else {
-      const int kr = c >> 4, ch = c & 15;
-      off = kr * KS_STRIDE + ch * 16;
-    }
-    *reinterpret_cast<uint4*>(tile + off) = st.v[i];
-  }
-}
-
-// MFMA 16x16x32 operand fragment for the 16 outer indices [woff + s*16, +16) and k-step kk (32 k).
-// lane l holds outer index (l&15) and k = (l>>4)*8 .. +8.
-template <int MODE>
-VBX_DEV bf16x8 frag(const char* tile, int woff, int s, int kk, int lane) {
-  if (MODE == 0) {
-    const int r = woff + s * 16 + (lane & 15);
-    const int ch = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((ch ^ (r & 7)) << 4));
-  } else {
-    // ds_read_b64_tr_b16: within each 16-lane group, lane a receives element (a&3) of the 8 bytes
-    // addressed by lanes 4j + (a>>2), j = 0..3.  With supplier lane s pointing at
-    // [k = k0 + (s>>2)][col = c0 + 4*(s&3)] lane a therefore receives [k0 + j][c0 + a].
-    const int g = lane >> 4, a = lane & 15;
-    const int kr = kk * 32 + g * 8 + (a >> 2);
-    const int col = woff + s * 16 + 4 * (a & 3);
-    const char* p = tile + kr * KS_STRIDE + col * 2;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 4 * KS_STRIDE));
-    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, r);
-  }
-}
+// (Round 1's register-staged 128 x 128 x 64 kernel, `gemm_kernel` / VBX_GEMM_LEGACY, was removed in round 6: docs/history.md.)
 
 struct GemmParams {
   const u16* A;
@@ -125,88 +59,6 @@ VBX_DEV f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-
-template <int MA, int MB, class Epi, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Give every
-  // XCD one CONTIGUOUS chunk of the tile sequence (n fastest), so the ~64 tiles an XCD runs concurrently share a few
-  // A row-panels and the B panels they stream stay in that XCD's L2.  Bijective for any tile count.
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int split = blockIdx.y;
-  const int kbeg = split * p.kchunk;
-  const int kend = min(p.K, kbeg + p.kchunk);
-  const int nt = (kend - kbeg + BK - 1) / BK;
-
-  // LDS map: [A buf0][B buf0][A buf1][B buf1]
-#define TILE_A(buf) (smem + (buf) * 2 * TILE_BYTES)
-#define TILE_B(buf) (smem + (buf) * 2 * TILE_BYTES + TILE_BYTES)
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  Staged sa, sb;
-  if (nt > 0) {
-    g2r<MA>(sa, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-    g2r<MB>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-    r2s<MA>(sa, TILE_A(0), tid);
-    r2s<MB>(sb, TILE_B(0), tid);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nt; t++) {
-    const int cur = t & 1;
-    const bool more = (t + 1) < nt;
-    if (more) {  // issue next tile's global loads before the MFMA phase (latency hides under it)
-      g2r<MA>(sa, p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid);
-      g2r<MB>(sb, p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int s = 0; s < 4; s++) af[s] = frag<MA>(TILE_A(cur), wm * 64, s, kk, lane);
-#pragma unroll
-      for (int s = 0; s < 4; s++) bfr[s] = frag<MB>(TILE_B(cur), wn * 64, s, kk, lane);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-    }
-    if (more) {
-      r2s<MA>(sa, TILE_A(cur ^ 1), tid);
-      r2s<MB>(sb, TILE_B(cur ^ 1), tid);
-    }
-    __syncthreads();
-  }
-
-  // ---- stage the fp32 C tile through LDS (C layout: col = lane&15, row = (lane>>4)*4 + reg) ----
-  float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        const int col = wn * 64 + j * 16 + (lane & 15);
-        Cs[row * CS_LD + col] = acc[i][j][r];
-      }
-  __syncthreads();
-  epi(Cs, m0, n0, tid, split, p.M, p.N, 128);
-}
-
 
 // =====================================================================================================
 // v2 main loop: LDS-DMA (global_load_lds, 16 B/lane) into a 4-stage ring of 128x128x32 k-tiles.
@@ -325,253 +177,10 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
 #undef VBX_SPLIT_
 }
 
-// ---- 160 x 128 tile, 2x2 waves of 80 x 64, ONE workgroup per CU with a 5-slot ring.  For the N = dim GEMMs (to_out,
-// FeedForward-out, the dgrads into the residual width) at M = 8 x 1040 = 8320 rows: 128-row tiles give 65 x 4 = 260 workgroups,
-// i.e. 4 CUs get TWO tiles and the kernel lasts as long as those (FeedForward-out: 37 us for 11.6 GFLOP); 8320 = 52 x 160 gives
-// 208 equal tiles, one per CU, in one round.  A single resident workgroup needs the deeper ring to keep the same number of
-// operand bytes in flight (4 stages x 18 KiB vs 3 workgroups x 2 x 16 KiB).  MA == 0 (A is K-contiguous); B either way.
-constexpr int V4_A_BYTES = 12288;                      // [192][32] 16-bit window, rows 160..191 never read
-constexpr int V4_STAGE = V4_A_BYTES + OP_BYTES;        // 20 KiB
-constexpr int V8_A_BYTES = 16384;                      // 8-wave form: [256][32] window (2 DMA instructions x 512 threads)
-constexpr int V8_STAGE = V8_A_BYTES + OP_BYTES;        // 24 KiB
-constexpr int GEMM_V8_LDS = 5 * V8_STAGE;              // 120 KiB
-constexpr int GEMM_V4_LDS = 5 * V4_STAGE;              // 100 KiB (5-slot ring); the 3-slot form uses 60 KiB
-// NST_ = 5: one workgroup per CU (100 KiB).  NST_ = 3: 60 KiB -> two workgroups per CU, for the wide GEMMs whose 128-row tile
-// count leaves a long tail (to_qkv: 1560 tiles = 6.09 per CU -> 7 rounds; 1248 tiles of 160 rows = 4.9 -> 5 rounds of 1.125).
-template <int MB, class Epi, bool F16, int NST_>
-__global__ __launch_bounds__(256, NST_ == 5 ? 1 : 2) void gemm_kernel_bm160(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * 160, n0 = tn * BN;
-  const int kend = p.K;
-  const int nt = (kend + BK2 - 1) / BK2;
-
-  DmaPlan<0, 192> da;  // 3 DMA instructions per thread; window rows >= 160 are pointed at the zero page
-  DmaPlan<MB, 128> db;
-  da.init(p.A, p.lda, m0, min(p.M, m0 + 160), tid);
-  db.init(p.B, p.ldb, n0, p.N, tid);
-  // DS immediates are 16-bit: slots 0-2 are addressed from the ring base, slots 3-4 from a second base 60 KiB further
-  FragPlan<0> fa, fa2;
-  FragPlan<MB> fb, fb2;
-  fa.init(smem, wm * 80, lane);
-  fb.init(smem, wn * 64, lane);
-  if (NST_ > 3) {
-    fa2.init(smem + 3 * V4_STAGE, wm * 80, lane);
-    fb2.init(smem + 3 * V4_STAGE, wn * 64, lane);
-  }
-
-  f32x4 acc[5][4];
-#pragma unroll
-  for (int i = 0; i < 5; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NST_ - 1; s++) {
-    if (s < nt) {
-      da.issue(smem + s * V4_STAGE, s * BK2, kend, tid);
-      db.issue(smem + s * V4_STAGE + V4_A_BYTES, s * BK2, kend, tid);
-    }
-  }
-  // (A software-pipelined variant -- fragments of k-tile t+1 requested before the MFMAs of t, two register sets -- was measured
-  //  SLOWER in situ: it has to wait for k-tile t+1 one iteration earlier, which costs more than the exposed LDS round trip.)
-  auto step = [&](auto stg_c, int t) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + NST_ - 1) % NST_;
-    // 5 DMA instructions per thread per stage; tile t has landed once at most min(NST-2, tiles left) younger stages are pending
-    const int younger = min(NST_ - 2, nt - 1 - t);
-    if (NST_ == 5 && younger >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    else if (NST_ == 5 && younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NST_ - 1 < nt) {
-      da.issue(smem + NXT * V4_STAGE, (t + NST_ - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * V4_STAGE + V4_A_BYTES, (t + NST_ - 1) * BK2, kend, tid);
-    }
-    bf16x8 af[5], bfr[4];
-    s16x4 dl, dh, blo[4], bhi[4];
-    constexpr int SO = (STG % 3) * V4_STAGE;  // offset from the base that covers this slot
-    const FragPlan<0>& pa = STG < 3 ? fa : fa2;
-    const FragPlan<MB>& pb = STG < 3 ? fb : fb2;
-    pa.template read<SO, 0>(af[0], dl, dh);
-    pa.template read<SO, 1>(af[1], dl, dh);
-    pa.template read<SO, 2>(af[2], dl, dh);
-    pa.template read<SO, 3>(af[3], dl, dh);
-    pa.template read<SO, 4>(af[4], dl, dh);
-    pb.template read<SO + V4_A_BYTES, 0>(bfr[0], blo[0], bhi[0]);
-    pb.template read<SO + V4_A_BYTES, 1>(bfr[1], blo[1], bhi[1]);
-    pb.template read<SO + V4_A_BYTES, 2>(bfr[2], blo[2], bhi[2]);
-    pb.template read<SO + V4_A_BYTES, 3>(bfr[3], blo[3], bhi[3]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (MB == 1) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
-        bfr[s] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-  };
-  for (int t = 0; t < nt; t += NST_) {
-    step(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-    if (NST_ == 5) {
-      if (t + 3 < nt) step(std::integral_constant<int, 3 % NST_>{}, t + 3);
-      if (t + 4 < nt) step(std::integral_constant<int, 4 % NST_>{}, t + 4);
-    }
-  }
-  // ---- epilogue in five 32-row chunks (wave rows 0-79 / 80-159: chunk 2 takes 16 rows from each)
-  float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int c = 0; c < 5; c++) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int trow = wm * 80 + i * 16;  // tile row of this fragment
-      if ((trow >> 5) == c) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++)
-            Cs[(trow - 32 * c + (lane >> 4) * 4 + rr) * CS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][rr];
-      }
-    }
-    __syncthreads();
-    epi(Cs, m0 + c * 32, n0, tid, 0, p.M, p.N, 32);
-  }
-}
-
-// ---- 160 x 128 tile with EIGHT waves of 80 x 32 (512 threads), one workgroup per CU, 5-slot ring: two waves per SIMD, so one
-// wave's MFMAs run while the other waits for its LDS fragments (with four waves that round trip is exposed on every k-step).
-// Tried (round 2, session 3): fragment prefetch -- the reads of k-step t+1 issued before the MFMAs of k-step t (two register
-// sets; ring = stage t+1 being read, t+2 / t+3 in flight, t+4 issued into the slot of stage t).  Correct, and worth nothing:
-// dgrad to_qkv 44.9 -> 43.9 us back to back, train step 9.96 -> 9.97 ms in the same run.  The k-step (~1000 cycles for 18 KiB of
-// operands and 320 MFMA cycles per SIMD) is not waiting for the LDS round trip; like every LDS-DMA loop here it runs at ~18 bytes
-// per clock per CU of fill, a third of what the same instruction streams from an L2-resident buffer without barriers
-// (tools/probes/l2_fill_rate.hip: 48-57 B/clk).
-template <int MB, class Epi, bool F16>
-__global__ __launch_bounds__(512, 1) void gemm_kernel_bm160x8(GemmParams p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int T = gridDim.x, xcd = blockIdx.x & 7, qi = blockIdx.x >> 3;
-  const int q = T >> 3, r = T & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + qi;
-  const int tiles_n = T / p.tiles_m;
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * 160, n0 = tn * BN;
-  const int kend = p.K;
-  const int nt = (kend + BK2 - 1) / BK2;
-  constexpr int NST_ = 5;
-
-  DmaPlan<0, 256, 512> da;  // 2 DMA instructions per thread over a 256-row window; rows >= 160 point at the zero page
-  DmaPlan<MB, 128, 512> db;
-  da.init(p.A, p.lda, m0, min(p.M, m0 + 160), tid);
-  db.init(p.B, p.ldb, n0, p.N, tid);
-  // DS immediates are 16-bit: one base per pair of 24-KiB slots
-  FragPlan<0> fa, fa2, fa3;
-  FragPlan<MB> fb, fb2, fb3;
-  fa.init(smem, wm * 80, lane);
-  fb.init(smem, wn * 32, lane);
-  fa2.init(smem + 2 * V8_STAGE, wm * 80, lane);
-  fb2.init(smem + 2 * V8_STAGE, wn * 32, lane);
-  fa3.init(smem + 4 * V8_STAGE, wm * 80, lane);
-  fb3.init(smem + 4 * V8_STAGE, wn * 32, lane);
-
-  f32x4 acc[5][2];
-#pragma unroll
-  for (int i = 0; i < 5; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NST_ - 1; s++) {
-    if (s < nt) {
-      da.issue(smem + s * V8_STAGE, s * BK2, kend, tid);
-      db.issue(smem + s * V8_STAGE + V8_A_BYTES, s * BK2, kend, tid);
-    }
-  }
-  auto step = [&](auto stg_c, int t) {
-    constexpr int STG = decltype(stg_c)::value;
-    constexpr int NXT = (STG + NST_ - 1) % NST_;
-    const int younger = min(NST_ - 2, nt - 1 - t);  // 3 DMA instructions per thread per stage
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NST_ - 1 < nt) {
-      da.issue(smem + NXT * V8_STAGE, (t + NST_ - 1) * BK2, kend, tid);
-      db.issue(smem + NXT * V8_STAGE + V8_A_BYTES, (t + NST_ - 1) * BK2, kend, tid);
-    }
-    bf16x8 af[5], bfr[2];
-    s16x4 dl, dh, blo[2], bhi[2];
-    constexpr int SO = (STG % 2) * V8_STAGE;
-    const FragPlan<0>& pa = STG < 2 ? fa : (STG < 4 ? fa2 : fa3);
-    const FragPlan<MB>& pb = STG < 2 ? fb : (STG < 4 ? fb2 : fb3);
-    pa.template read<SO, 0>(af[0], dl, dh);
-    pa.template read<SO, 1>(af[1], dl, dh);
-    pa.template read<SO, 2>(af[2], dl, dh);
-    pa.template read<SO, 3>(af[3], dl, dh);
-    pa.template read<SO, 4>(af[4], dl, dh);
-    pb.template read<SO + V8_A_BYTES, 0>(bfr[0], blo[0], bhi[0]);
-    pb.template read<SO + V8_A_BYTES, 1>(bfr[1], blo[1], bhi[1]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (MB == 1) {
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        s16x8 v = {blo[s][0], blo[s][1], blo[s][2], blo[s][3], bhi[s][0], bhi[s][1], bhi[s][2], bhi[s][3]};
-        bfr[s] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
-  };
-  for (int t = 0; t < nt; t += 5) {
-    step(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) step(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < nt) step(std::integral_constant<int, 2>{}, t + 2);
-    if (t + 3 < nt) step(std::integral_constant<int, 3>{}, t + 3);
-    if (t + 4 < nt) step(std::integral_constant<int, 4>{}, t + 4);
-  }
-  // ---- epilogue: 64-row chunks [0,64) [64,128) [128,160); threads 0-255 run the functor on the first 32 rows of a chunk,
-  // threads 256-511 on the second 32
-  float* Cs = reinterpret_cast<float*>(smem);
-  const int half = tid >> 8, tq = tid & 255;
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int trow = wm * 80 + i * 16;
-      if ((trow >> 6) == c) {
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++)
-            Cs[(trow - 64 * c + (lane >> 4) * 4 + rr) * CS_LD + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][rr];
-      }
-    }
-    __syncthreads();
-    if (c < 2 || half == 0) epi(Cs + half * 32 * CS_LD, m0 + c * 64 + half * 32, n0, tq, 0, p.M, p.N, 32);
-  }
-}
-
+// ---- The one-round 160-row tile.  For the N = dim GEMMs (to_out, FeedForward-out, the dgrads into the residual width) at M = 8 x 1040 =
+// 8320 rows: 128-row tiles give 65 x 4 = 260 workgroups, i.e. 4 CUs get TWO tiles and the kernel lasts as long as those; 8320 =
+// 52 x 160 gives 208 equal tiles, one per CU, in one round.  (Rounds 1-2 ran it 32 deep, with 4 waves / a 5-slot ring and then 8
+// waves; the 64-deep form below replaced both and they were removed in round 6 -- numbers in docs/history.md.)
 // ---- 160 x 128 x 64: the one-round tile with 128-BYTE operand rows.  An LDS-DMA instruction costs the texture path one slot
 // per cache line it touches: 8 rows x 128 B stream at 52 B/clk per CU from L2, the 16 rows x 64 B pieces of a 32-deep k-tile at
 // 27 B/clk (tools/probes/l2_fill_rate.hip swz) -- and every k-loop of this file ran at ~18.  So the K-contiguous operands are staged
@@ -1062,11 +671,8 @@ struct EpiQKV {
 template <int MA, int MB, bool F16 = false, class Epi>
 int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
   static bool attr_set = false;  // >48 KiB dynamic LDS needs the opt-in once per kernel
-  static const bool legacy = getenv("VBX_GEMM_LEGACY") != nullptr;  // A/B switch: 1-deep register-staged main loop
-  auto kern = gemm_kernel<MA, MB, Epi, F16>;
   auto kern128 = gemm_kernel_v2<MA, MB, Epi, F16, 128>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern128), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
     attr_set = true;
   }
@@ -1091,54 +697,23 @@ int launch(GemmParams p, const Epi& epi, int splits, hipStream_t st) {
     static const bool multi160 = !(getenv("VBX_BM160_MULTI") && atoi(getenv("VBX_BM160_MULTI")) == 0);
     constexpr int multi_k = 1024;  // at K = 512 the same tile loses to the 128 x 256 tile (dgrad FeedForward-out 27.8 vs 20.6 us)
     const bool light = std::is_same<Epi, EpiBF16>::value || std::is_same<Epi, EpiF32>::value;
-    const bool use160 = (b160 ? atoi(b160) != 0 : true) && !legacy && splits == 1 &&
+    const bool use160 = (b160 ? atoi(b160) != 0 : true) && splits == 1 &&
                         ((t128 > 256 && (t160 <= 256 || all160)) || (t160 <= 256 && t160 >= min160) ||
                          (multi160 && light && p.K >= multi_k && t160 > 256));
-    // the 8-wave form is the default (same run: sample 366.9 -> 359.3 ms, train step 13.37 -> 13.20 ms); VBX_GEMM_BM160X8=0: A/B
-    static const char* b160x8 = getenv("VBX_GEMM_BM160X8");
-    if (use160 && (b160x8 ? atoi(b160x8) != 0 : true)) {
-      static bool attr8 = false;
-      // 64-deep stages (128-byte operand rows) are the default: in the train step to_out 27.2 -> 23.8 us, FeedForward-out 33.6 ->
-      // 28.0, dgrad to_qkv 50.4 -> 43.9, dgrad FeedForward-in 52.0 -> 41.8, step 10.24 -> 9.99 ms (same run).  VBX_BM160_K64=0: A/B.
-      static const bool k64 = !(getenv("VBX_BM160_K64") && atoi(getenv("VBX_BM160_K64")) == 0);
-      if (k64) {
-        static bool attr9 = false;
-        auto k9 = gemm_kernel_bm160k64<MB, Epi, F16>;
-        if (!attr9) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V9_LDS);
-          attr9 = true;
-        }
-        p.tiles_m = cdiv(p.M, 160);
-        hipLaunchKernelGGL(k9, dim3(p.tiles_m * tiles_n), dim3(512), GEMM_V9_LDS, st, p, epi);
-        VBX_LAUNCH_CHECK();
-        return 0;
-      }
-      auto k8 = gemm_kernel_bm160x8<MB, Epi, F16>;
-      if (!attr8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V8_LDS);
-        attr8 = true;
-      }
-      p.tiles_m = cdiv(p.M, 160);
-      hipLaunchKernelGGL(k8, dim3(p.tiles_m * tiles_n), dim3(512), GEMM_V8_LDS, st, p, epi);
-      VBX_LAUNCH_CHECK();
-      return 0;
-    }
     if (use160) {
-      static bool attr160 = false;
-      auto k160 = gemm_kernel_bm160<MB, Epi, F16, 5>;
-      if (!attr160) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k160), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V4_LDS);
-        attr160 = true;
+      static bool attr9 = false;
+      auto k9 = gemm_kernel_bm160k64<MB, Epi, F16>;
+      if (!attr9) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V9_LDS);
+        attr9 = true;
       }
       p.tiles_m = cdiv(p.M, 160);
-      hipLaunchKernelGGL(k160, dim3(p.tiles_m * tiles_n), dim3(256), GEMM_V4_LDS, st, p, epi);
+      hipLaunchKernelGGL(k9, dim3(p.tiles_m * tiles_n), dim3(512), GEMM_V9_LDS, st, p, epi);
       VBX_LAUNCH_CHECK();
       return 0;
     }
   }
-  if (legacy) {
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * tiles_n, splits), dim3(256), GEMM_LDS, st, p, epi);
-  } else {
+  {
     bool small = false;
     if constexpr (MA == 0) {
       // N = dim GEMMs (out-proj, ff-out, dgrads into the residual width): fewer than ~1.5 workgroups per CU with

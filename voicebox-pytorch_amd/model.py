@@ -78,11 +78,8 @@ class _AttendFn(torch.autograd.Function):
             _lib.call("vbx_attn_bwd_dropout", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
                       H * 64, B, H, Np, ctx.scale, rm, cm, ctx.drop_p, _lib.current_stream())
         else:
-            scratch = None  # the default two-body kernel needs none; the one-pass chain kernel: flags + running dq sums (~36 MB)
-            if _lib.lib().vbx_attn_bwd_variant() == 2:
-                scratch = torch.empty(_lib.lib().vbx_attn_bwd_scratch_bytes(B, H, Np), dtype=torch.uint8, device=dev)
             _lib.call("vbx_attn_bwd", q16, k16, qb, kb, vb, m8 if ctx.has_mask else None, out, 1, do, lse, delta, dq, dk, dv,
-                      H * 64, B, H, Np, ctx.scale, scratch, _lib.current_stream())
+                      H * 64, B, H, Np, ctx.scale, None, _lib.current_stream())  # (`scratch`: unused since round 6)
         dvh = dv.view(B, Np, H, 64).permute(0, 2, 1, 3)
         return dq.to(ctx.in_dtype), dk.to(ctx.in_dtype), dvh.to(ctx.in_dtype), None, None, None, None
 
