@@ -9,6 +9,6 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
 for n in 0 1 2 3; do /opt/rocm/bin/hipcc $F -DVBX_ATTN_ABL_DKDV=$n -c $C/attn.hip -o $L/attn_abl$n.o & done
 wait
 for n in 0 1 2 3; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_abl$n.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/attn_abl$n.o $L/norm.o $L/gateloop.o $L/ops.o $L/runtime.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_abl$n.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/gemm5.o $L/attn_abl$n.o $L/norm.o $L/gateloop.o $L/ops.o $L/runtime.o
 done
 echo built

@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   for n in $NS; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DVBX_BWD_ABL=$n -c $C/attn.hip -o $L/attn_babl$n.o & done
   wait
   for n in $NS; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_babl$n.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/attn_babl$n.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_babl$n.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/gemm5.o $L/attn_babl$n.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o
   done
   echo built
 else

@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.."
 L=voicebox-pytorch_amd/lib; C=voicebox-pytorch_amd/csrc
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DVBX_ATTN_DIAG -c $C/attn.hip -o $L/attn_diag.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_diag.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/attn_diag.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_diag.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/gemm5.o $L/attn_diag.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o
   echo built $L/libvbx_hip_diag.so
 else
   for rep in 1 2; do for n in 0 1 6 8 14 49 64 384 63 447; do

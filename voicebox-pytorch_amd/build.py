@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libvbx_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "gemm4.hip", "attn.hip", "norm.hip", "gateloop.hip", "ops.hip", "precise.hip", "runtime.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "gemm4.hip", "gemm5.hip", "attn.hip", "norm.hip", "gateloop.hip", "ops.hip", "precise.hip", "runtime.hip"]
 
 
 def _hipcc():

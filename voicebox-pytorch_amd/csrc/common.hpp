@@ -159,6 +159,8 @@ int vbx_gemm3(const vbx_gemm_desc* d, hipStream_t st);
 int vbx_gemm3_tn_splitk_grouped(const vbx_gemm_desc* descs, int n, hipStream_t st);
 // gemm4.hip: the 128 x 256 tile, two workgroups per CU (NT / NN descriptors)
 int vbx_gemm4(const vbx_gemm_desc* d, hipStream_t st);
+// gemm5.hip: the weight-stationary kernel (NT, K = 512, QKV / GEGLU epilogues)
+int vbx_gemm5(const vbx_gemm_desc* d, hipStream_t st);
 // 0: automatic choice per shape (default), 1: gemm.hip kernels only, 2: gemm3 wherever it can serve, 3: gemm4 wherever it can
 // serve (VBX_GEMM_PATH=<n> presets it; VBX_GEMM3=0 is the same as 1)
 int vbx_gemm_path();

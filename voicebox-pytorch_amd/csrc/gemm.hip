@@ -780,12 +780,12 @@ int vbx_gemm_path() {
     const char* e = getenv("VBX_GEMM_PATH");
     const char* e3 = getenv("VBX_GEMM3");
     g_gemm_path = e ? atoi(e) : ((e3 && atoi(e3) == 0) ? 1 : 0);
-    if (g_gemm_path < 0 || g_gemm_path > 3) g_gemm_path = 0;
+    if (g_gemm_path < 0 || g_gemm_path > 4) g_gemm_path = 0;
   }
   return g_gemm_path;
 }
 extern "C" int vbx_gemm_select(int path) {
-  VBX_REQUIRE(path >= 0 && path <= 3, "vbx_gemm_select: 0 automatic, 1 128-wide kernels only, 2 256x256 tile wherever it serves, 3 128x256 tile wherever it serves");
+  VBX_REQUIRE(path >= 0 && path <= 4, "vbx_gemm_select: 0 automatic, 1 128-wide kernels only, 2 256x256 tile wherever it serves, 3 128x256 tile wherever it serves, 4 = 0 with the weight-stationary kernel forced on");
   g_gemm_path = path;
   return 0;
 }
@@ -797,7 +797,17 @@ extern "C" int vbx_gemm_select(int path) {
 //    two phases better than one 256 x 256 or two lock-stepped 128 x 256 workgroups (a start-phase stagger of the co-resident
 //    workgroups, VBX_GEMM_STAGGER, did not help either); the N = dim GEMMs have too few wide tiles.
 //    Paths 2 / 3 force them for measurements (tools/native/gemm3_check).
+static int gemm_tile_fallback(const vbx_gemm_desc* d);
 static int gemm_tile_for(const vbx_gemm_desc* d) {
+  const int path = vbx_gemm_path();
+  if (path == 2) return 3;
+  if (path == 1) return 1;
+  // K = 512 linear layers with a row-wise epilogue (to_qkv, FeedForward-in): the weight-stationary kernel (gemm5.hip).  VBX_GEMM5=0: A/B.
+  static const bool g5 = getenv("VBX_GEMM5") && atoi(getenv("VBX_GEMM5")) != 0;  // (opt-in until it wins in situ)
+  if ((g5 || path == 4) && path != 3 && d->mode == VBX_GEMM_NT && d->K == 512 && (d->epilogue == VBX_EPI_QKV || d->epilogue == VBX_EPI_GEGLU)) return 5;
+  return gemm_tile_fallback(d);
+}
+static int gemm_tile_fallback(const vbx_gemm_desc* d) {  // the LDS-tiled kernels' choice (everything gemm5 does not serve)
   const int path = vbx_gemm_path();
   if (path == 2) return 3;
   if (path == 1) return 1;
@@ -832,7 +842,12 @@ extern "C" int vbx_gemm(const vbx_gemm_desc* d, void* stream) {
   VBX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "vbx_gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
   VBX_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "vbx_gemm: leading dims must be multiples of 8 (16-byte rows)");
   VBX_REQUIRE(d->N % 8 == 0, "vbx_gemm: N must be a multiple of 8");
-  const int tile = gemm_tile_for(d);
+  int tile = gemm_tile_for(d);
+  if (tile == 5) {
+    const int rc = vbx_gemm5(d, st);
+    if (rc != VBX_EUNSUPPORTED) return rc;
+    tile = gemm_tile_fallback(d);
+  }
   if (d->delta) {  // only the 128 x 256 tile's row-staged epilogue produces the attention delta (gemm_epi3.hpp): serve it there or say no
     if (tile != 4) return VBX_EUNSUPPORTED;
     return vbx_gemm4(d, st);
