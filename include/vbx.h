@@ -97,6 +97,14 @@ int vbx_gemm(const vbx_gemm_desc* d, void* stream);
  * 8-wave kernel (gemm3.hip) wherever it can serve, 3 the 128 x 256 two-workgroups-per-CU kernel (gemm4.hip) wherever it can.
  * Not thread safe; call before launching work. */
 int vbx_gemm_select(int path);
+/* Round 6: to_qkv and FeedForward-in at K = 512 (NT, VBX_EPI_QKV / VBX_EPI_GEGLU, every backward copy or none) run on the
+ * WEIGHT-STATIONARY kernel (csrc/gemm5.hip): one 4-wave workgroup per CU keeps a 256-feature weight panel in its registers and walks
+ * 32-row activation blocks; the epilogue of a block runs inside the next block's MFMA stream.  It owns a whole CU (512 registers
+ * per lane, 128 KiB LDS), so two such launches on two streams cannot share CUs: a caller that runs two of them concurrently
+ * (the sampler's two half-batch streams) gives each a share with vbx_gemm5_cu_limit(n) -- the launches then use at most n CUs
+ * (0 = all; process-global, read at launch, i.e. baked into a captured graph).  VBX_GEMM5=0 / vbx_gemm_select(1): the tiled kernels.
+ * vbx_gemm_select(4): as 0 with this kernel forced on even when VBX_GEMM5=0. */
+int vbx_gemm5_cu_limit(int n);
 /* n (1..4) TN / VBX_EPI_SPLITK GEMMs in ONE launch of the 256 x 256 tile (same slab layout and results as n vbx_gemm calls):
  * the four weight-gradient GEMMs of a layer are 8-24 such tiles each; together, with 3 K-splits, they fill 198 CUs (92 us in
  * situ against 4 x 38 us as separate 128-wide launches).  With vbx_gemm_select(1) it falls back to n separate launches. */

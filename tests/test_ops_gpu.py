@@ -183,7 +183,11 @@ def rot_tables(Np, R):
     return fr, fr[:, :32].cos().contiguous(), fr[:, :32].sin().contiguous()
 
 
-@pytest.mark.parametrize("Bsz,Np,H,D,qknorm", [(2, 56, 2, 64, True), (2, 1040, 4, 256, True), (1, 40, 2, 128, False)])
+@pytest.mark.parametrize("Bsz,Np,H,D,qknorm", [(2, 56, 2, 64, True), (2, 1040, 4, 256, True), (1, 40, 2, 128, False),
+                                               # K = 512: the weight-stationary kernel (csrc/gemm5.hip) under "auto" -- ragged last block,
+                                               # batches changing inside a block, a panel with two idle waves (H = 2), Np < 32, no qk-norm
+                                               (3, 100, 4, 512, True), (2, 77, 2, 512, True), (1, 24, 6, 512, True), (2, 33, 2, 512, False),
+                                               (4, 1040, 16, 512, True)])
 def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     """to_qkv + MultiheadRMSNorm + rotary fused (voicebox_pytorch.py:320-328)."""
     g = torch.Generator().manual_seed(Np)
@@ -194,21 +198,21 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     qg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
     kg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
     fr, rc, rs = rot_tables(Np, 16)
-    q16 = torch.empty(Bsz, H, Np, 64, dtype=torch.float16, device=dev)
-    k16 = torch.empty_like(q16)
-    qb = torch.empty(Bsz, H, Np, 64, dtype=torch.bfloat16, device=dev)
-    kb = torch.empty_like(qb)
-    v = torch.empty_like(qb)
-    v16 = torch.empty_like(q16)
-    qrn = torch.empty(Bsz, H, Np, device=dev)
-    krn = torch.empty_like(qrn)
+    q16 = torch.full((Bsz, H, Np, 64), float("nan"), dtype=torch.float16, device=dev)
+    k16 = torch.full_like(q16, float("nan"))
+    qb = torch.full((Bsz, H, Np, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    kb = torch.full_like(qb, float("nan"))
+    v = torch.full_like(qb, float("nan"))
+    v16 = torch.full_like(q16, float("nan"))
+    qrn = torch.full((Bsz, H, Np), float("nan"), device=dev)
+    krn = torch.full_like(qrn, float("nan"))
     gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_QKV, x, W, M, 3 * I, D, Np=Np, H=H, qk_scale=8.0 if qknorm else 0.0,
          q_gamma=qg, k_gamma=kg, rot_cos=rc.to(dev), rot_sin=rs.to(dev), q16=q16, k16=k16, qb=qb, kb=kb, v=v,
          q_rnorm=qrn, k_rnorm=krn, f16=1, v16=v16, q_prescale=L.lib().vbx_attn_q_prescale(10.0))
     qkv = (x.double().cpu() @ W.double().cpu().t()).view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
     q, k, vv = qkv[0], qkv[1], qkv[2]
+    assert rel_err(qrn, 1 / q.norm(dim=-1)) < 1e-5 and rel_err(krn, 1 / k.norm(dim=-1)) < 1e-5
     if qknorm:
-        assert rel_err(qrn, 1 / q.norm(dim=-1)) < 1e-5
         q = restate.l2norm_scale(q, 64) * qg.double().cpu()[:, None, :]
         k = restate.l2norm_scale(k, 64) * kg.double().cpu()[:, None, :]
     q, k = restate.apply_rotary(fr.double(), q), restate.apply_rotary(fr.double(), k)
@@ -216,6 +220,72 @@ def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     assert rel_err(q16, q * L.lib().vbx_attn_q_prescale(10.0)) < 6e-4 and rel_err(k16, k) < 6e-4
     assert rel_err(qb, q) < 4e-3 and rel_err(kb, k) < 4e-3
     assert rel_err(v, vv) < 4e-3 and rel_err(v16, vv) < 6e-4
+
+
+@pytest.mark.parametrize("Bsz,Np,H", [(3, 100, 4), (2, 1040, 16)])
+def test_gemm5_inference_outputs_and_tiled_agreement(L, Bsz, Np, H):
+    """K = 512 to_qkv without the backward's copies (what the sampler runs): the weight-stationary kernel writes q16 / k16 / v16 only,
+    agrees with fp64, and agrees with the 128-wide tiled kernels to rounding (the two differ in fp32 summation order and in the
+    1 / |x| sequence: v_rsq + Newton step against IEEE sqrt + divide)."""
+    g = torch.Generator().manual_seed(Np + H)
+    D, I, M = 512, H * 64, Bsz * Np
+    x = torch.randn(M, D, generator=g).half().to(dev)
+    W = (torch.randn(3 * I, D, generator=g) * D ** -0.5).half().to(dev)
+    qg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
+    kg = (1 + 0.1 * torch.randn(H, 64, generator=g)).to(dev)
+    fr, rc, rs = rot_tables(Np, 16)
+    ps = L.lib().vbx_attn_q_prescale(10.0)
+    outs = {}
+    for path in (0, 1):  # automatic (gemm5) / the 128-wide tiled kernels
+        L.lib().vbx_gemm_select(path)
+        q16 = torch.full((Bsz, H, Np, 64), float("nan"), dtype=torch.float16, device=dev)
+        k16, v16 = torch.full_like(q16, float("nan")), torch.full_like(q16, float("nan"))
+        gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_QKV, x, W, M, 3 * I, D, Np=Np, H=H, qk_scale=8.0, q_gamma=qg, k_gamma=kg, rot_cos=rc.to(dev),
+             rot_sin=rs.to(dev), q16=q16, k16=k16, f16=1, v16=v16, q_prescale=ps)
+        outs[path] = (q16, k16, v16)
+    L.lib().vbx_gemm_select(0)
+    qkv = (x.double().cpu() @ W.double().cpu().t()).view(Bsz, Np, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q = restate.apply_rotary(fr.double(), restate.l2norm_scale(qkv[0], 64) * qg.double().cpu()[:, None, :])
+    k = restate.apply_rotary(fr.double(), restate.l2norm_scale(qkv[1], 64) * kg.double().cpu()[:, None, :])
+    for path in (0, 1):
+        q16, k16, v16 = outs[path]
+        assert rel_err(q16, q * ps) < 6e-4 and rel_err(k16, k) < 6e-4 and rel_err(v16, qkv[2]) < 6e-4
+    for a, b in zip(outs[0], outs[1]):  # at most an fp16 ulp apart, almost everywhere equal
+        d = (a.float() - b.float()).abs()
+        assert float((d / (b.float().abs() + 1e-3)).max()) < 2.5e-3 and float((d > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("M,Fd,Fp,train", [(300, 341, 384, True), (70, 60, 64, False), (2100, 1365, 1408, True), (1234, 1365, 1408, False)])
+def test_gemm5_geglu(L, M, Fd, Fp, train):
+    """FeedForward[0] + GEGLU at K = 512 on the weight-stationary kernel (fp16 operands, the runtime's forward): fp16 G (+ bf16 copy
+    and the interleaved bf16 pre-activation in training), ragged M, against fp64."""
+    g = torch.Generator().manual_seed(M)
+    D = 512
+    x = torch.randn(M, D, generator=g).half().to(dev)
+    W1 = torch.randn(2 * Fd, D, generator=g) * D ** -0.5
+    b1 = torch.randn(2 * Fd, generator=g) * 0.1
+    W1p = torch.empty(2 * Fp, D, dtype=torch.bfloat16, device=dev)
+    b1p = torch.empty(2 * Fp, device=dev)
+    W1h = torch.empty(2 * Fp, D, dtype=torch.float16, device=dev)
+    L.call("vbx_pack_weight", W1.to(dev), 2 * Fd, D, W1p, W1h, 2 * Fp, D, 1, Fd, st())
+    L.call("vbx_pack_bias", b1.to(dev), 2 * Fd, b1p, 2 * Fp, 1, Fd, st())
+    g16 = torch.full((M + 1, Fp), float("nan"), dtype=torch.float16, device=dev)
+    gb = torch.full((M + 1, Fp), float("nan"), dtype=torch.bfloat16, device=dev)
+    h1 = torch.full((M + 1, 2 * Fp), float("nan"), dtype=torch.bfloat16, device=dev)
+    kw = dict(C2=h1, C3=gb) if train else {}
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_GEGLU, x, W1h, M, 2 * Fp, D, C=g16, ldc=Fp, bias=b1p, f16=1, **kw)
+    hdn = x.double().cpu() @ W1.half().double().t() + b1.double()
+    a, gate = hdn.chunk(2, dim=-1)
+    ref = F.gelu(gate) * a
+    assert rel_err(g16[:M, :Fd], ref) < 6e-4
+    assert float(g16[:M, Fd:].float().abs().max()) == 0.0 and bool(torch.isnan(g16[M]).all())  # padding exactly zero, nothing past row M
+    if train:
+        assert rel_err(gb[:M, :Fd], ref) < 4e-3 and bool(torch.isnan(gb[M]).all()) and bool(torch.isnan(h1[M]).all())
+        blk = h1[:M].float().cpu().view(M, Fp // 64, 2, 64)
+        assert rel_err(blk[:, :, 0].reshape(M, Fp)[:, :Fd], a) < 4e-3
+        assert rel_err(blk[:, :, 1].reshape(M, Fp)[:, :Fd], gate) < 4e-3
+    else:
+        assert bool(torch.isnan(gb).all()) and bool(torch.isnan(h1).all())  # inference: the backward's copies are not written
 
 
 @pytest.mark.parametrize("Fd,Fp", [(341, 384), (405, 448)])

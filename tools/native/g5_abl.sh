@@ -7,7 +7,7 @@ L=voicebox-pytorch_amd/lib; C=voicebox-pytorch_amd/csrc
 mode=$1; shift
 NS=${@:-1 8 9 11}
 if [ "$mode" = build ]; then
-  for n in $NS; do mkdir -p $L/g5abl$n; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DVBX_G5_ABL=$n -c $C/gemm5.hip -o $L/g5abl$n/gemm5.o & done
+  for n in $NS; do mkdir -p $L/g5abl$n; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -fno-slp-vectorize -DVBX_G5_ABL=$n -c $C/gemm5.hip -o $L/g5abl$n/gemm5.o & done
   wait
   for n in $NS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/g5abl$n/libvbx_hip.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/g5abl$n/gemm5.o $L/attn.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o || exit 1

@@ -32,6 +32,7 @@ _PROTOS = {
     "vbx_check_device": [I],
     "vbx_gemm": [C.POINTER(GemmDesc), P],
     "vbx_gemm_select": [I],
+    "vbx_gemm5_cu_limit": [I],
     "vbx_prof_enable": [I],
     "vbx_gemm_tn_splitk_grouped": [C.POINTER(GemmDesc), I, P],
     "vbx_splitk_reduce": [P, I, I, I, P, I, I, I, I, I, I, P],

@@ -9,6 +9,11 @@ LIB = os.path.join(HERE, "lib", "libvbx_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "gemm4.hip", "gemm5.hip", "attn.hip", "norm.hip", "gateloop.hip", "ops.hip", "precise.hip", "runtime.hip"]
 
 
+# gemm5.hip: its epilogue is hand-slotted into the gaps of the MFMA stream; SLP-packed fp32 (v_pk_mul_f32 / v_pk_fma_f32) costs more beside
+# MFMAs than the two scalar operations it replaces (MI355X_MICROARCH.md, per-instruction constants)
+EXTRA_FLAGS = {"gemm5.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -70,7 +75,7 @@ def build(force=False, verbose=True):
         shared.append(os.path.join(HERE, "..", "include", "vbx.h"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(src)] + [os.path.getmtime(f) for f in shared]):
             continue
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", src, "-o", obj]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -52,7 +53,10 @@ __device__ unsigned long long* g5_trace_buf = nullptr;
 #else
 #define G5_STAMP(i) do { } while (0)
 #endif
-__device__ uint4 g5_trash[64 * 16];  // where the lanes of rows >= M store (256 B per lane): keeps every store unconditional
+__device__ uint4 g5_trash[64 * 16];
+__device__ const float g5_ones[64] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                      1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                      1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};  // gamma of a v head / without qk-norm  // where the lanes of rows >= M store (256 B per lane): keeps every store unconditional
 
 template <bool F16>
 VBX_DEV f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
@@ -112,11 +116,44 @@ VBX_DEV void g5_split(int gr, int Np, float inv_np, int& b, int& n) {
   if (n >= Np) { n -= Np; b++; }
 }
 
-// ---- Epilogues.  A workgroup's waves run the epilogue of block j - 1 INSIDE the MFMA phase of block j (one basic block: no
-// branches, every store unconditional -- rows >= M go to g5_trash), in three pieces: pre (row statistics, addresses), then the two
-// halves pr = 0, 1 of the accumulator registers (8 registers of each feature block), each with up to four 16-byte LDS reads
-// (nreads) that the kernel places between its own fragment reads and waits for by count.
-//
+// ---- Epilogues, SLOTTED.  One wave per SIMD means nothing but this wave's own instructions can fill the gaps of its MFMA stream
+// (a v_mfma_f32_32x32x16 occupies the matrix pipe for 32 cycles; about five other instructions issue under it), and left to the
+// scheduler the two streams end up one after the other (measured: 5400 = 2930 + 2400 cycles per block).  So the epilogue of block
+// j - 1 is cut into 64 micro-steps of <= ~5 vector instructions, slot<S>() for S = 0..63, and the kernel issues MFMA S of block j,
+// then slot S, then a sched_barrier(0) that pins the order.  A slot reads the PREVIOUS block's accumulators (p0 / p1) and keeps its
+// state in a Ctx.  No branches, every store unconditional (rows >= M go to g5_trash).  LDS reads of the epilogue (the rotary rows):
+// issued by the kernel at slots 8 / 33 (reads<pr>()), complete from slots 17 / 41 on.
+// A micro-step's results are made opaque where the step ends: hipcc otherwise SINKS them towards their users (a later slot, often
+// behind the branch of a DMA piece), and the careful slotting collapses into one run of vector instructions.
+#define G5_PIN1(a) asm volatile("" : "+v"(a))
+#define G5_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define G5_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+VBX_DEV unsigned g5_cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+VBX_DEV unsigned g5_cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+VBX_DEV float g5_clamp16(float x) {  // common.hpp f32_to_f16_sat's clamp: +-65504, NaN stays NaN (v_med3 alone would turn it into a bound)
+  const float y = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+  return x != x ? x : y;
+}
+template <int KIND>
+VBX_DEV unsigned g5_pk(float a, float b) {
+  if constexpr (KIND == G5_F16) return g5_cvt_pk_f16(a, b);
+  else if constexpr (KIND == G5_F16_SAT) return g5_cvt_pk_f16(g5_clamp16(a), g5_clamp16(b));
+  else return g5_cvt_pk_bf16(a, b);
+}
+// the four packed registers of one 32-feature block's half pr (groups 2 pr, 2 pr + 1) -> one 16-byte store per lane
+VBX_DEV void g5_swap4(unsigned (&k)[4]) { g5_swap(k[0], k[2]); g5_swap(k[1], k[3]); }
+VBX_DEV void g5_st16(u16* dst, int pr, const unsigned (&k)[4], int lane) {
+  *reinterpret_cast<uint4*>(dst + 16 * pr + ((lane >> 5) << 3)) = make_uint4(k[0], k[1], k[2], k[3]);
+}
+
 // to_qkv + MultiheadRMSNorm + rotary (the arithmetic of gemm.hip's EpiQKV on the transposed accumulators).  Slab = one head of q, k
 // or v: block 0 = features d < 32, block 1 = d + 32.  KIND 0: q / k heads, KIND 1: v heads.
 struct Epi5QKV {
@@ -136,9 +173,15 @@ struct Epi5QKV {
     float post;      // q16 = q-hat * qps
     float nscale, none;  // row multiplier = rinv * nscale + none: (qk_scale, 0), or (0, 1) without qk-norm -- arithmetic, not a branch
   };
-  struct Row {
+  struct Ctx {
+    float ssa, ssb, rinv, r, rp;
+    int gr, b, n;
+    unsigned o;
     u16 *p16, *pb;
-    float r;
+    float* prn;
+    f32x4 e[4];
+    float lo, hi, lc, hc, ol0, oh0;     // pair in flight, and the even pair's results awaiting their partner for the pack
+    unsigned k16l[4], k16h[4], kbl[4], kbh[4];  // packed halves: fp16 lo / hi block, bf16 lo / hi block
   };
   template <int KIND> static constexpr int nreads() { return KIND == 0 ? 4 : 0; }
   VBX_DEV int wrow(int slab, int blk) const { return slab * 64 + blk * 32; }
@@ -152,100 +195,154 @@ struct Epi5QKV {
     st.post = which == 0 ? qps : 1.0f;
     st.nscale = qk_scale > 0.f ? qk_scale : 0.f;
     st.none = qk_scale > 0.f ? 0.f : 1.f;
-    if (which < 2 && qk_scale > 0.f) {
-      const float* g = (which == 0 ? qg : kg) + st.head * 64;
-      g5_load16(g, lane, st.glo);
-      g5_load16(g + 32, lane, st.ghi);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; j++) st.glo[j] = st.ghi[j] = 1.f;
-    }
+    // (one unconditional load through a selected pointer: two code paths filling the arrays made hipcc keep them in scratch memory,
+    //  i.e. a scratch load + vmcnt(0) in front of every use inside the MFMA phase)
+    const float* g = (which < 2 && qk_scale > 0.f) ? (which == 0 ? qg : kg) + st.head * 64 : g5_ones;
+    g5_load16(g, lane, st.glo);
+    g5_load16(g + 32, lane, st.ghi);
   }
-  // the rotary rows of a block's 32 tokens -> LDS (cos 4 KiB | sin 4 KiB; token row of 128 B, 16-byte chunk c at c ^ ((t >> 1) & 7)):
-  // wave w moves tokens 8 w .. 8 w + 7, lane i = token 8 w + i / 8, chunk position i % 8
-  VBX_DEV void issue_rot(char* slot, int row0, int wave, int lane, int M) const {
+  // The rotary rows of a block's 32 tokens -> LDS (cos 4 KiB | sin 4 KiB; token row of 128 B, 16-byte chunk c at c ^ ((t >> 1) & 7)):
+  // wave w moves tokens 8 w .. 8 w + 7, lane i = token 8 w + i / 8, chunk position i % 8.  piece 0: cos, piece 1: sin.
+  VBX_DEV void issue_rot(int piece, char* slot, int row0, int wave, int lane, int M) const {
     const int tt = 8 * wave + (lane >> 3);
     int b, n;
     g5_split(min(row0 + tt, M - 1), Np, inv_np, b, n);
     const long so = (long)n * 32 + ((((lane & 7) ^ (tt >> 1)) & 7) << 2);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rc + so),
-                                     (__attribute__((address_space(3))) void*)(slot + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rs + so),
-                                     (__attribute__((address_space(3))) void*)(slot + 4096 + wave * 1024), 16, 0, 0);
-  }
-  template <int KIND, bool TRAIN>
-  VBX_DEV void pre(const State& st, Row& rw, const f32x16& a0, const f32x16& a1, int row0, int lane, int M) const {
-    const int gr = row0 + (lane & 31);
-    const bool valid = gr < M;
-    int b, n;
-    g5_split(max(min(gr, M - 1), 0), Np, inv_np, b, n);  // (always a real row: nothing below is worth a branch to the compiler)
-    unsigned o = (unsigned)(((b * H + st.head) * Np + n) * 64);  // < 2^31 elements (host check)
-    asm volatile("" : "+v"(o));  // (computed for every lane: hipcc otherwise wraps it in an exec branch and splits the MFMA block)
-    u16* tr = reinterpret_cast<u16*>(g5_trash) + lane * 128;
-    rw.p16 = (valid ? st.d16 : tr) + (valid ? o : 0u);
-    if constexpr (TRAIN) rw.pb = (valid ? st.db : tr) + (valid ? o : 0u);
-    if constexpr (KIND == 0) {
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 16; j++) ss = fmaf(a0[j], a0[j], fmaf(a1[j], a1[j], ss));
-      ss = g5_halfsum(ss);
-      const float rinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize (voicebox_pytorch.py:286); the IEEE sequence, as EpiQKV
-      rw.r = fmaf(rinv, st.nscale, st.none);
-      if constexpr (TRAIN) {
-        const bool wr = valid && lane < 32;
-        unsigned orn = (unsigned)((b * H + st.head) * Np + n);
-        asm volatile("" : "+v"(orn));
-        float* prn = (wr ? st.rn : reinterpret_cast<float*>(tr)) + (wr ? orn : 0u);
-        *prn = rinv;
-      }
-    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((piece ? rs : rc) + so),
+                                     (__attribute__((address_space(3))) void*)(slot + piece * 4096 + wave * 1024), 16, 0, 0);
   }
   // LDS reads of half pr: cos / sin of the lane's token at features 16 pr + 4 hi + {0..3}, + 8
   template <int KIND>
-  VBX_DEV void reads(int pr, unsigned rot_addr, f32x4 (&e)[4]) const {
+  VBX_DEV void reads(int pr, unsigned rot_addr, Ctx& c) const {
     if constexpr (KIND == 0) {
       if (pr == 0) {
-        G5_DS_B128(e[0], rot_addr, 0); G5_DS_B128(e[1], rot_addr ^ 32, 0); G5_DS_B128(e[2], rot_addr, 4096); G5_DS_B128(e[3], rot_addr ^ 32, 4096);
+        G5_DS_B128(c.e[0], rot_addr, 0); G5_DS_B128(c.e[1], rot_addr ^ 32, 0); G5_DS_B128(c.e[2], rot_addr, 4096); G5_DS_B128(c.e[3], rot_addr ^ 32, 4096);
       } else {
-        G5_DS_B128(e[0], rot_addr ^ 64, 0); G5_DS_B128(e[1], rot_addr ^ 96, 0); G5_DS_B128(e[2], rot_addr ^ 64, 4096); G5_DS_B128(e[3], rot_addr ^ 96, 4096);
+        G5_DS_B128(c.e[0], rot_addr ^ 64, 0); G5_DS_B128(c.e[1], rot_addr ^ 96, 0); G5_DS_B128(c.e[2], rot_addr ^ 64, 4096); G5_DS_B128(c.e[3], rot_addr ^ 96, 4096);
       }
     }
   }
-  template <int KIND, bool TRAIN, bool F16>
-  VBX_DEV void half(const State& st, const Row& rw, int pr, const f32x16& a0, const f32x16& a1, const f32x4 (&e)[4], int lane) const {
-    float olo[8], ohi[8];
-    if constexpr (KIND == 1) {  // v: plain head split
-#pragma unroll
-      for (int i = 0; i < 8; i++) { olo[i] = a0[8 * pr + i]; ohi[i] = a1[8 * pr + i]; }
-      g5_store16<G5_F16_SAT>(rw.p16, pr, olo, lane);
-      g5_store16<G5_F16_SAT>(rw.p16 + 32, pr, ohi, lane);
-      if constexpr (TRAIN) {
-        g5_store16<G5_BF16>(rw.pb, pr, olo, lane);
-        g5_store16<G5_BF16>(rw.pb + 32, pr, ohi, lane);
+  template <int KIND>
+  VBX_DEV void wait_reads(Ctx& c, std::integral_constant<int, 0>) const { if constexpr (KIND == 0) g5_wait4<0>(c.e[0], c.e[1], c.e[2], c.e[3]); }
+  template <int KIND>
+  VBX_DEV void wait_reads(Ctx& c, std::integral_constant<int, 4>) const { if constexpr (KIND == 0) g5_wait4<4>(c.e[0], c.e[1], c.e[2], c.e[3]); }
+
+  // one pair (registers J of both blocks) of a q / k head, in two parts of ~4-5 instructions
+  template <bool TRAIN, int J, int PART>
+  VBX_DEV void pair(const State& st, Ctx& c, const f32x16& p0, const f32x16& p1) const {
+    constexpr int i = J & 7;  // index inside the half
+    if constexpr (PART == 0) {
+      c.lo = p0[J] * st.glo[J];
+      c.hi = p1[J] * st.ghi[J];
+      const float cs = c.e[i >> 2][i & 3];
+      c.lc = c.lo * cs;
+      c.hc = c.hi * cs;
+      G5_PIN4(c.lo, c.hi, c.lc, c.hc);
+    } else {
+      const float sn = c.e[2 + (i >> 2)][i & 3];
+      float ol = fmaf(-c.hi, sn, c.lc);  // rotate_half (voicebox_pytorch.py:193-199)
+      float oh = fmaf(c.lo, sn, c.hc);
+      if constexpr ((i & 1) == 0) {
+        c.ol0 = ol;
+        c.oh0 = oh;
+        G5_PIN2(c.ol0, c.oh0);
+      } else {  // the pair's partner is there: scale by the row's 1 / |x| * scale (* q prescale) and pack
+        constexpr int k = i >> 1;
+        if constexpr (TRAIN) {
+          c.kbl[k] = g5_cvt_pk_bf16(c.ol0 * c.r, ol * c.r);
+          c.kbh[k] = g5_cvt_pk_bf16(c.oh0 * c.r, oh * c.r);
+        }
+        c.k16l[k] = g5_cvt_pk_f16(c.ol0 * c.rp, ol * c.rp);
+        c.k16h[k] = g5_cvt_pk_f16(c.oh0 * c.rp, oh * c.rp);
+        G5_PIN2(c.k16l[k], c.k16h[k]);
+        if constexpr (TRAIN) G5_PIN2(c.kbl[k], c.kbh[k]);
+      }
+    }
+  }
+  template <int KIND, bool TRAIN, bool F16, int S>
+  VBX_DEV void slot(const State& st, Ctx& c, const f32x16& p0, const f32x16& p1, int row0, int lane, int M) const {
+    u16* tr = reinterpret_cast<u16*>(g5_trash) + lane * 128;
+    if constexpr (S == 11) {  // row addresses (both kinds)
+      c.gr = row0 + (lane & 31);
+      g5_split(max(min(c.gr, M - 1), 0), Np, inv_np, c.b, c.n);
+      G5_PIN2(c.b, c.n);
+    } else if constexpr (S == 12) {
+      c.o = (unsigned)(((c.b * H + st.head) * Np + c.n) * 64);  // < 2^31 elements (host check)
+      G5_PIN1(c.o);
+    } else if constexpr (S == 13) {
+      const bool valid = c.gr < M;
+      c.p16 = (valid ? st.d16 : tr) + (valid ? c.o : 0u);
+      if constexpr (TRAIN) c.pb = (valid ? st.db : tr) + (valid ? c.o : 0u);
+    }
+    if constexpr (KIND == 1) {  // v: plain head split; half pr in slots 17.. / 41..
+      if constexpr ((S >= 17 && S < 21) || (S >= 41 && S < 45)) {
+        constexpr int pr = S >= 41, k = (S - 17) % 24;  // packed register k of the half: accumulator registers 8 pr + 2 k, + 1
+        c.k16l[k] = g5_pk<G5_F16_SAT>(p0[8 * pr + 2 * k], p0[8 * pr + 2 * k + 1]);
+        c.k16h[k] = g5_pk<G5_F16_SAT>(p1[8 * pr + 2 * k], p1[8 * pr + 2 * k + 1]);
+        G5_PIN2(c.k16l[k], c.k16h[k]);
+        if constexpr (TRAIN) {
+          c.kbl[k] = g5_cvt_pk_bf16(p0[8 * pr + 2 * k], p0[8 * pr + 2 * k + 1]);
+          c.kbh[k] = g5_cvt_pk_bf16(p1[8 * pr + 2 * k], p1[8 * pr + 2 * k + 1]);
+          G5_PIN2(c.kbl[k], c.kbh[k]);
+        }
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const float lo = a0[8 * pr + i] * st.glo[8 * pr + i], hi = a1[8 * pr + i] * st.ghi[8 * pr + i];
-        const float c = e[i >> 2][i & 3], s = e[2 + (i >> 2)][i & 3];
-        // rotate_half (voicebox_pytorch.py:193-199), then the row's 1 / |x| * scale
-        olo[i] = (lo * c - hi * s) * rw.r;
-        ohi[i] = (hi * c + lo * s) * rw.r;
+      if constexpr (S < 8) {  // sum of squares, two chains
+        if constexpr (S == 0) { c.ssa = 0.f; c.ssb = 0.f; }
+        c.ssa = fmaf(p0[2 * S], p0[2 * S], c.ssa);
+        c.ssb = fmaf(p1[2 * S], p1[2 * S], c.ssb);
+        c.ssa = fmaf(p0[2 * S + 1], p0[2 * S + 1], c.ssa);
+        c.ssb = fmaf(p1[2 * S + 1], p1[2 * S + 1], c.ssb);
+        G5_PIN2(c.ssa, c.ssb);
+      } else if constexpr (S == 8) {
+        c.ssa = g5_halfsum(c.ssa + c.ssb);
+        G5_PIN1(c.ssa);
+      } else if constexpr (S == 9) {
+        // 1 / max(|x|, 1e-12) (F.normalize, voicebox_pytorch.py:286) as v_rsq + one Newton step (the raw v_rsq alone moved the chaotic
+        // random-init loss, gemm.hip EpiQKV; with the step it is within an ulp of the IEEE sequence, which costs ~25 instructions)
+        const float x = fmaxf(c.ssa, 1e-24f);
+        const float y = __builtin_amdgcn_rsqf(x);
+        c.rinv = y * fmaf(-0.5f * x * y, y, 1.5f);
+        G5_PIN1(c.rinv);
+      } else if constexpr (S == 10) {
+        c.r = fmaf(c.rinv, st.nscale, st.none);
+        c.rp = c.r * st.post;
+        G5_PIN2(c.r, c.rp);
+      } else if constexpr (S == 14 && TRAIN) {
+        const bool wr = c.gr < M && lane < 32;
+        c.prn = (wr ? st.rn : reinterpret_cast<float*>(tr)) + (wr ? (unsigned)((c.b * H + st.head) * Np + c.n) : 0u);
+      } else if constexpr (S == 15 && TRAIN) {
+        *c.prn = c.rinv;
+      } else if constexpr (S >= 17 && S < 33) {
+        this->template pair<TRAIN, ((S - 17) >> 1), ((S - 17) & 1)>(st, c, p0, p1);
+      } else if constexpr (S >= 41 && S < 57) {
+        this->template pair<TRAIN, (8 + ((S - 41) >> 1)), ((S - 41) & 1)>(st, c, p0, p1);
       }
-      if constexpr (TRAIN) {
-        g5_store16<G5_BF16>(rw.pb, pr, olo, lane);
-        g5_store16<G5_BF16>(rw.pb + 32, pr, ohi, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i++) { olo[i] *= st.post; ohi[i] *= st.post; }
-      g5_store16<G5_F16>(rw.p16, pr, olo, lane);
-      g5_store16<G5_F16>(rw.p16 + 32, pr, ohi, lane);
+    }
+    // swaps and stores of a half (both kinds)
+    constexpr int SW = KIND == 1 ? 21 : 33;  // first slot after half 0's packs (half 1: + 24)
+    if constexpr (S == SW || S == SW + 24) {
+      g5_swap4(c.k16l);
+      g5_swap4(c.k16h);
+    } else if constexpr (S == SW + 1 || S == SW + 25) {
+      constexpr int pr = S > SW + 1;
+      g5_st16(c.p16, pr, c.k16l, lane);
+      g5_st16(c.p16 + 32, pr, c.k16h, lane);
+    } else if constexpr (TRAIN && (S == SW + 2 || S == SW + 26)) {
+      g5_swap4(c.kbl);
+      g5_swap4(c.kbh);
+    } else if constexpr (TRAIN && (S == SW + 3 || S == SW + 27)) {
+      constexpr int pr = S > SW + 3;
+      g5_st16(c.pb, pr, c.kbl, lane);
+      g5_st16(c.pb + 32, pr, c.kbh, lane);
     }
   }
 };
 
-// ---- FeedForward[0] + GEGLU.  Packed weight rows (gemm.hip EpiGEGLU): every 128 rows = 64 "x" rows then their 64 "gate" rows.
+// FeedForward[0] + GEGLU.  Packed weight rows (gemm.hip EpiGEGLU): every 128 rows = 64 "x" rows then their 64 "gate" rows.
 // Slab s = 32 x rows + their 32 gate rows: block 0 = x, block 1 = gate; output columns (s >> 1) * 64 + (s & 1) * 32 + 0..31.
+// The 16 outputs of a lane take ~19 instructions each: output J in slots 4 J' .. 4 J' + 3 (half 0: slots 0-31, half 1: 32-63, the
+// row addresses squeezed into the first slots' spare room).
 struct Epi5GEGLU {
   u16* G; long ldg; const float* bias; u16* H1; long ldh; u16* Gb;
   static constexpr int KINDS = 1;
@@ -256,8 +353,12 @@ struct Epi5GEGLU {
     int col;  // first output column of the slab
     int wx;   // first packed weight row of the x block
   };
-  struct Row {
+  struct Ctx {
+    int gr;
+    unsigned og, oh;
     u16 *pg, *pgb, *ph;
+    float x, g, t, pl, ee, o0, x0, g0;
+    unsigned kg[4], kgb[4], khx[4], khg[4];
   };
   template <int KIND> static constexpr int nreads() { return 0; }
   VBX_DEV int wrow(int slab, int blk) const { return (slab >> 1) * 128 + blk * 64 + (slab & 1) * 32; }
@@ -268,40 +369,82 @@ struct Epi5GEGLU {
     g5_load16(bias + st.wx, lane, st.bx);
     g5_load16(bias + st.wx + 64, lane, st.bg);
   }
-  VBX_DEV void issue_rot(char*, int, int, int, int) const {}
-  template <int KIND, bool TRAIN>
-  VBX_DEV void pre(const State& st, Row& rw, const f32x16&, const f32x16&, int row0, int lane, int M) const {
-    const int gr = row0 + (lane & 31);
-    const bool valid = gr < M;
+  VBX_DEV void issue_rot(int, char*, int, int, int, int) const {}
+  template <int KIND> VBX_DEV void reads(int, unsigned, Ctx&) const {}
+  template <int KIND, int N> VBX_DEV void wait_reads(Ctx&, std::integral_constant<int, N>) const {}
+  template <int KIND, bool TRAIN, bool F16, int S>
+  VBX_DEV void slot(const State& st, Ctx& c, const f32x16& p0, const f32x16& p1, int row0, int lane, int M) const {
     u16* tr = reinterpret_cast<u16*>(g5_trash) + lane * 128;
-    unsigned og = (unsigned)(max(min(gr, M - 1), 0) * (int)ldg + st.col), oh = (unsigned)(max(min(gr, M - 1), 0) * (int)ldh + st.wx);  // < 2^31 (host check)
-    asm volatile("" : "+v"(og), "+v"(oh));  // (computed for every lane: no exec branch inside the MFMA block)
-    rw.pg = (valid ? G : tr) + (valid ? og : 0u);
-    if constexpr (TRAIN) {
-      rw.pgb = (valid ? Gb : tr) + (valid ? og : 0u);
-      rw.ph = (valid ? H1 : tr) + (valid ? oh : 0u);
+    constexpr int J = S >> 2, PART = S & 3;  // accumulator register and the quarter of its work
+    // erf-GELU as common.hpp gelu_erf (Abramowitz-Stegun 7.1.26), cut in four
+    if constexpr (S == 33) st_half<TRAIN>(c, 0, lane);  // half 0's stores (its swaps closed slot 31; kg[] is packed again from slot 39 on)
+    if constexpr (PART == 0) {
+      if constexpr (S == 0) {
+        c.gr = row0 + (lane & 31);
+        const int rr = max(min(c.gr, M - 1), 0);
+        c.og = (unsigned)(rr * (int)ldg + st.col);
+        if constexpr (TRAIN) c.oh = (unsigned)(rr * (int)ldh + st.wx);
+      }
+      c.x = p0[J] + st.bx[J];
+      c.g = p1[J] + st.bg[J];
+      const float z = c.g * 0.70710678118654752440f;
+      c.t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(z), 1.0f));
+      c.ee = -z * z;
+      G5_PIN4(c.x, c.g, c.t, c.ee);
+    } else if constexpr (PART == 1) {
+      if constexpr (S == 1) {
+        const bool valid = c.gr < M;
+        c.pg = (valid ? G : tr) + (valid ? c.og : 0u);
+        if constexpr (TRAIN) {
+          c.pgb = (valid ? Gb : tr) + (valid ? c.og : 0u);
+          c.ph = (valid ? H1 : tr) + (valid ? c.oh : 0u);
+        }
+      }
+      float pl = fmaf(1.061405429f, c.t, -1.453152027f);
+      pl = fmaf(pl, c.t, 1.421413741f);
+      pl = fmaf(pl, c.t, -0.284496736f);
+      c.pl = fmaf(pl, c.t, 0.254829592f);
+      c.ee = __expf(c.ee);
+      G5_PIN2(c.pl, c.ee);
+    } else if constexpr (PART == 2) {
+      const float r = fmaf(-c.pl * c.t, c.ee, 1.0f);
+      const float er = copysignf(r, c.g);
+      c.pl = 0.5f * c.g * (1.0f + er) * c.x;  // gelu(gate) * x
+      G5_PIN1(c.pl);
+    } else {
+      if constexpr ((J & 1) == 0) {
+        c.o0 = c.pl;
+        if constexpr (TRAIN) { c.x0 = c.x; c.g0 = c.g; }
+      } else {
+        constexpr int k = (J & 7) >> 1;
+        c.kg[k] = g5_pk<F16 ? G5_F16_SAT : G5_BF16>(c.o0, c.pl);
+        if constexpr (TRAIN) {
+          c.kgb[k] = g5_cvt_pk_bf16(c.o0, c.pl);
+          c.khx[k] = g5_cvt_pk_bf16(c.x0, c.x);
+          c.khg[k] = g5_cvt_pk_bf16(c.g0, c.g);
+        }
+      }
+      // a half is packed after J = 7 / 15: swaps and stores ride in the spare room of the following slots' PART 3
+      if constexpr (J == 7 || J == 15) {
+        g5_swap4(c.kg);
+        if constexpr (TRAIN) { g5_swap4(c.kgb); g5_swap4(c.khx); g5_swap4(c.khg); }
+      }
+      if constexpr (J == 15) st_half<TRAIN>(c, 1, lane);
     }
   }
-  template <int KIND>
-  VBX_DEV void reads(int, unsigned, f32x4 (&)[4]) const {}
-  template <int KIND, bool TRAIN, bool F16>
-  VBX_DEV void half(const State& st, const Row& rw, int pr, const f32x16& a0, const f32x16& a1, const f32x4 (&)[4], int lane) const {
-    float x[8], g[8], o[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      x[i] = a0[8 * pr + i] + st.bx[8 * pr + i];
-      g[i] = a1[8 * pr + i] + st.bg[8 * pr + i];
-      o[i] = gelu_erf(g[i]) * x[i];
-    }
-    if constexpr (F16) g5_store16<G5_F16_SAT>(rw.pg, pr, o, lane);
-    else g5_store16<G5_BF16>(rw.pg, pr, o, lane);
+  template <bool TRAIN>
+  VBX_DEV void st_half(Ctx& c, int pr, int lane) const {
+    g5_st16(c.pg, pr, c.kg, lane);
     if constexpr (TRAIN) {
-      g5_store16<G5_BF16>(rw.pgb, pr, o, lane);
-      g5_store16<G5_BF16>(rw.ph, pr, x, lane);
-      g5_store16<G5_BF16>(rw.ph + 64, pr, g, lane);
+      g5_st16(c.pgb, pr, c.kgb, lane);
+      g5_st16(c.ph, pr, c.khx, lane);
+      g5_st16(c.ph + 64, pr, c.khg, lane);
     }
   }
 };
+
+template <int... I, class Fn>
+VBX_DEV void g5_for_slots(std::integer_sequence<int, I...>, Fn&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 template <class Epi, bool F16, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
@@ -314,10 +457,11 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
   const bool active = slab_raw < p.nslab;
   const int slab = active ? slab_raw : 0;  // (an idle wave of the last panel repeats slab 0 into the trash)
 
-  // ---- the stationary weight slab: 2 feature blocks x 32 k-steps of A-operand fragments (256 registers).  Loaded THROUGH the LDS:
-  // a lane's fragments are 16-byte pieces of 32 different rows -- as direct global loads every instruction touches 32 cache lines
-  // (13 us of prologue); as 1 KiB row DMAs into a wave-private 32 KiB region + the activation fragments' swizzled reads it is an
-  // L2 -> LDS stream of 256 KiB per workgroup.
+  // ---- the stationary weight slab: 2 feature blocks x 32 k-steps of A-operand fragments = 256 registers, ALL of the accumulator
+  // half of the register file (the MFMAs below name them with "a" constraints: A / B operands may be AGPRs, so no copy is ever made).
+  // Loaded THROUGH the LDS: a lane's fragments are 16-byte pieces of 32 different rows -- as direct global loads every instruction
+  // touches 32 cache lines (13 us of prologue); as 1 KiB row DMAs into a wave-private 32 KiB region + the activation fragments'
+  // swizzled reads it is an L2 -> LDS stream of 256 KiB per workgroup.
   s16x8 w[2][G5_KS];
   G5_STAMP(0);
   {
@@ -348,29 +492,59 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
   G5_STAMP(1);
   typename Epi::State st;
   epi.init(st, slab, lane);
-  if (!active) {  // idle wave: its stores go to the trash
-    // (the State's output pointers are only used through Row, which pre() redirects for rows >= M: give it M = 0)
-  }
-  const int Meff = active ? p.M : 0;  // rows >= Meff are "invalid" for the epilogue
+  const int Meff = active ? p.M : 0;  // rows >= Meff are "invalid" for the epilogue: an idle wave stores to the trash
 
   auto run = [&](auto kind_c) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr int E = Epi::template nreads<KIND>();   // LDS reads of an epilogue half
     constexpr int NP = 8 + (Epi::HAS_ROT ? 2 : 0);    // LDS-DMA pieces per wave per block
     // ---- activation ring.  This wave's 8 rows of a block: t = 8 wave + q, chunk position = lane -> source chunk lane ^ (t & 15)
+    // Per piece q: a constant per-lane byte offset (row 8 wave + q of the block, swizzled chunk) on a per-block uniform base, so a piece
+    // costs no address arithmetic inside the phase (as first written: ~16 scalar instructions per piece, 170 per phase).  Only the
+    // ragged last block (rows >= M clamp to row M - 1) computes addresses per lane.
     const int swz0 = (wave & 1) * 8;
-    auto issue = [&](int j) {  // block j of this workgroup -> X slot j % 3, rotary slot j % 4
-      if constexpr (VBX_G5_ABL & 2) return;
-      const int rb = idx + j * p.wpp;
-      char* dst = smem + (j % G5_NSLOT) * G5_SLOT + wave * 8 * G5_ROWB;
+    unsigned voff[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int row = min(rb * 32 + wave * 8 + q, p.M - 1);
-        const u16* src = p.A + (long)row * p.lda + ((lane ^ (swz0 + q)) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + q * G5_ROWB), 16, 0, 0);
+    for (int q = 0; q < 8; q++) voff[q] = (unsigned)((wave * 8 + q) * (int)p.lda * 2 + ((lane ^ (swz0 + q)) << 4));
+    const bool voff_ok = 32L * p.lda * 2 < (1L << 31);
+    struct Blk {  // what the pieces of one block share (computed once per phase, not per piece)
+      bool fast;
+      const char* base;
+      char* xdst;
+      char* rdst;
+      int row0;
+    };
+    auto blk_of = [&](int j) {
+      const int rb = idx + j * p.wpp;
+      Blk b;
+      b.fast = rb * 32 + 32 <= p.M && voff_ok;
+      b.base = reinterpret_cast<const char*>(p.A) + (long)rb * 32 * p.lda * 2;
+      b.xdst = smem + (j % G5_NSLOT) * G5_SLOT + wave * 8 * G5_ROWB;
+      b.rdst = smem + G5_ROT0 + (j & 3) * G5_ROTSLOT;
+      b.row0 = rb * 32;
+      return b;
+    };
+    auto issue_piece = [&](int q, const Blk& b) {  // piece q of a block of this workgroup -> its X slot / rotary slot
+      if constexpr (VBX_G5_ABL & 2) return;
+      if (q < 8) {
+        char* dst = b.xdst + q * G5_ROWB;
+        if (b.fast) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b.base + voff[q]),
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+          const int row = min(b.row0 + wave * 8 + q, p.M - 1);
+          const u16* src = p.A + (long)row * p.lda + ((lane ^ (swz0 + q)) << 3);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      } else {
+        epi.issue_rot(q - 8, b.rdst, b.row0, wave, lane, p.M);
       }
-      if constexpr (Epi::HAS_ROT) epi.issue_rot(smem + G5_ROT0 + (j & 3) * G5_ROTSLOT, rb * 32, wave, lane, p.M);
+    };
+    auto issue = [&](int j) {
+      const Blk b = blk_of(j);
+#pragma unroll
+      for (int q = 0; q < NP; q++) issue_piece(q, b);
     };
     // fragment addresses inside a slot: token t = lane & 31, k-step s = 8 u + v: chunk 2 s + (lane >> 5) at position ^ (t & 15)
     unsigned fa[8];
@@ -383,93 +557,68 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       rot_a = (unsigned)(size_t)LDS_PTR(char, smem) + G5_ROT0 + t * 128 + ((((lane >> 5) ^ (t >> 1)) & 7) << 4);
     }
     f32x16 acc0, acc1, prv0, prv1;
-    // One phase = the MFMAs of block j (DO_MFMA) with the epilogue of block j - 1 (DO_EPI) in between, as ONE basic block.
-    // LDS operations in program order (all inline asm, so the order is the source order) and the counted waits:
-    //   R(xa,0) | R(xb,1) W(xa) M0 [pre] R(xa,2) W(xb) M1 | R(xb,3) E0 W(xa) M2 R(xa,4) W(xb) M3 W(E0) [half 0]
-    //           | R(xb,5) E1 W(xa) M4 R(xa,6) W(xb) M5 W(E1) [half 1] | R(xb,7) W(xa) M6 W(xb) M7
+    typename Epi::Ctx cx;
+    // One phase = the 64 MFMAs of block j (MF), each followed by micro-step S of block j - 1's epilogue (EP) and -- in the first
+    // slots -- one LDS-DMA piece of block j + 2; sched_barrier(0) after every slot pins the order.  MFMA S: k-step S / 2, feature
+    // block S % 2; the fragments of k-steps 4 kb .. 4 kb + 3 are batch kb in register set kb % 2.  LDS operations in program order
+    // (all inline asm) and the counted waits:  R(b0) | s0: R(b1) W(b0) | s8: R(b2) W(b1) E0 | s16: R(b3) W(b2) | s17: W(E0) |
+    // s24: R(b4) W(b3) | s32: R(b5) W(b4) | s33: E1 | s40: R(b6) W(b5) | s41: W(E1) | s48: R(b7) W(b6) | s56: W(b7).
     auto phase = [&](auto mf_c, auto ep_c, int j) {
-      constexpr bool DO_MFMA = decltype(mf_c)::value && !(VBX_G5_ABL & 8), DO_EPI = decltype(ep_c)::value && !(VBX_G5_ABL & 1);
-      constexpr int X4 = DO_MFMA ? 4 : 0, EE = DO_EPI ? E : 0;
+      constexpr bool MF = decltype(mf_c)::value && !(VBX_G5_ABL & 8), EP = decltype(ep_c)::value && !(VBX_G5_ABL & 1);
+      constexpr int EE = EP ? E : 0, X4 = MF ? 4 : 0;
       const unsigned so = (unsigned)((j % G5_NSLOT) * G5_SLOT);
       const unsigned ra = rot_a + (unsigned)(((j - 1) & 3) * G5_ROTSLOT);
-      s16x8 xa[4], xb[4];
-      f32x4 e[4];
-      typename Epi::Row rw;
-#define G5_READ4(x, kb)                                                          \
-  if constexpr (DO_MFMA) {                                                       \
-    G5_DS_B128(x[0], fa[((kb) * 4 + 0) & 7] + so, (((kb) * 4 + 0) >> 3) * 256);  \
-    G5_DS_B128(x[1], fa[((kb) * 4 + 1) & 7] + so, (((kb) * 4 + 1) >> 3) * 256);  \
-    G5_DS_B128(x[2], fa[((kb) * 4 + 2) & 7] + so, (((kb) * 4 + 2) >> 3) * 256);  \
-    G5_DS_B128(x[3], fa[((kb) * 4 + 3) & 7] + so, (((kb) * 4 + 3) >> 3) * 256);  \
-  }
-#define G5_WAIT(x, n) if constexpr (DO_MFMA) g5_wait4<n>(x[0], x[1], x[2], x[3])
-#define G5_MFMA4(x, kb)                                                          \
-  if constexpr (DO_MFMA) {                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; i++) {                              \
-      acc0 = mfma32<F16>(w[0][(kb) * 4 + i], x[i], acc0);                        \
-      acc1 = mfma32<F16>(w[1][(kb) * 4 + i], x[i], acc1);                        \
-    }                                                                            \
-  }
-      if constexpr (DO_MFMA) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc0[i] = acc1[i] = 0.f;
-      }
-      G5_READ4(xa, 0);
-      // pair 0
-      G5_READ4(xb, 1);
-      G5_WAIT(xa, X4);
-      G5_MFMA4(xa, 0);
-      if constexpr (DO_EPI) epi.template pre<KIND, TRAIN>(st, rw, prv0, prv1, (idx + (j - 1) * p.wpp) * 32, lane, Meff);
-      G5_READ4(xa, 2);
-      G5_WAIT(xb, X4);
-      G5_MFMA4(xb, 1);
-      // pair 1 + epilogue half 0
-      G5_READ4(xb, 3);
-      if constexpr (EE > 0) epi.template reads<KIND>(0, ra, e);
-      G5_WAIT(xa, X4 + EE);
-      G5_MFMA4(xa, 2);
-      G5_READ4(xa, 4);
-      G5_WAIT(xb, EE + X4);
-      G5_MFMA4(xb, 3);
-      if constexpr (DO_EPI) {
-        if constexpr (EE > 0) g5_wait4<X4>(e[0], e[1], e[2], e[3]);
-        epi.template half<KIND, TRAIN, F16>(st, rw, 0, prv0, prv1, e, lane);
-      }
-      // pair 2 + epilogue half 1
-      G5_READ4(xb, 5);
-      if constexpr (EE > 0) epi.template reads<KIND>(1, ra, e);
-      G5_WAIT(xa, X4 + EE);
-      G5_MFMA4(xa, 4);
-      G5_READ4(xa, 6);
-      G5_WAIT(xb, EE + X4);
-      G5_MFMA4(xb, 5);
-      if constexpr (DO_EPI) {
-        if constexpr (EE > 0) g5_wait4<X4>(e[0], e[1], e[2], e[3]);
-        epi.template half<KIND, TRAIN, F16>(st, rw, 1, prv0, prv1, e, lane);
-      }
-      // pair 3
-      G5_READ4(xb, 7);
-      G5_WAIT(xa, X4);
-      G5_MFMA4(xa, 6);
-      G5_WAIT(xb, 0);
-      G5_MFMA4(xb, 7);
-      if constexpr (DO_MFMA && DO_EPI) {  // the epilogue's vector instructions go INTO the gaps of the MFMA stream (one wave per SIMD:
-        // nothing else can fill them) instead of where the source has them
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, G5_VALU_PER_MFMA, 0);
+      const int row0 = (idx + (j - 1) * p.wpp) * 32;
+      const bool more = j + 2 < nb;
+      const Blk nxt = blk_of(j + 2);
+      s16x8 xs[2][4];
+#define G5_RD(kb)                                                                                       \
+  G5_DS_B128(xs[(kb) & 1][0], fa[((kb) * 4 + 0) & 7] + so, (((kb) * 4 + 0) >> 3) * 256);                \
+  G5_DS_B128(xs[(kb) & 1][1], fa[((kb) * 4 + 1) & 7] + so, (((kb) * 4 + 1) >> 3) * 256);                \
+  G5_DS_B128(xs[(kb) & 1][2], fa[((kb) * 4 + 2) & 7] + so, (((kb) * 4 + 2) >> 3) * 256);                \
+  G5_DS_B128(xs[(kb) & 1][3], fa[((kb) * 4 + 3) & 7] + so, (((kb) * 4 + 3) >> 3) * 256)
+      if constexpr (MF) { G5_RD(0); }
+      g5_for_slots(std::make_integer_sequence<int, 64>{}, [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        constexpr int kb = S >> 3;
+        if constexpr (MF && (S & 7) == 0) {
+          if constexpr (kb + 1 < 8) { G5_RD(kb + 1); }
+          constexpr int N = (kb + 1 < 8 ? 4 : 0) + ((kb == 2 || kb == 5) ? EE : 0);
+          g5_wait4<N>(xs[kb & 1][0], xs[kb & 1][1], xs[kb & 1][2], xs[kb & 1][3]);
         }
+        if constexpr (EE > 0 && (S == 8 || S == 33)) epi.template reads<KIND>(S == 33, ra, cx);  // (33: pair 7 of half 0 still reads e[] in slot 32)
+        if constexpr (EE > 0 && (S == 17 || S == 41)) epi.template wait_reads<KIND>(cx, std::integral_constant<int, X4>{});
+        if constexpr (MF) {
+          constexpr int ks = S >> 1, fb = S & 1;
+          f32x16& acc = fb ? acc1 : acc0;
+          const s16x8& x = xs[kb & 1][ks & 3];
+          if constexpr (S < 2) {
+            if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x));
+          } else {
+            if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w[fb][ks]), "v"(x));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w[fb][ks]), "v"(x));
+          }
+        }
+        // the LDS-DMA pieces of block j + 2 (after this phase's barrier: their slots are free), early in the phase so that they have
+        // landed by the next one's vmcnt(NP) -- that allowance is then what lets this phase's STORES stay in flight
+        if constexpr (decltype(mf_c)::value && (S & 1) == 1 && (S >> 1) < NP) {
+          if (more) issue_piece(S >> 1, nxt);
+        }
+        if constexpr (EP) epi.template slot<KIND, TRAIN, F16, S>(st, cx, prv0, prv1, row0, lane, Meff);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (MF) {
+        // an MFMA's result may be read by a vector instruction only 18 + wait states after a 16-pass MFMA issued (the assembler does
+        // not pad inline asm): the copies below are the first readers
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
+        prv0 = acc0;
+        prv1 = acc1;
       }
-      if constexpr (DO_MFMA) { prv0 = acc0; prv1 = acc1; }
-      else if constexpr (decltype(mf_c)::value) { prv0 = acc0; prv1 = acc1; }
-#undef G5_READ4
-#undef G5_WAIT
-#undef G5_MFMA4
     };
     // block j has landed (this wave's pieces; the barrier makes it everyone's).  At most the NP pieces of block j + 1 may stay in
     // flight: loads return in order, so <= NP outstanding operations of any kind means block j is complete -- and block j + 1 was
-    // requested a whole phase ago, so in practice the allowance is what lets the previous epilogue's STORES stay in flight.
+    // requested early in the previous phase, so in practice the allowance is what lets the previous epilogue's STORES stay in flight.
     auto top = [&](int j) {
       G5_STAMP(2 + 4 * j);
       if (j + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
@@ -477,13 +626,10 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       G5_STAMP(3 + 4 * j);
       __builtin_amdgcn_s_barrier();  // ... and every wave is done reading block j - 1 (X slot) and j - 2 (rotary slot): they take block j + 2
       G5_STAMP(4 + 4 * j);
-      if (j + 2 < nb) issue(j + 2);
       G5_STAMP(5 + 4 * j);
     };
     using T = std::true_type;
     using F = std::false_type;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc0[i] = acc1[i] = prv0[i] = prv1[i] = 0.f;
     issue(0);
     if (nb > 1) issue(1);
     top(0);
@@ -513,6 +659,7 @@ int launch5k(const G5Params& p, const Epi& epi, int grid, hipStream_t st) {
   VBX_LAUNCH_CHECK();
   return 0;
 }
+int g5_cu_limit = 0;  // vbx_gemm5_cu_limit
 template <class Epi>
 int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipStream_t st) {
   static int ncu = 0;
@@ -525,8 +672,9 @@ int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipSt
   G5Params p;
   p.A = (const u16*)d->A; p.W = (const u16*)d->B; p.M = d->M; p.lda = d->lda; p.ldb = d->ldb;
   p.nslab = nslab; p.npan = cdiv(nslab, 4); p.nrb = cdiv(d->M, 32);
-  if (p.npan > ncu || d->M >= (1 << 22)) return VBX_EUNSUPPORTED;
-  p.wpp = ncu / p.npan;
+  const int cus = (g5_cu_limit > 0 && g5_cu_limit < ncu) ? g5_cu_limit : ncu;
+  if (p.npan > cus || d->M >= (1 << 22)) return VBX_EUNSUPPORTED;
+  p.wpp = cus / p.npan;
   if (p.wpp > p.nrb) p.wpp = p.nrb;
   const int grid = p.npan * p.wpp;
   if (d->f16) return train ? launch5k<Epi, true, true>(p, epi, grid, st) : launch5k<Epi, true, false>(p, epi, grid, st);
@@ -535,6 +683,11 @@ int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipSt
 
 }  // namespace
 
+extern "C" int vbx_gemm5_cu_limit(int n) {
+  VBX_REQUIRE(n >= 0, "vbx_gemm5_cu_limit: n >= 0 (0 = every CU)");
+  g5_cu_limit = n;
+  return 0;
+}
 #ifdef VBX_G5_TRACE
 extern "C" int vbx_debug_gemm5_trace(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g5_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
 #endif

@@ -19,6 +19,7 @@ joined branches of one graph 82.5, two free-running graphs 81.7, with the offset
 tools/sample_offset.py); results bit-identical to the single-stream run.  VBX_SAMPLE_SPLIT=1 restores the single stream (A/B).
 Without a graph (use_graph=False) the halves run as fork / join branches per interval.
 """
+import contextlib
 import os
 
 import torch
@@ -142,7 +143,26 @@ class MidpointSampler:
         for s in self.side_streams:
             cur.wait_stream(s)
 
+    @contextlib.contextmanager
+    def _cu_share(self):
+        """The weight-stationary to_qkv / FeedForward-in kernel (csrc/gemm5.hip) owns whole CUs: with `split` concurrent parts every
+        launch gets 1 / split of the chip (include/vbx.h vbx_gemm5_cu_limit; read at launch, so baked into the captured graphs) --
+        the two parts' launches then run side by side instead of one behind the other."""
+        if self.split == 1:
+            yield
+            return
+        ncu = torch.cuda.get_device_properties(self.y.device).multi_processor_count
+        _lib.call("vbx_gemm5_cu_limit", max(ncu // self.split, 1))
+        try:
+            yield
+        finally:
+            _lib.call("vbx_gemm5_cu_limit", 0)
+
     def _capture(self):
+        with self._cu_share():
+            self._capture_shared()
+
+    def _capture_shared(self):
         # warm up on a side stream (one-time kernel attribute calls, weight packing), then capture one interval
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -212,5 +232,6 @@ class MidpointSampler:
                 if self.use_graph:
                     self.graph.replay()
                 else:
-                    self._interval()
+                    with self._cu_share():
+                        self._interval()
         return self.y.clone()
