@@ -28,6 +28,9 @@ namespace {
 #ifndef VBX_G5_ABL
 #define VBX_G5_ABL 0  // diagnostic builds (tools/native/g5_abl.sh): 1 no epilogue, 2 no DMA, 8 no MFMAs -- wrong results by construction
 #endif
+#ifndef G5_STAGGER
+#define G5_STAGGER 0  // (measured: the four waves taking turns at the texture path is 1-3 us SLOWER than all issuing in the same slots)
+#endif
 #ifndef G5_VALU_PER_MFMA
 #define G5_VALU_PER_MFMA 5
 #endif
@@ -45,6 +48,7 @@ struct G5Params {
   const u16* W;
   int M, nslab, npan, wpp, nrb;
   long lda, ldb;
+  unsigned abytes;  // bytes of A the kernel may read: ((M - 1) lda + K) * 2 < 2^31
 };
 
 #ifdef VBX_G5_TRACE  // diagnostic build (tools/native/g5_trace.sh): s_memtime stamps of wave 0 of every workgroup, [wg][64] u64
@@ -73,6 +77,12 @@ VBX_DEV void g5_wait4(T& a, T& b, T& c, T& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
 }
 
+// one LDS-DMA piece (64 lanes x 16 B -> lds_dst + 16 lane) as a raw BUFFER load: descriptor {base, bytes} in SGPRs, per-lane byte
+// offset voff, uniform byte offset soff; out-of-range lanes write zeros
+VBX_DEV void g5_buf_lds(const void* base, unsigned bytes, char* lds_dst, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
 VBX_DEV void g5_swap(unsigned& a, unsigned& b) {  // upper half-wave of a <-> lower half-wave of b (cdna_hip_programming.md T21)
   auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   a = r[0];
@@ -207,9 +217,8 @@ struct Epi5QKV {
     const int tt = 8 * wave + (lane >> 3);
     int b, n;
     g5_split(min(row0 + tt, M - 1), Np, inv_np, b, n);
-    const long so = (long)n * 32 + ((((lane & 7) ^ (tt >> 1)) & 7) << 2);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((piece ? rs : rc) + so),
-                                     (__attribute__((address_space(3))) void*)(slot + piece * 4096 + wave * 1024), 16, 0, 0);
+    const int so = n * 128 + ((((lane & 7) ^ (tt >> 1)) & 7) << 4);
+    g5_buf_lds(piece ? rs : rc, (unsigned)(Np * 128), slot + piece * 4096 + wave * 1024, so, 0);
   }
   // LDS reads of half pr: cos / sin of the lane's token at features 16 pr + 4 hi + {0..3}, + 8
   template <int KIND>
@@ -506,10 +515,10 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     unsigned voff[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) voff[q] = (unsigned)((wave * 8 + q) * (int)p.lda * 2 + ((lane ^ (swz0 + q)) << 4));
-    const bool voff_ok = 32L * p.lda * 2 < (1L << 31);
+    // X pieces as BUFFER loads to LDS (descriptor in SGPRs + constant per-lane byte offset + per-block uniform soffset: no address
+    // arithmetic per piece; rows >= M are out of the buffer's range and arrive as zeros).
     struct Blk {  // what the pieces of one block share (computed once per phase, not per piece)
-      bool fast;
-      const char* base;
+      int soff;     // byte offset of the block's first row
       char* xdst;
       char* rdst;
       int row0;
@@ -517,8 +526,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     auto blk_of = [&](int j) {
       const int rb = idx + j * p.wpp;
       Blk b;
-      b.fast = rb * 32 + 32 <= p.M && voff_ok;
-      b.base = reinterpret_cast<const char*>(p.A) + (long)rb * 32 * p.lda * 2;
+      b.soff = rb * 32 * (int)p.lda * 2;
       b.xdst = smem + (j % G5_NSLOT) * G5_SLOT + wave * 8 * G5_ROWB;
       b.rdst = smem + G5_ROT0 + (j & 3) * G5_ROTSLOT;
       b.row0 = rb * 32;
@@ -527,16 +535,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     auto issue_piece = [&](int q, const Blk& b) {  // piece q of a block of this workgroup -> its X slot / rotary slot
       if constexpr (VBX_G5_ABL & 2) return;
       if (q < 8) {
-        char* dst = b.xdst + q * G5_ROWB;
-        if (b.fast) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b.base + voff[q]),
-                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        } else {
-          const int row = min(b.row0 + wave * 8 + q, p.M - 1);
-          const u16* src = p.A + (long)row * p.lda + ((lane ^ (swz0 + q)) << 3);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        g5_buf_lds(p.A, p.abytes, b.xdst + q * G5_ROWB, (int)voff[q], b.soff);
       } else {
         epi.issue_rot(q - 8, b.rdst, b.row0, wave, lane, p.M);
       }
@@ -571,6 +570,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       const int row0 = (idx + (j - 1) * p.wpp) * 32;
       const bool more = j + 2 < nb;
       const Blk nxt = blk_of(j + 2);
+      const bool more_w[4] = {more && wave == 0, more && wave == 1, more && wave == 2, more && wave == 3};
       s16x8 xs[2][4];
 #define G5_RD(kb)                                                                                       \
   G5_DS_B128(xs[(kb) & 1][0], fa[((kb) * 4 + 0) & 7] + so, (((kb) * 4 + 0) >> 3) * 256);                \
@@ -602,9 +602,16 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
         }
         // the LDS-DMA pieces of block j + 2 (after this phase's barrier: their slots are free), early in the phase so that they have
         // landed by the next one's vmcnt(NP) -- that allowance is then what lets this phase's STORES stay in flight
+#if G5_STAGGER
+        // (the four waves take turns: wave w issues in slots 1 + w, 5 + w, ... so that no two pieces meet at the texture path)
+        if constexpr (decltype(mf_c)::value && S >= 1 && S <= 4 * NP) {
+          if (more_w[(S - 1) & 3]) issue_piece((S - 1) >> 2, nxt);
+        }
+#else
         if constexpr (decltype(mf_c)::value && (S & 1) == 1 && (S >> 1) < NP) {
           if (more) issue_piece(S >> 1, nxt);
         }
+#endif
         if constexpr (EP) epi.template slot<KIND, TRAIN, F16, S>(st, cx, prv0, prv1, row0, lane, Meff);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -672,6 +679,8 @@ int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipSt
   G5Params p;
   p.A = (const u16*)d->A; p.W = (const u16*)d->B; p.M = d->M; p.lda = d->lda; p.ldb = d->ldb;
   p.nslab = nslab; p.npan = cdiv(nslab, 4); p.nrb = cdiv(d->M, 32);
+  if (((long)d->M + 32) * d->lda * 2 >= (1L << 31)) return VBX_EUNSUPPORTED;
+  p.abytes = (unsigned)((((long)d->M - 1) * d->lda + G5_K) * 2);
   const int cus = (g5_cu_limit > 0 && g5_cu_limit < ncu) ? g5_cu_limit : ncu;
   if (p.npan > cus || d->M >= (1 << 22)) return VBX_EUNSUPPORTED;
   p.wpp = cus / p.npan;
