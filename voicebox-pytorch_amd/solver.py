@@ -152,7 +152,8 @@ class MidpointSampler:
             yield
             return
         ncu = torch.cuda.get_device_properties(self.y.device).multi_processor_count
-        _lib.call("vbx_gemm5_cu_limit", max(ncu // self.split, 1))
+        share = int(os.environ.get("VBX_GEMM5_CUS", "0")) or max(ncu // self.split, 1)  # (VBX_GEMM5_CUS=<n>: A/B of the share)
+        _lib.call("vbx_gemm5_cu_limit", share)
         try:
             yield
         finally:
