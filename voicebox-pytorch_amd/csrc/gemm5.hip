@@ -28,9 +28,8 @@ namespace {
 #ifndef VBX_G5_ABL
 #define VBX_G5_ABL 0  // diagnostic builds (tools/native/g5_abl.sh): 1 no epilogue, 2 no DMA, 8 no MFMAs -- wrong results by construction
 #endif
-#ifndef G5_STAGGER
-#define G5_STAGGER 0  // (measured: the four waves taking turns at the texture path is 1-3 us SLOWER than all issuing in the same slots)
-#endif
+// (Measured and removed: the four waves taking turns at the texture path -- wave w issuing its pieces in slots 1 + w, 5 + w, ... --
+//  is 1-3 us SLOWER than all four issuing in the same slots.)
 #ifndef G5_VALU_PER_MFMA
 #define G5_VALU_PER_MFMA 5
 #endif
@@ -133,11 +132,13 @@ VBX_DEV void g5_split(int gr, int Np, float inv_np, int& b, int& n) {
 // then slot S, then a sched_barrier(0) that pins the order.  A slot reads the PREVIOUS block's accumulators (p0 / p1) and keeps its
 // state in a Ctx.  No branches, every store unconditional (rows >= M go to g5_trash).  LDS reads of the epilogue (the rotary rows):
 // issued by the kernel at slots 8 / 33 (reads<pr>()), complete from slots 17 / 41 on.
-// A micro-step's results are made opaque where the step ends: hipcc otherwise SINKS them towards their users (a later slot, often
-// behind the branch of a DMA piece), and the careful slotting collapses into one run of vector instructions.
-#define G5_PIN1(a) asm volatile("" : "+v"(a))
-#define G5_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define G5_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+// The phase must stay ONE basic block: with a branch anywhere in it (as first written: around the DMA pieces of a block past the
+// last) hipcc SINKS a micro-step's results towards their users in a later block and the slotting collapses into one run of vector
+// instructions; pinning every result with an empty asm works too but costs a wait state per pin (~50 per phase).  G5_PIN* mark where
+// the pins were (no-ops now).
+#define G5_PIN1(a)
+#define G5_PIN2(a, b)
+#define G5_PIN4(a, b, c, d)
 VBX_DEV unsigned g5_cvt_pk_f16(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -213,12 +214,12 @@ struct Epi5QKV {
   }
   // The rotary rows of a block's 32 tokens -> LDS (cos 4 KiB | sin 4 KiB; token row of 128 B, 16-byte chunk c at c ^ ((t >> 1) & 7)):
   // wave w moves tokens 8 w .. 8 w + 7, lane i = token 8 w + i / 8, chunk position i % 8.  piece 0: cos, piece 1: sin.
-  VBX_DEV void issue_rot(int piece, char* slot, int row0, int wave, int lane, int M) const {
+  VBX_DEV void issue_rot(int piece, char* slot, int row0, int wave, int lane, int M, bool live) const {
     const int tt = 8 * wave + (lane >> 3);
     int b, n;
-    g5_split(min(row0 + tt, M - 1), Np, inv_np, b, n);
+    g5_split(max(min(row0 + tt, M - 1), 0), Np, inv_np, b, n);
     const int so = n * 128 + ((((lane & 7) ^ (tt >> 1)) & 7) << 4);
-    g5_buf_lds(piece ? rs : rc, (unsigned)(Np * 128), slot + piece * 4096 + wave * 1024, so, 0);
+    g5_buf_lds(piece ? rs : rc, live ? (unsigned)(Np * 128) : 0u, slot + piece * 4096 + wave * 1024, so, 0);
   }
   // LDS reads of half pr: cos / sin of the lane's token at features 16 pr + 4 hi + {0..3}, + 8
   template <int KIND>
@@ -378,7 +379,7 @@ struct Epi5GEGLU {
     g5_load16(bias + st.wx, lane, st.bx);
     g5_load16(bias + st.wx + 64, lane, st.bg);
   }
-  VBX_DEV void issue_rot(int, char*, int, int, int, int) const {}
+  VBX_DEV void issue_rot(int, char*, int, int, int, int, bool) const {}
   template <int KIND> VBX_DEV void reads(int, unsigned, Ctx&) const {}
   template <int KIND, int N> VBX_DEV void wait_reads(Ctx&, std::integral_constant<int, N>) const {}
   template <int KIND, bool TRAIN, bool F16, int S>
@@ -518,6 +519,8 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     // X pieces as BUFFER loads to LDS (descriptor in SGPRs + constant per-lane byte offset + per-block uniform soffset: no address
     // arithmetic per piece; rows >= M are out of the buffer's range and arrive as zeros).
     struct Blk {  // what the pieces of one block share (computed once per phase, not per piece)
+      unsigned xbytes;  // the X buffer's size, or 0 for a block past this workgroup's last: every lane is then out of range and the
+      bool live;        // piece writes zeros into a free slot -- no branch around a piece, so the whole phase is ONE basic block
       int soff;     // byte offset of the block's first row
       char* xdst;
       char* rdst;
@@ -526,7 +529,9 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     auto blk_of = [&](int j) {
       const int rb = idx + j * p.wpp;
       Blk b;
-      b.soff = rb * 32 * (int)p.lda * 2;
+      b.live = j < nb;
+      b.xbytes = b.live ? p.abytes : 0u;
+      b.soff = b.live ? rb * 32 * (int)p.lda * 2 : 0;
       b.xdst = smem + (j % G5_NSLOT) * G5_SLOT + wave * 8 * G5_ROWB;
       b.rdst = smem + G5_ROT0 + (j & 3) * G5_ROTSLOT;
       b.row0 = rb * 32;
@@ -535,9 +540,9 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     auto issue_piece = [&](int q, const Blk& b) {  // piece q of a block of this workgroup -> its X slot / rotary slot
       if constexpr (VBX_G5_ABL & 2) return;
       if (q < 8) {
-        g5_buf_lds(p.A, p.abytes, b.xdst + q * G5_ROWB, (int)voff[q], b.soff);
+        g5_buf_lds(p.A, b.xbytes, b.xdst + q * G5_ROWB, (int)voff[q], b.soff);
       } else {
-        epi.issue_rot(q - 8, b.rdst, b.row0, wave, lane, p.M);
+        epi.issue_rot(q - 8, b.rdst, b.row0, wave, lane, p.M, b.live);
       }
     };
     auto issue = [&](int j) {
@@ -568,9 +573,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       const unsigned so = (unsigned)((j % G5_NSLOT) * G5_SLOT);
       const unsigned ra = rot_a + (unsigned)(((j - 1) & 3) * G5_ROTSLOT);
       const int row0 = (idx + (j - 1) * p.wpp) * 32;
-      const bool more = j + 2 < nb;
       const Blk nxt = blk_of(j + 2);
-      const bool more_w[4] = {more && wave == 0, more && wave == 1, more && wave == 2, more && wave == 3};
       s16x8 xs[2][4];
 #define G5_RD(kb)                                                                                       \
   G5_DS_B128(xs[(kb) & 1][0], fa[((kb) * 4 + 0) & 7] + so, (((kb) * 4 + 0) >> 3) * 256);                \
@@ -602,16 +605,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
         }
         // the LDS-DMA pieces of block j + 2 (after this phase's barrier: their slots are free), early in the phase so that they have
         // landed by the next one's vmcnt(NP) -- that allowance is then what lets this phase's STORES stay in flight
-#if G5_STAGGER
-        // (the four waves take turns: wave w issues in slots 1 + w, 5 + w, ... so that no two pieces meet at the texture path)
-        if constexpr (decltype(mf_c)::value && S >= 1 && S <= 4 * NP) {
-          if (more_w[(S - 1) & 3]) issue_piece((S - 1) >> 2, nxt);
-        }
-#else
-        if constexpr (decltype(mf_c)::value && (S & 1) == 1 && (S >> 1) < NP) {
-          if (more) issue_piece(S >> 1, nxt);
-        }
-#endif
+        if constexpr (decltype(mf_c)::value && (S & 1) == 1 && (S >> 1) < NP) issue_piece(S >> 1, nxt);
         if constexpr (EP) epi.template slot<KIND, TRAIN, F16, S>(st, cx, prv0, prv1, row0, lane, Meff);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -628,8 +622,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     // requested early in the previous phase, so in practice the allowance is what lets the previous epilogue's STORES stay in flight.
     auto top = [&](int j) {
       G5_STAMP(2 + 4 * j);
-      if (j + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");  // (every phase issues NP pieces, the last two into free slots with nothing to read)
       G5_STAMP(3 + 4 * j);
       __builtin_amdgcn_s_barrier();  // ... and every wave is done reading block j - 1 (X slot) and j - 2 (rotary slot): they take block j + 2
       G5_STAMP(4 + 4 * j);
@@ -638,7 +631,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     using T = std::true_type;
     using F = std::false_type;
     issue(0);
-    if (nb > 1) issue(1);
+    issue(1);
     top(0);
     phase(T{}, F{}, 0);
     for (int j = 1; j < nb; j++) {
@@ -647,6 +640,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     }
     G5_STAMP(2 + 4 * nb);
     phase(F{}, T{}, nb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA piece may still be in flight when the workgroup's LDS is handed on
     G5_STAMP(3 + 4 * nb);
   };
   if constexpr (Epi::KINDS == 2) {
