@@ -214,11 +214,13 @@ struct Epi5QKV {
   }
   // The rotary rows of a block's 32 tokens -> LDS (cos 4 KiB | sin 4 KiB; token row of 128 B, 16-byte chunk c at c ^ ((t >> 1) & 7)):
   // wave w moves tokens 8 w .. 8 w + 7, lane i = token 8 w + i / 8, chunk position i % 8.  piece 0: cos, piece 1: sin.
-  VBX_DEV void issue_rot(int piece, char* slot, int row0, int wave, int lane, int M, bool live) const {
+  VBX_DEV int rot_off(int row0, int wave, int lane, int M) const {  // this lane's byte offset into the cos / sin tables for a block
     const int tt = 8 * wave + (lane >> 3);
     int b, n;
     g5_split(max(min(row0 + tt, M - 1), 0), Np, inv_np, b, n);
-    const int so = n * 128 + ((((lane & 7) ^ (tt >> 1)) & 7) << 4);
+    return n * 128 + ((((lane & 7) ^ (tt >> 1)) & 7) << 4);
+  }
+  VBX_DEV void issue_rot(int piece, char* slot, int so, int wave, bool live) const {
     g5_buf_lds(piece ? rs : rc, live ? (unsigned)(Np * 128) : 0u, slot + piece * 4096 + wave * 1024, so, 0);
   }
   // LDS reads of half pr: cos / sin of the lane's token at features 16 pr + 4 hi + {0..3}, + 8
@@ -379,7 +381,8 @@ struct Epi5GEGLU {
     g5_load16(bias + st.wx, lane, st.bx);
     g5_load16(bias + st.wx + 64, lane, st.bg);
   }
-  VBX_DEV void issue_rot(int, char*, int, int, int, int, bool) const {}
+  VBX_DEV int rot_off(int, int, int, int) const { return 0; }
+  VBX_DEV void issue_rot(int, char*, int, int, bool) const {}
   template <int KIND> VBX_DEV void reads(int, unsigned, Ctx&) const {}
   template <int KIND, int N> VBX_DEV void wait_reads(Ctx&, std::integral_constant<int, N>) const {}
   template <int KIND, bool TRAIN, bool F16, int S>
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       int soff;     // byte offset of the block's first row
       char* xdst;
       char* rdst;
-      int row0;
+      int rso;      // this lane's offset into the rotary tables
     };
     auto blk_of = [&](int j) {
       const int rb = idx + j * p.wpp;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       b.soff = b.live ? rb * 32 * (int)p.lda * 2 : 0;
       b.xdst = smem + (j % G5_NSLOT) * G5_SLOT + wave * 8 * G5_ROWB;
       b.rdst = smem + G5_ROT0 + (j & 3) * G5_ROTSLOT;
-      b.row0 = rb * 32;
+      b.rso = Epi::HAS_ROT ? epi.rot_off(rb * 32, wave, lane, p.M) : 0;
       return b;
     };
     auto issue_piece = [&](int q, const Blk& b) {  // piece q of a block of this workgroup -> its X slot / rotary slot
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       if (q < 8) {
         g5_buf_lds(p.A, b.xbytes, b.xdst + q * G5_ROWB, (int)voff[q], b.soff);
       } else {
-        epi.issue_rot(q - 8, b.rdst, b.row0, wave, lane, p.M, b.live);
+        epi.issue_rot(q - 8, b.rdst, b.rso, wave, b.live);
       }
     };
     auto issue = [&](int j) {
