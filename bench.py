@@ -132,6 +132,11 @@ def isolated_gemm_us(args, dev, which):
         d.mode, d.epilogue, d.M, d.N, d.K, d.lda, d.ldb, d.ldc = _lib.VBX_GEMM_NT, _lib.VBX_EPI_GEGLU, M, 2 * Fp, D, D, D, Fp
         d.A, d.B, d.C, d.bias, d.f16 = x.data_ptr(), w.data_ptr(), g.data_ptr(), bias.data_ptr(), 1
         keep = [x, w, bias, g]
+        if args.mode == "train":  # the SAME work as the in-situ stage: the training forward also writes the bf16 pre-activation and the bf16 copy
+            h1 = torch.empty(M, 2 * Fp, dtype=torch.bfloat16, device=dev)
+            gb = torch.empty(M, Fp, dtype=torch.bfloat16, device=dev)
+            d.C2, d.C3 = h1.data_ptr(), gb.data_ptr()
+            keep += [h1, gb]
     elif which == "dgrad to_qkv":
         x = torch.randn(M, 3 * I, device=dev).bfloat16()
         w = (torch.randn(3 * I, D, device=dev) * D ** -0.5).bfloat16()
@@ -152,7 +157,7 @@ def isolated_gemm_us(args, dev, which):
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the COMMITTED PMC passes of this command (tools/pmc_summary.py) -- a
     constant read from profiles/, not measured in this run: returns (bytes, source file)."""
-    for name in ("r05_train_pmc.json", "r04_train_pmc.json", "r03_train_pmc.json", "r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
+    for name in ("r06_train_pmc.json", "r05_train_pmc.json", "r04_train_pmc.json", "r03_train_pmc.json", "r02_train_pmc.json", "r02_mid_train_pmc.json", "r01_bench_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue
