@@ -176,6 +176,7 @@ struct Epi5QKV {
   float inv_np;
   static constexpr int KINDS = 2;
   static constexpr bool HAS_ROT = true;
+  static constexpr bool HAS_CINIT = false;  // accumulators start at 0
   struct State {
     float glo[16], ghi[16];
     int kind, head;
@@ -184,6 +185,7 @@ struct Epi5QKV {
     float post;      // q16 = q-hat * qps
     float nscale, none;  // row multiplier = rinv * nscale + none: (qk_scale, 0), or (0, 1) without qk-norm -- arithmetic, not a branch
   };
+  VBX_DEV f32x16 cinit(const State&, int) const { return f32x16{}; }  // (never used)
   struct Ctx {
     float ssa, ssb, rinv, r, rp;
     int gr, b, n;
@@ -353,18 +355,18 @@ struct Epi5QKV {
 
 // FeedForward[0] + GEGLU.  Packed weight rows (gemm.hip EpiGEGLU): every 128 rows = 64 "x" rows then their 64 "gate" rows.
 // Slab s = 32 x rows + their 32 gate rows: block 0 = x, block 1 = gate; output columns (s >> 1) * 64 + (s & 1) * 32 + 0..31.
-// The 16 outputs of a lane take ~19 instructions each: output J in slots 4 J' .. 4 J' + 3 (half 0: slots 0-31, half 1: 32-63, the
-// row addresses squeezed into the first slots' spare room).
 struct Epi5GEGLU {
   u16* G; long ldg; const float* bias; u16* H1; long ldh; u16* Gb;
   static constexpr int KINDS = 1;
   static constexpr bool HAS_ROT = false;
+  static constexpr bool HAS_CINIT = true;  // the bias is the C operand of a chain's first MFMA: no add in the epilogue
   struct State {
-    float bx[16], bg[16];
+    f32x16 cinit[2];  // bias of the x block / the gate block, in accumulator register order
     int kind;
     int col;  // first output column of the slab
     int wx;   // first packed weight row of the x block
   };
+  VBX_DEV f32x16 cinit(const State& st, int fb) const { return st.cinit[fb]; }
   struct Ctx {
     int gr;
     unsigned og, oh;
@@ -378,18 +380,33 @@ struct Epi5GEGLU {
     st.kind = 0;
     st.col = (slab >> 1) * 64 + (slab & 1) * 32;
     st.wx = wrow(slab, 0);
-    g5_load16(bias + st.wx, lane, st.bx);
-    g5_load16(bias + st.wx + 64, lane, st.bg);
+    float bx[16], bg[16];
+    g5_load16(bias + st.wx, lane, bx);
+    g5_load16(bias + st.wx + 64, lane, bg);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { st.cinit[0][j] = bx[j]; st.cinit[1][j] = bg[j]; }
   }
   VBX_DEV int rot_off(int, int, int, int) const { return 0; }
   VBX_DEV void issue_rot(int, char*, int, int, bool) const {}
   template <int KIND> VBX_DEV void reads(int, unsigned, Ctx&) const {}
   template <int KIND, int N> VBX_DEV void wait_reads(Ctx&, std::integral_constant<int, N>) const {}
+  template <bool TRAIN>
+  VBX_DEV void st_half(Ctx& c, int pr, int lane) const {
+    g5_st16(c.pg, pr, c.kg, lane);
+    if constexpr (TRAIN) {
+      g5_st16(c.pgb, pr, c.kgb, lane);
+      g5_st16(c.ph, pr, c.khx, lane);
+      g5_st16(c.ph + 64, pr, c.khg, lane);
+    }
+  }
+  // The 16 outputs of a lane: output J in slots 4 J .. 4 J + 3 (half 0: slots 0-31, half 1: 32-63; the row addresses ride in the first
+  // slots).  erf-GELU as common.hpp gelu_erf (Abramowitz-Stegun 7.1.26: erf z = sgn z (1 - P(t) e^{-z^2}), t = 1 / (1 + p |z|), z = g / sqrt 2)
+  // with the constants folded -- t = 1 / (1 + (p / sqrt 2) |g|), e^{-z^2} = 2^(-(log2 e / 2) g^2) -- and the sign handled without a
+  // select: with q = P(t) t' e^{-z^2} >= 0 and h = g / 2, gelu(g) = h (1 + sgn g (1 - q)) = (h + |h|) - |h| q.  ~15 instructions per output.
   template <int KIND, bool TRAIN, bool F16, int S>
   VBX_DEV void slot(const State& st, Ctx& c, const f32x16& p0, const f32x16& p1, int row0, int lane, int M) const {
     u16* tr = reinterpret_cast<u16*>(g5_trash) + lane * 128;
     constexpr int J = S >> 2, PART = S & 3;  // accumulator register and the quarter of its work
-    // erf-GELU as common.hpp gelu_erf (Abramowitz-Stegun 7.1.26), cut in four
     if constexpr (S == 33) st_half<TRAIN>(c, 0, lane);  // half 0's stores (its swaps closed slot 31; kg[] is packed again from slot 39 on)
     if constexpr (PART == 0) {
       if constexpr (S == 0) {
@@ -398,12 +415,10 @@ struct Epi5GEGLU {
         c.og = (unsigned)(rr * (int)ldg + st.col);
         if constexpr (TRAIN) c.oh = (unsigned)(rr * (int)ldh + st.wx);
       }
-      c.x = p0[J] + st.bx[J];
-      c.g = p1[J] + st.bg[J];
-      const float z = c.g * 0.70710678118654752440f;
-      c.t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(z), 1.0f));
-      c.ee = -z * z;
-      G5_PIN4(c.x, c.g, c.t, c.ee);
+      c.x = p0[J];  // (bias included: it was the accumulator's initial value)
+      c.g = p1[J];
+      c.t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(c.g), 1.0f));
+      c.ee = (c.g * c.g) * (-0.5f * 1.44269504088896340736f);
     } else if constexpr (PART == 1) {
       if constexpr (S == 1) {
         const bool valid = c.gr < M;
@@ -417,13 +432,11 @@ struct Epi5GEGLU {
       pl = fmaf(pl, c.t, 1.421413741f);
       pl = fmaf(pl, c.t, -0.284496736f);
       c.pl = fmaf(pl, c.t, 0.254829592f);
-      c.ee = __expf(c.ee);
-      G5_PIN2(c.pl, c.ee);
+      c.ee = __builtin_amdgcn_exp2f(c.ee);
     } else if constexpr (PART == 2) {
-      const float r = fmaf(-c.pl * c.t, c.ee, 1.0f);
-      const float er = copysignf(r, c.g);
-      c.pl = 0.5f * c.g * (1.0f + er) * c.x;  // gelu(gate) * x
-      G5_PIN1(c.pl);
+      const float q = (c.pl * c.t) * c.ee;
+      const float h = 0.5f * c.g;
+      c.pl = fmaf(-fabsf(h), q, h + fabsf(h)) * c.x;  // gelu(gate) * x
     } else {
       if constexpr ((J & 1) == 0) {
         c.o0 = c.pl;
@@ -437,21 +450,11 @@ struct Epi5GEGLU {
           c.khg[k] = g5_cvt_pk_bf16(c.g0, c.g);
         }
       }
-      // a half is packed after J = 7 / 15: swaps and stores ride in the spare room of the following slots' PART 3
-      if constexpr (J == 7 || J == 15) {
+      if constexpr (J == 7 || J == 15) {  // a half is packed: exchange the half-waves' registers
         g5_swap4(c.kg);
         if constexpr (TRAIN) { g5_swap4(c.kgb); g5_swap4(c.khx); g5_swap4(c.khg); }
       }
       if constexpr (J == 15) st_half<TRAIN>(c, 1, lane);
-    }
-  }
-  template <bool TRAIN>
-  VBX_DEV void st_half(Ctx& c, int pr, int lane) const {
-    g5_st16(c.pg, pr, c.kg, lane);
-    if constexpr (TRAIN) {
-      g5_st16(c.pgb, pr, c.kgb, lane);
-      g5_st16(c.ph, pr, c.khx, lane);
-      g5_st16(c.ph + 64, pr, c.khg, lane);
     }
   }
 };
@@ -598,7 +601,10 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
           constexpr int ks = S >> 1, fb = S & 1;
           f32x16& acc = fb ? acc1 : acc0;
           const s16x8& x = xs[kb & 1][ks & 3];
-          if constexpr (S < 2) {
+          if constexpr (S < 2 && Epi::HAS_CINIT) {  // a chain's first MFMA: C = the epilogue's initial value (a bias), straight from its registers
+            if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x), "v"(epi.cinit(st, fb)));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x), "v"(epi.cinit(st, fb)));
+          } else if constexpr (S < 2) {
             if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x));
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w[fb][ks]), "v"(x));
           } else {
