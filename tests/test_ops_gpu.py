@@ -102,7 +102,8 @@ def gemm(L, mode, epi, A, B, M, N, K, **kw):
     assert rc == 0, L.lib().vbx_last_error()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64), (4160, 512, 1408), (8320, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 200), (128, 128, 64), (8320, 512, 1024), (77, 1536, 512), (8320, 512, 1000), (8200, 512, 64), (4160, 512, 1408), (8320, 1024, 1024),
+                                   (8320, 1024, 512), (1234, 1408, 512), (70, 576, 512)])
 def test_gemm_nt_bf16_f32(L, M, N, K, tile_path):
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -122,6 +123,10 @@ def test_gemm_nt_bf16_f32(L, M, N, K, tile_path):
     out32b = torch.empty(M, N, device=dev)
     gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_F32, A, Bw, M, N, K, C=out32b, ldc=N)
     assert rel_err(out32b, ref) < 1e-5
+    # without a bias: at K = 512 and N a multiple of 64 the automatic choice is the weight-stationary kernel's plain bf16 epilogue
+    out_nb = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    gemm(L, L.VBX_GEMM_NT, L.VBX_EPI_BF16, A, Bw, M, N, K, C=out_nb, ldc=N)
+    assert rel_err(out_nb[:M], ref) < 4e-3 and bool(torch.isnan(out_nb[M]).all())
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 264, 200), (8320, 1024, 512), (130, 64, 1408), (8320, 512, 3072), (8320, 512, 360), (4160, 512, 1024), (8320, 1024, 3072)])

@@ -210,6 +210,18 @@ static void model_shapes(bool do_time, bool do_race, int Bt) {
     d.C2 = nullptr; d.C3 = nullptr;
     bs.push_back({"ff_in eval", d, 2.0 * M * 2 * Fp * D, {{G, (size_t)M * Fp * 2}}, {1}, {0}});
   }
+  {  // the K = 512 dgrads as NT products on transposed weight copies (plain bf16 epilogue); the same product as NN for comparison
+    auto A512b = dev(randn16((size_t)M * D, 1.0f, false));
+    auto WoT = dev(randn16((size_t)I * D, 0.03f, false)), W2T = dev(randn16((size_t)Fp * D, 0.03f, false));
+    uint16_t* Cb = devfill<uint16_t>((size_t)M * Fp, 0);
+    for (int N : {I, Fp}) {
+      vbx_gemm_desc d{}; d.mode = VBX_GEMM_NT; d.epilogue = VBX_EPI_BF16; d.M = M; d.N = N; d.K = D; d.lda = D; d.ldb = D; d.ldc = N;
+      d.A = A512b; d.B = N == I ? WoT : W2T; d.C = Cb;
+      bs.push_back({N == I ? "dgrad to_out as NT (N=1024)" : "dgrad ff_out as NT (N=1408)", d, 2.0 * M * N * D, {{Cb, (size_t)M * N * 2}}, {0}, {0}});
+      vbx_gemm_desc e = d; e.mode = VBX_GEMM_NN; e.ldb = N;  // (timing only: the same buffer read as [512][N])
+      if (do_time && !do_race) bs.push_back({N == I ? "dgrad to_out as NN (today)" : "dgrad ff_out as NN (today)", e, 2.0 * M * N * D, {{Cb, (size_t)M * N * 2}}, {0}, {0}});
+    }
+  }
   if (do_race) {
     printf("== race screen / agreement with the 128-wide path, batch %d\n", Bt);
     for (auto& b : bs) {

@@ -804,7 +804,9 @@ static int gemm_tile_for(const vbx_gemm_desc* d) {
   if (path == 1) return 1;
   // K = 512 linear layers with a row-wise epilogue (to_qkv, FeedForward-in): the weight-stationary kernel (gemm5.hip).  VBX_GEMM5=0: A/B.
   static const bool g5 = !(getenv("VBX_GEMM5") && atoi(getenv("VBX_GEMM5")) == 0);
-  if ((g5 || path == 4) && path != 3 && d->mode == VBX_GEMM_NT && d->K == 512 && (d->epilogue == VBX_EPI_QKV || d->epilogue == VBX_EPI_GEGLU)) return 5;
+  if ((g5 || path == 4) && path != 3 && d->mode == VBX_GEMM_NT && d->K == 512 &&
+      (d->epilogue == VBX_EPI_QKV || d->epilogue == VBX_EPI_GEGLU || (d->epilogue == VBX_EPI_BF16 && !d->f16 && !d->bias && d->N >= 512)))
+    return 5;
   return gemm_tile_fallback(d);
 }
 static int gemm_tile_fallback(const vbx_gemm_desc* d) {  // the LDS-tiled kernels' choice (everything gemm5 does not serve)

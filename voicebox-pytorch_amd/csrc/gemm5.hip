@@ -459,6 +459,54 @@ struct Epi5GEGLU {
   }
 };
 
+// Plain bf16 output C[M, ldc] = A . W^T (+ nothing): the K = 512 dgrads of the training step on TRANSPOSED weight copies (runtime.hip:
+// d(attention out) = dx . W_out, d(GEGLU out) = dx . W_2 as NT products).  Slab s = output columns 64 s .. 64 s + 63.
+struct Epi5BF16 {
+  u16* C; long ldc; int N;
+  static constexpr int KINDS = 1;
+  static constexpr bool HAS_ROT = false;
+  static constexpr bool HAS_CINIT = false;
+  struct State {
+    int kind, col;
+  };
+  VBX_DEV f32x16 cinit(const State&, int) const { return f32x16{}; }
+  struct Ctx {
+    int gr;
+    unsigned oc;
+    u16* pc;
+    unsigned kl[4], kh[4];
+  };
+  template <int KIND> static constexpr int nreads() { return 0; }
+  VBX_DEV int wrow(int slab, int blk) const { return slab * 64 + blk * 32; }
+  VBX_DEV void init(State& st, int slab, int) const { st.kind = 0; st.col = slab * 64; }
+  VBX_DEV int rot_off(int, int, int, int) const { return 0; }
+  VBX_DEV void issue_rot(int, char*, int, int, bool) const {}
+  template <int KIND> VBX_DEV void reads(int, unsigned, Ctx&) const {}
+  template <int KIND, int NN> VBX_DEV void wait_reads(Ctx&, std::integral_constant<int, NN>) const {}
+  template <int KIND, bool TRAIN, bool F16, int S>
+  VBX_DEV void slot(const State& st, Ctx& c, const f32x16& p0, const f32x16& p1, int row0, int lane, int M) const {
+    u16* tr = reinterpret_cast<u16*>(g5_trash) + lane * 128;
+    if constexpr (S == 0) {
+      c.gr = row0 + (lane & 31);
+      c.oc = (unsigned)(max(min(c.gr, M - 1), 0) * (int)ldc + st.col);
+    } else if constexpr (S == 1) {
+      const bool valid = c.gr < M;
+      c.pc = (valid ? C : tr) + (valid ? c.oc : 0u);
+    } else if constexpr ((S >= 4 && S < 8) || (S >= 36 && S < 40)) {
+      constexpr int pr = S >= 36, k = S & 3;
+      c.kl[k] = g5_cvt_pk_bf16(p0[8 * pr + 2 * k], p0[8 * pr + 2 * k + 1]);
+      c.kh[k] = g5_cvt_pk_bf16(p1[8 * pr + 2 * k], p1[8 * pr + 2 * k + 1]);
+    } else if constexpr (S == 8 || S == 40) {
+      g5_swap4(c.kl);
+      g5_swap4(c.kh);
+    } else if constexpr (S == 9 || S == 41) {
+      constexpr int pr = S == 41;
+      g5_st16(c.pc, pr, c.kl, lane);
+      g5_st16(c.pc + 32, pr, c.kh, lane);
+    }
+  }
+};
+
 template <int... I, class Fn>
 VBX_DEV void g5_for_slots(std::integer_sequence<int, I...>, Fn&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -725,6 +773,12 @@ int vbx_gemm5(const vbx_gemm_desc* d, hipStream_t st) {
     if ((long)d->M * d->N >= (1L << 31) || (long)d->M * d->ldc >= (1L << 31)) return VBX_EUNSUPPORTED;
     Epi5GEGLU e{(u16*)d->C, d->ldc, d->bias, (u16*)d->C2, d->N, (u16*)d->C3};
     return launch5(d, e, d->N / 64, d->C2 != nullptr, st);
+  }
+  if (d->epilogue == VBX_EPI_BF16) {
+    if (d->bias || !d->C || d->ldc % 8 || d->N % 64 || d->delta || d->f16) return VBX_EUNSUPPORTED;
+    if ((long)d->M * d->ldc >= (1L << 31)) return VBX_EUNSUPPORTED;
+    Epi5BF16 e{(u16*)d->C, d->ldc, d->N};
+    return launch5(d, e, cdiv(d->N, 64), false, st);
   }
   return VBX_EUNSUPPORTED;
 }
