@@ -48,6 +48,7 @@ struct G5Params {
   int M, nslab, npan, wpp, nrb;
   long lda, ldb;
   unsigned abytes;  // bytes of A the kernel may read: ((M - 1) lda + K) * 2 < 2^31
+  int px, xs;       // XCD map: panel groups (1, 2 or 4; 0 = plain map) and workgroups per XCD
 };
 
 #ifdef VBX_G5_TRACE  // diagnostic build (tools/native/g5_trace.sh): s_memtime stamps of wave 0 of every workgroup, [wg][64] u64
@@ -514,9 +515,30 @@ template <class Epi, bool F16, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pan = blockIdx.x / p.wpp, idx = blockIdx.x - pan * p.wpp;
-  if (pan >= p.npan || idx >= p.nrb) return;
-  const int nb = (p.nrb - idx + p.wpp - 1) / p.wpp;  // this workgroup's blocks: idx, idx + wpp, ...
+  // Work of this workgroup: panel `pan`, row blocks rb0, rb0 + rbs, ... (nb of them).
+  //  plain map  : wpp workgroups per panel, workgroup idx of a panel takes row blocks idx, idx + wpp, ...  Every panel's workgroups
+  //               sit on all 8 XCDs, so every L2 fetches the whole activation matrix (8 x the algorithmic read, PMC);
+  //  XCD map    : (px > 0; launch5 picks it when it costs no extra block per workgroup) XCD x = blockIdx % 8 serves the panels of group
+  //               x % px and the row blocks of slice x / px only: an activation row is fetched by px L2s instead of 8.  Placement is a
+  //               locality hint (workgroups are dealt round-robin to the XCDs), never a correctness assumption.
+  int pan, rb0, rbs, nb;
+  if (p.px > 0) {
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;        // XCD, slot on it (0 .. xs - 1)
+    const int pg = x % p.px, rg = x / p.px, ppg = p.npan / p.px;
+    const int base = p.xs / ppg, extra = p.xs - base * ppg;  // workgroups per panel of the group: base + 1 for the first `extra`
+    const int cut = extra * (base + 1);
+    const int pl = s < cut ? s / (base + 1) : extra + (s - cut) / base;
+    const int li = s < cut ? s - pl * (base + 1) : (s - cut) - (pl - extra) * base;
+    const int cnt = pl < extra ? base + 1 : base;
+    const int nrg = 8 / p.px, r0 = (int)((long)rg * p.nrb / nrg), r1 = (int)((long)(rg + 1) * p.nrb / nrg);
+    pan = pg * ppg + pl; rb0 = r0 + li; rbs = cnt;
+    nb = rb0 < r1 ? (r1 - rb0 + cnt - 1) / cnt : 0;
+  } else {
+    pan = blockIdx.x / p.wpp;
+    rb0 = blockIdx.x - pan * p.wpp; rbs = p.wpp;
+    nb = (pan < p.npan && rb0 < p.nrb) ? (p.nrb - rb0 + p.wpp - 1) / p.wpp : 0;
+  }
+  if (nb == 0) return;
   const int slab_raw = pan * 4 + wave;
   const bool active = slab_raw < p.nslab;
   const int slab = active ? slab_raw : 0;  // (an idle wave of the last panel repeats slab 0 into the trash)
@@ -581,7 +603,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       int rso;      // this lane's offset into the rotary tables
     };
     auto blk_of = [&](int j) {
-      const int rb = idx + j * p.wpp;
+      const int rb = rb0 + j * rbs;
       Blk b;
       b.live = j < nb;
       b.xbytes = b.live ? p.abytes : 0u;
@@ -626,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
       constexpr int EE = EP ? E : 0, X4 = MF ? 4 : 0;
       const unsigned so = (unsigned)((j % G5_NSLOT) * G5_SLOT);
       const unsigned ra = rot_a + (unsigned)(((j - 1) & 3) * G5_ROTSLOT);
-      const int row0 = (idx + (j - 1) * p.wpp) * 32;
+      const int row0 = (rb0 + (j - 1) * rbs) * 32;
       const Blk nxt = blk_of(j + 2);
       s16x8 xs[2][4];
 #define G5_RD(kb)                                                                                       \
@@ -736,7 +758,20 @@ int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipSt
   if (p.npan > cus || d->M >= (1 << 22)) return VBX_EUNSUPPORTED;
   p.wpp = cus / p.npan;
   if (p.wpp > p.nrb) p.wpp = p.nrb;
-  const int grid = p.npan * p.wpp;
+  int grid = p.npan * p.wpp;
+  p.px = 0; p.xs = 0;
+  static const bool xcd_map = !(getenv("VBX_GEMM5_XCD") && atoi(getenv("VBX_GEMM5_XCD")) == 0);
+  if (xcd_map && cus == ncu && ncu % 8 == 0 && p.nrb >= 8 * 8) {
+    // the XCD map with the fewest panel groups (= the fewest L2s fetching an activation row) that costs no extra block per workgroup
+    const int plain_max = cdiv(p.nrb, p.wpp), xs = ncu / 8;
+    for (int px = 1; px <= 4 && !p.px; px *= 2) {
+      if (p.npan % px) continue;
+      const int ppg = p.npan / px, nrg = 8 / px;
+      if (ppg > xs) continue;
+      const int cnt_min = xs / ppg, rows_max = cdiv(p.nrb, nrg);  // (slices differ by at most one row block)
+      if (cdiv(rows_max, cnt_min) <= plain_max) { p.px = px; p.xs = xs; grid = ncu; }
+    }
+  }
   if (d->f16) return train ? launch5k<Epi, true, true>(p, epi, grid, st) : launch5k<Epi, true, false>(p, epi, grid, st);
   return train ? launch5k<Epi, false, true>(p, epi, grid, st) : launch5k<Epi, false, false>(p, epi, grid, st);
 }
