@@ -12,7 +12,13 @@
 //     sixth of the L2 -> LDS bytes per MFMA of the 128 x 128 tile;
 //   * the product is computed TRANSPOSED (features x tokens): a lane then owns ONE token and, of its 64 features, the 16 rotary
 //     pairs (d, d + 32) -- acc0[j] / acc1[j] -- so the sum of squares is 32 FMAs + one half-wave exchange, rotate_half needs no
-//     cross-lane traffic, the GEGLU gate sits beside its value, and a v_permlane32_swap per register pair gives 16-byte stores.
+//     cross-lane traffic, the GEGLU gate sits beside its value, and a v_permlane32_swap per register pair gives 16-byte stores;
+//   * one wave per SIMD means nothing but the wave's own instructions can fill the gaps of its MFMA stream: the epilogue of block j - 1 is
+//     cut into 64 micro-steps that sit, pinned, behind the 64 MFMAs of block j ("Epilogues, SLOTTED" below); the MFMAs are inline asm
+//     naming the weight fragments as AGPR operands (hipcc copies AGPR operands to VGPRs first: 4 v_accvgpr_read per MFMA);
+//   * the phase (64 MFMAs + the slotted epilogue + the LDS-DMA pieces of block j + 2) is ONE branch-free basic block.
+// Measured (tools/native/gemm5_check, B = 8 x 1040 rows, back to back): to_qkv 54-57 -> 34 us (inference outputs) / 39 us (training
+// outputs), FeedForward-in 38 -> 31 / 49 -> 37 us; what each step of the way measured: docs/history.md "Round 6", DESIGN.md section 8.
 // Layouts (checked on the GPU by tools/native/gemm5_check.cpp against a double-precision host reference and the 128-wide kernels):
 //   MFMA 32x32x16: A operand lane l = row (l & 31), k = 8 (l >> 5) + 0..7;  B operand lane l = column (l & 31), same k;
 //                  D register j of lane l = row (j & 3) + 8 (j >> 2) + 4 (l >> 5), column l & 31.
@@ -30,9 +36,6 @@ namespace {
 #endif
 // (Measured and removed: the four waves taking turns at the texture path -- wave w issuing its pieces in slots 1 + w, 5 + w, ... --
 //  is 1-3 us SLOWER than all four issuing in the same slots.)
-#ifndef G5_VALU_PER_MFMA
-#define G5_VALU_PER_MFMA 5
-#endif
 constexpr int G5_KS = 32;               // k-steps of 16: K = 512
 constexpr int G5_K = G5_KS * 16;
 constexpr int G5_ROWB = G5_K * 2;       // bytes per activation row
