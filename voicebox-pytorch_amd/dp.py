@@ -200,7 +200,10 @@ def gather_adaln_factors(dada, temb, group=None):
     """Every rank's adaLN gradient factors -> (dada_all [L, W * B, J4], temb_all [W * B, Th], floats this rank put on the wire).
     dada [L, B, J4], temb [B, Th] (fp32, any device the backend serves).  The gradient of layer l's adaLN weight block summed over the
     ranks is dada_all[l]^T . temb_all -- what an all-reduce of the per-rank products dada_r[l]^T . temb_r would deliver, from
-    B * (L * J4 + Th) floats per rank instead of L * J4 * Th."""
+    B * (L * J4 + Th) floats per rank instead of L * J4 * Th.
+    REQUIRES the same local batch B on every rank (an equal-size all-gather; what a DistributedSampler / Accelerate's even batches give):
+    a caller that shards unevenly must use the materialised exchange (`adaln_exchange="materialize"`), whose all-reduce does not depend
+    on B -- with unequal B this collective errors or hangs (README "Known limits")."""
     L, B, J4 = dada.shape
     Th = temb.shape[1]
     mine = torch.cat((dada.reshape(-1), temb.reshape(-1)))
