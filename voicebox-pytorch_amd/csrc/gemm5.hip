@@ -35,7 +35,9 @@ namespace {
 #define VBX_G5_ABL 0  // diagnostic builds (tools/native/g5_abl.sh): 1 no epilogue, 2 no DMA, 8 no MFMAs -- wrong results by construction
 #endif
 // (Measured and removed: the four waves taking turns at the texture path -- wave w issuing its pieces in slots 1 + w, 5 + w, ... --
-//  is 1-3 us SLOWER than all four issuing in the same slots.)
+//  is 1-3 us SLOWER than all four issuing in the same slots.  Block 0's activation rows requested before the weight rounds (weight
+//  regions moved behind slot 0, 160 KiB of LDS): 39.6 / 34.4 / 38.6 / 33.1 us against 39.1 / 34.4 / 38.4 / 32.7 us in the same call --
+//  nothing: the weight rounds are L2-bandwidth-bound and the first block's 32 KiB queue behind them either way.)
 constexpr int G5_KS = 32;               // k-steps of 16: K = 512
 constexpr int G5_K = G5_KS * 16;
 constexpr int G5_ROWB = G5_K * 2;       // bytes per activation row
