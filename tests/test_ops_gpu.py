@@ -192,7 +192,9 @@ def rot_tables(Np, R):
                                                # K = 512: the weight-stationary kernel (csrc/gemm5.hip) under "auto" -- ragged last block,
                                                # batches changing inside a block, a panel with two idle waves (H = 2), Np < 32, no qk-norm
                                                (3, 100, 4, 512, True), (2, 77, 2, 512, True), (1, 24, 6, 512, True), (2, 33, 2, 512, False),
-                                               (4, 1040, 16, 512, True)])
+                                               (4, 1040, 16, 512, True),
+                                               # >= 64 row blocks: the XCD-aware work map; 7 x 1049 = 7343 rows: ragged last block, odd Np
+                                               (7, 1049, 16, 512, True)])
 def test_gemm_qkv_epilogue(L, Bsz, Np, H, D, qknorm, tile_path):
     """to_qkv + MultiheadRMSNorm + rotary fused (voicebox_pytorch.py:320-328)."""
     g = torch.Generator().manual_seed(Np)
@@ -260,7 +262,8 @@ def test_gemm5_inference_outputs_and_tiled_agreement(L, Bsz, Np, H):
         assert float((d / (b.float().abs() + 1e-3)).max()) < 2.5e-3 and float((d > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("M,Fd,Fp,train", [(300, 341, 384, True), (70, 60, 64, False), (2100, 1365, 1408, True), (1234, 1365, 1408, False)])
+@pytest.mark.parametrize("M,Fd,Fp,train", [(300, 341, 384, True), (70, 60, 64, False), (2100, 1365, 1408, True), (1234, 1365, 1408, False),
+                                           (7343, 1365, 1408, True)])
 def test_gemm5_geglu(L, M, Fd, Fp, train):
     """FeedForward[0] + GEGLU at K = 512 on the weight-stationary kernel (fp16 operands, the runtime's forward): fp16 G (+ bf16 copy
     and the interleaved bf16 pre-activation in training), ragged M, against fp64."""
