@@ -382,8 +382,8 @@ def main():
                                "flops_per_launch": top["gflop_per_launch"] * 1e9, "us_per_launch": top["us_per_launch"],
                                "measured": "HIP events around the stage's launch(es) on the launch stream, in situ (vbx_prof_*), "
                                            + ("averaged over the layers of 3 extra steps" if args.mode == "train" else
-                                              "one eager single-stream full-batch 2-interval sample (the timed run integrates two half "
-                                              "batches on two streams under hipGraph: its wall clock is `value`)"),
+                                              "one eager single-stream full-batch 2-interval sample (the timed run replays the captured "
+                                              "interval graph(s): its wall clock is `value`)"),
                                "isolated_us": {k: isolated_gemm_us(args, dev, k) for k in ("fwd ff_in", "dgrad to_qkv")},
                                "mfma_us_per_step": round(sum(r["us_per_step"] for r in mf), 1),
                                "kernels": rows}
@@ -404,8 +404,8 @@ def main():
             out["sample"] = {"ms": round(dt * 1e3, 2), "frames_per_s": round(args.batch * args.frames / dt, 1), "nfe": nfe,
                              "ms_per_nfe": round(dt * 1e3 / nfe, 3), "fwd_frac": round(fwd_flops * nfe / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
                              "what": f"ConditionalFlowMatcherWrapper.sample(cond=(8,{args.frames},{args.dim}), steps={steps_pts}) "
-                                     f"= {args.intervals} midpoint intervals under hipGraph (the two halves of the batch integrated concurrently as "
-                                     f"two branches of the graph, solver.py), median of three timed runs after the capture run",
+                                     f"= {args.intervals} midpoint intervals under hipGraph (one stream at dim 512, where the weight-stationary GEMMs own whole "
+                                     f"CUs; two concurrent half batches at other widths: solver.py), median of three timed runs after the capture run",
                              "runs_ms": [round(t * 1e3, 2) for t in dts]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -1503,6 +1503,13 @@ def test_sampler_concurrent_halves_equal_single_stream(golden, monkeypatch):
         assert torch.equal(s, ref)
         monkeypatch.setenv("VBX_SAMPLE_SPLIT", "1")
         assert MidpointSampler(vb, B, N, 5).split == 1
+        monkeypatch.delenv("VBX_SAMPLE_SPLIT")
+        # dim 512: the weight-stationary to_qkv / FeedForward-in kernel owns whole CUs -> one stream by default (two with VBX_GEMM5=0)
+        import voicebox_pytorch_amd as vbx512
+        vb512 = vbx512.VoiceBox(dim=512, num_cond_tokens=10, depth=2, dim_head=64, heads=8, condition_on_text=False).to(dev).eval()
+        assert MidpointSampler(vb512, 4, 64, 3).split == 1
+        monkeypatch.setenv("VBX_GEMM5", "0")
+        assert MidpointSampler(vb512, 4, 64, 3).split == 2
 
 
 def test_sampler_adaln_table_is_bit_identical_and_follows_weight_updates(golden, monkeypatch):

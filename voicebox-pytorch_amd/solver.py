@@ -11,7 +11,7 @@ state is kept (the reference stacks the whole trajectory, voicebox_pytorch.py:12
 
 Concurrent halves.  Every kernel of a forward has a ramp, a drain and -- the GEMMs -- a VALU-bound epilogue during which the
 matrix pipes idle (tools/native/gemm_trace.cpp); batch elements are independent in every kernel of the path.  So a batch of
-B >= 4 (even) is integrated as TWO half-batches on two streams, each with its own engine (activation arena; the packed weights
+B >= 4 (even) is integrated as TWO half-batches on two streams (the default except at dim 512, see MidpointSampler.__init__), each with its own engine (activation arena; the packed weights
 are shared) and its own captured interval graph: one kernel stream fills the other's holes.  The two integrations never meet
 before the end, and the second stream starts SPLIT_OFFSET_US late, so that different kernels of the two forwards overlap
 (attention beside GEMMs) rather than the same ones.  Measured on the benchmark shape, 16 intervals: one stream 85.7 ms, two
@@ -25,9 +25,10 @@ import os
 import torch
 
 from . import _lib
+from .engine import precise_enabled
 
 
-SPLIT_OFFSET_US = 60.0  # start delay of the second (third, ...) half-batch stream; 30 .. 250 us measured equal
+SPLIT_OFFSET_US = float(os.environ.get("VBX_SAMPLE_OFFSET_US", "60"))  # start delay of the second (third, ...) half-batch stream; 30 .. 250 us measured equal
 
 
 class _Part:
@@ -39,7 +40,14 @@ class MidpointSampler:
         assert steps >= 2, "need at least two time points"
         self.vb, self.B, self.N, self.steps = voicebox, B, N, steps
         if split is None:
-            env = os.environ.get("VBX_SAMPLE_SPLIT", "2")
+            # Default: two concurrent half batches -- EXCEPT where the weight-stationary kernel serves to_qkv / FeedForward-in (dim 512,
+            # csrc/gemm5.hip): it owns whole CUs, the half batches' launches cannot interleave with it, and ONE stream is then both
+            # faster and deterministic (round 6, ten runs each on one box: 286.0 ms every run against 284-294, mostly 292; with the tiled
+            # kernels 317.5 against 298-303 -- the split was a remedy for THEIR idle phases).  VBX_SAMPLE_SPLIT=1 / 2 overrides.
+            env = os.environ.get("VBX_SAMPLE_SPLIT")
+            if env is None:
+                g5 = voicebox._cfg["D"] == 512 and os.environ.get("VBX_GEMM5", "1") != "0" and not precise_enabled()
+                env = "1" if g5 else "2"
             if env not in ("1", "2"):
                 raise ValueError(f"VBX_SAMPLE_SPLIT must be 1 or 2 (concurrent half batches are the only measured, tested split), got {env!r}")
             split = int(env)
