@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libvbx_hip_diag.so $L/api.o $L/gemm.o $L/gemm3.o $L/gemm4.o $L/gemm5.o $L/attn_diag.o $L/norm.o $L/gateloop.o $L/ops.o $L/precise.o $L/runtime.o
   echo built $L/libvbx_hip_diag.so
 else
-  for rep in 1 2; do for n in 0 1 6 8 14 49 64 384 63 447; do
+  for rep in 1 2; do for n in ${ABLS:-0 1 6 8 14 16 49 64 384 63 447}; do
     echo -n "ABL=$n  "; VBX_LIB_PATH=$L/libvbx_hip_diag.so VBX_FWD_ABL3=$n NP=${NP:-1040} python tools/attn_bench.py 50 2>&1 | grep "fwd_eval"
   done; done
 fi

@@ -381,6 +381,11 @@ VBX_ABL_KERNEL(14) { extern __shared__ __attribute__((aligned(16))) char smem[];
 #include "attn_fwd_v3_body.inc"
 }
 #undef VBX_FWD_ABL
+#define VBX_FWD_ABL 16
+VBX_ABL_KERNEL(16) { extern __shared__ __attribute__((aligned(16))) char smem[];
+#include "attn_fwd_v3_body.inc"
+}
+#undef VBX_FWD_ABL
 #define VBX_FWD_ABL 49
 VBX_ABL_KERNEL(49) { extern __shared__ __attribute__((aligned(16))) char smem[];
 #include "attn_fwd_v3_body.inc"
@@ -1016,7 +1021,7 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
                        (const u16*)k16, (const u16*)v, mask, (u16*)out, (u16*)out_bf16, lse, H, Np, QK_UNIT, BH, xmap);     \
     break;
     switch (a3) {
-      VBX_ABL_LAUNCH(1) VBX_ABL_LAUNCH(6) VBX_ABL_LAUNCH(8) VBX_ABL_LAUNCH(14) VBX_ABL_LAUNCH(49) VBX_ABL_LAUNCH(64)
+      VBX_ABL_LAUNCH(1) VBX_ABL_LAUNCH(6) VBX_ABL_LAUNCH(8) VBX_ABL_LAUNCH(14) VBX_ABL_LAUNCH(16) VBX_ABL_LAUNCH(49) VBX_ABL_LAUNCH(64)
       VBX_ABL_LAUNCH(384) VBX_ABL_LAUNCH(63) VBX_ABL_LAUNCH(447)
       default: VBX_REQUIRE(false, "VBX_FWD_ABL3: no such ablation build");
     }
