@@ -282,6 +282,12 @@ static void model_shapes(bool do_time, bool do_race) {
     bs.push_back({"to_out (NT f16, N=512 K=1024, + resid)", d, 2.0 * M * D * I, {{Cf, (size_t)M * D * 4}}}); }
   { vbx_gemm_desc d = base(VBX_GEMM_NT, VBX_EPI_F32, D, Fp, A1408h, Fp, W2h, Fp); d.f16 = 1; d.C = Cf; d.ldc = D; d.resid = resid; d.bias = bias;
     bs.push_back({"ff_out (NT f16, N=512 K=1408, + bias + resid)", d, 2.0 * M * D * Fp, {{Cf, (size_t)M * D * 4}}}); }
+  if (do_time && !do_race) {  // what the fp32 residual read costs these launches: the same GEMMs without it
+    { vbx_gemm_desc d = base(VBX_GEMM_NT, VBX_EPI_F32, D, I, A1024h, I, Wouth, I); d.f16 = 1; d.C = Cf; d.ldc = D;
+      bs.push_back({"to_out WITHOUT the residual (timing only)", d, 2.0 * M * D * I, {{Cf, (size_t)M * D * 4}}}); }
+    { vbx_gemm_desc d = base(VBX_GEMM_NT, VBX_EPI_BF16, D, I, A1024h, I, Wouth, I); d.f16 = 0; d.A = A1024b; d.B = Woutb; d.C = Cb; d.ldc = D;
+      bs.push_back({"to_out shape, bf16 output, no residual (timing only)", d, 2.0 * M * D * I, {{Cb, (size_t)M * D * 2}}}); }
+  }
   { vbx_gemm_desc d = base(VBX_GEMM_NN, VBX_EPI_BF16, D, 3 * I, A3072b, 3 * I, Wqkvb, D); d.C = Cb; d.ldc = D;
     bs.push_back({"dgrad to_qkv (NN bf16, N=512 K=3072)", d, 2.0 * M * D * 3 * I, {{Cb, (size_t)M * D * 2}}}); }
   { vbx_gemm_desc d = base(VBX_GEMM_NN, VBX_EPI_BF16, D, 2 * Fp, A2816b, 2 * Fp, W1b, D); d.C = Cb; d.ldc = D;
