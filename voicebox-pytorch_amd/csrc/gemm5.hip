@@ -183,6 +183,7 @@ struct Epi5QKV {
   static constexpr int KINDS = 2;
   static constexpr bool HAS_ROT = true;
   static constexpr bool HAS_CINIT = false;  // accumulators start at 0
+  static float panel_cost(int pan, int npan) { return 3 * pan >= 2 * npan ? 0.85f : 1.0f; }  // v heads: no norm, no rotary (host side)
   struct State {
     float glo[16], ghi[16];
     int kind, head;
@@ -366,6 +367,7 @@ struct Epi5GEGLU {
   static constexpr int KINDS = 1;
   static constexpr bool HAS_ROT = false;
   static constexpr bool HAS_CINIT = true;  // the bias is the C operand of a chain's first MFMA: no add in the epilogue
+  static float panel_cost(int, int) { return 1.0f; }
   struct State {
     f32x16 cinit[2];  // bias of the x block / the gate block, in accumulator register order
     int kind;
@@ -472,6 +474,7 @@ struct Epi5BF16 {
   static constexpr int KINDS = 1;
   static constexpr bool HAS_ROT = false;
   static constexpr bool HAS_CINIT = false;
+  static float panel_cost(int, int) { return 1.0f; }
   struct State {
     int kind, col;
   };
@@ -524,8 +527,11 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
   //  plain map  : wpp workgroups per panel, workgroup idx of a panel takes row blocks idx, idx + wpp, ...  Every panel's workgroups
   //               sit on all 8 XCDs, so every L2 fetches the whole activation matrix (8 x the algorithmic read, PMC);
   //  XCD map    : (px > 0; launch5 picks it when it costs no extra block per workgroup) XCD x = blockIdx % 8 serves the panels of group
-  //               x % px and the row blocks of slice x / px only: an activation row is fetched by px L2s instead of 8.  Placement is a
-  //               locality hint (workgroups are dealt round-robin to the XCDs), never a correctness assumption.
+  //               x % px (panels g, g + px, g + 2 px, ...) and the row blocks of slice x / px only: an activation row is fetched by px
+  //               L2s instead of 8.  The group's xs workgroups are dealt to its panels base + 1 to the first panels, base to the last:
+  //               at to_qkv with px = 4 that is 11 / 11 / 10 for the q / k / v panel -- the v panel's blocks are the cheap ones (no
+  //               norm, no rotary), so its workgroups take 13 of them while the q / k ones take 12.  Placement is a locality hint
+  //               (workgroups are dealt round-robin to the XCDs), never a correctness assumption.
   int pan, rb0, rbs, nb;
   if (p.px > 0) {
     const int x = blockIdx.x & 7, s = blockIdx.x >> 3;        // XCD, slot on it (0 .. xs - 1)
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void gemm5_kernel(G5Params p, Epi epi) {
     const int li = s < cut ? s - pl * (base + 1) : (s - cut) - (pl - extra) * base;
     const int cnt = pl < extra ? base + 1 : base;
     const int nrg = 8 / p.px, r0 = (int)((long)rg * p.nrb / nrg), r1 = (int)((long)(rg + 1) * p.nrb / nrg);
-    pan = pg * ppg + pl; rb0 = r0 + li; rbs = cnt;
+    pan = pl * p.px + pg; rb0 = r0 + li; rbs = cnt;  // (groups interleave the panels: with 4 groups a group = one q, one k and one v panel)
     nb = rb0 < r1 ? (r1 - rb0 + cnt - 1) / cnt : 0;
   } else {
     pan = blockIdx.x / p.wpp;
@@ -767,14 +773,24 @@ int launch5(const vbx_gemm_desc* d, const Epi& epi, int nslab, bool train, hipSt
   p.px = 0; p.xs = 0;
   static const bool xcd_map = !(getenv("VBX_GEMM5_XCD") && atoi(getenv("VBX_GEMM5_XCD")) == 0);
   if (xcd_map && cus == ncu && ncu % 8 == 0 && p.nrb >= 8 * 8) {
-    // the XCD map with the fewest panel groups (= the fewest L2s fetching an activation row) that costs no extra block per workgroup
-    const int plain_max = cdiv(p.nrb, p.wpp), xs = ncu / 8;
-    for (int px = 1; px <= 4 && !p.px; px *= 2) {
-      if (p.npan % px) continue;
+    // the XCD map with the lowest cost = max over panels of (row blocks per workgroup x the panel's relative block time, Epi::panel_cost:
+    // a v head of to_qkv has a light epilogue), if that is no worse than the plain map; ties go to fewer panel groups (= fewer L2s
+    // fetching an activation row).  VBX_GEMM5_PX=<1|2|4> forces one (A/B).
+    static const int px_force = getenv("VBX_GEMM5_PX") ? atoi(getenv("VBX_GEMM5_PX")) : 0;
+    const int xs = ncu / 8;
+    float best = (float)cdiv(p.nrb, p.wpp);
+    for (int px = 1; px <= 4; px *= 2) {
+      if (p.npan % px || (px_force && px != px_force)) continue;
       const int ppg = p.npan / px, nrg = 8 / px;
       if (ppg > xs) continue;
-      const int cnt_min = xs / ppg, rows_max = cdiv(p.nrb, nrg);  // (slices differ by at most one row block)
-      if (cdiv(rows_max, cnt_min) <= plain_max) { p.px = px; p.xs = xs; grid = ncu; }
+      const int base = xs / ppg, extra = xs - base * ppg, rows_max = cdiv(p.nrb, nrg);  // (slices differ by at most one row block)
+      float cost = 0.f;
+      for (int pl = 0; pl < ppg; pl++)
+        for (int pg = 0; pg < px; pg++) {
+          const float c = (float)cdiv(rows_max, pl < extra ? base + 1 : base) * Epi::panel_cost(pl * px + pg, p.npan);
+          cost = c > cost ? c : cost;
+        }
+      if (cost < best - 1e-3f || (px_force && !p.px) || (!p.px && cost <= best + 1e-3f)) { best = cost < best ? cost : best; p.px = px; p.xs = xs; grid = ncu; }
     }
   }
   if (d->f16) return train ? launch5k<Epi, true, true>(p, epi, grid, st) : launch5k<Epi, true, false>(p, epi, grid, st);
