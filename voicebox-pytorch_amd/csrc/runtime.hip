@@ -283,23 +283,26 @@ void carve_acts(const vbx_model* m, Acts& a) {
     a.slab_floats = sf;
     a.slabs = c.take<float>(4 * sf);  // four regions: the layer's weight-gradient slabs stay live until its batched reduce
     // partial records of the layer's small gradients: L regions each (vbx_model.defer_reduce: every layer keeps its own until layer 0
-    // reduces them all; otherwise region 0 is reused).  Always carved: the arena layout must not depend on a per-call switch.
+    // reduces them all; otherwise region 0 is reused).  The arena layout must not depend on a per-call switch, so the count follows the
+    // MODEL only: GateLoop and u-net models never defer (vbx_model_backward_layer) and get one region (at dim 1024 /
+    // depth 24 the L regions are several hundred MB).
+    const size_t nreg = (m->gateloop || m->unet) ? 1 : (size_t)d.L;
     a.np_stride = (size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * 2 * d.D;  // >= the LayerNorm backward's 16-row records
     a.cp_stride = (size_t)d.B * vbx_rmsnorm_bwd_chunks(d.Np) * d.D;
-    a.npart = c.take<float>(a.np_stride * d.L);
-    a.npart2 = c.take<float>(a.np_stride * d.L);  // attention pre-norm partials (batched reduce)
-    a.cpart = c.take<float>(a.cp_stride * d.L);
+    a.npart = c.take<float>(a.np_stride * nreg);
+    a.npart2 = c.take<float>(a.np_stride * nreg);  // attention pre-norm partials (batched reduce)
+    a.cpart = c.take<float>(a.cp_stride * nreg);
     a.dada = c.take<float>((size_t)d.B * d.J);
     a.dtemb = c.take<float>((size_t)d.B * d.Th);
     size_t cs = (size_t)vbx_colsum_scratch_floats((int)d.M, 2 * d.Fp);
     if (cs < (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp) cs = (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp;
     a.cs_scratch = c.take<float>(cs);
     a.cs_stride = (size_t)vbx_geglu_bwd_colsum_slabs() * 2 * d.Fp;
-    a.cs_layers = c.take<float>(a.cs_stride * d.L);
+    a.cs_layers = c.take<float>(a.cs_stride * nreg);
     {
       const int r1 = vbx_qknorm_rope_bwd_gpart_rows(d.B), r2 = d.B * vbx_attn_bwd_fused_tiles(d.Np);
       a.gp_stride = (size_t)2 * (r1 > r2 ? r1 : r2) * d.H * 64;
-      a.gpart = c.take<float>(a.gp_stride * d.L);
+      a.gpart = c.take<float>(a.gp_stride * nreg);
     }
     a.tmp2d = c.take<float>(2 * d.D);
     a.ada_scratch = c.take<float>(std::max((size_t)vbx_adaln_proj_bwd_scratch_floats(d.B, d.Th, 4 * d.D),
