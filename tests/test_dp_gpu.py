@@ -540,6 +540,12 @@ def test_trainer_accumulation_and_reference_checkpoint_format(tmp_path, golden):
     for (k, a), (_, b) in zip(vb2.state_dict().items(), vb.state_dict().items()):
         assert torch.equal(a, b), k
     tr2.train_step()
+    # split_batches=True (trainer.py:83,93): batch_size is the global batch; one process -> the same loader
+    vb3, _ = make()
+    tr3 = vbx.VoiceBoxTrainer(vbx.ConditionalFlowMatcherWrapper(voicebox=vb3), batch_size=2, dataset=Latents(), num_train_steps=2,
+                              valid_frac=0.25, results_folder=str(tmp_path / "r3"), split_batches=True)
+    assert tr3.rank_batch_size == 2 and tr3.dl.batch_size == 2
+    tr3.train_step()
 
 
 def _nccl_world1_worker(port, out):

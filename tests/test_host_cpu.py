@@ -456,3 +456,15 @@ def test_gradient_norm_range_plan(depth, served):
         assert covered == n and rest == sorted(rest)  # a partition of the buffer
     assert Engine.complement_ranges(10, [(0, 10)]) == [] and Engine.complement_ranges(10, []) == [0, 10]
     assert Engine.complement_ranges(12, [(4, 8), (2, 6)]) == [0, 2, 8, 12]  # overlapping, unsorted blocks
+
+
+def test_trainer_split_batches_rank_batch():
+    """trainer.py:83,93 (Accelerator(split_batches=...)): False -> every rank loads batch_size samples; True -> batch_size is the global
+    batch and must be a round multiple of the number of processes."""
+    from voicebox_pytorch_amd.trainer import VoiceBoxTrainer
+
+    assert VoiceBoxTrainer.rank_batch(8, 4, False) == 8
+    assert VoiceBoxTrainer.rank_batch(8, 4, True) == 2
+    assert VoiceBoxTrainer.rank_batch(8, 1, True) == 8
+    with pytest.raises(ValueError, match="round multiple"):
+        VoiceBoxTrainer.rank_batch(6, 4, True)

@@ -72,11 +72,13 @@ class VoiceBoxTrainer(nn.Module):
         super().__init__()
         assert isinstance(cfm_wrapper, ConditionalFlowMatcherWrapper)
         self.wd = float(wd)  # > 0: AdamW with decay on the ndim >= 2 parameters (get_optimizer, optimizer.py:10-35)
-        if split_batches:
-            raise NotImplementedError("split_batches: every rank loads its own batch_size samples (Accelerate's default)")
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if self.distributed else 0
         self.world = dist.get_world_size() if self.distributed else 1
+        # split_batches (trainer.py:83,93 -> Accelerator(split_batches=...)): batch_size is the GLOBAL batch of a step, every rank
+        # loads batch_size / world of it (False, Accelerate's default: every rank loads its own batch_size samples)
+        self.split_batches = bool(split_batches)
+        self.rank_batch_size = self.rank_batch(batch_size, self.world, self.split_batches)
         self.cfm_wrapper = cfm_wrapper
         self.register_buffer('steps', torch.Tensor([0]))
         self.batch_size, self.grad_accum_every = batch_size, grad_accum_every
@@ -105,7 +107,7 @@ class VoiceBoxTrainer(nn.Module):
         sampler = None
         if self.world > 1:  # what accelerator.prepare(dl) does: each rank sees its own shard
             sampler = torch.utils.data.distributed.DistributedSampler(self.ds, num_replicas=self.world, rank=self.rank, shuffle=True)
-        self.dl = get_dataloader(self.ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, drop_last=drop_last)
+        self.dl = get_dataloader(self.ds, batch_size=self.rank_batch_size, shuffle=sampler is None, sampler=sampler, drop_last=drop_last)
         self.valid_dl = get_dataloader(self.valid_ds, batch_size=batch_size, shuffle=True, drop_last=drop_last)
         self.dl_iter, self.valid_dl_iter = cycle(self.dl, sampler), cycle(self.valid_dl)
         self.log_every, self.save_model_every, self.save_results_every = log_every, save_model_every, save_results_every
@@ -113,6 +115,16 @@ class VoiceBoxTrainer(nn.Module):
         if self.is_main and force_clear_prev_results is True and self.results_folder.exists():
             rmtree(str(self.results_folder))
         self.results_folder.mkdir(parents=True, exist_ok=True)
+
+    @staticmethod
+    def rank_batch(batch_size, world, split_batches):
+        """Samples one rank loads per step: batch_size (Accelerate's default) or batch_size / world (split_batches=True)."""
+        if not split_batches:
+            return batch_size
+        if batch_size % world:
+            raise ValueError(f"split_batches=True: batch_size ({batch_size}) must be a round multiple of the number of processes "
+                             f"({world})")  # Accelerate's own condition
+        return batch_size // world
 
     # ---- checkpoint format of the reference (trainer.py:191-207)
     def _optim_param_order(self):
