@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v2(GemmParams p, Epi epi) 
 // (24 KiB: 3 DMA instructions x 512 threads, rows >= 160 from the zero page) + B [128][64] or two K-strided [32][128] images
 // (16 KiB), 3 stages = 120 KiB, one barrier per 64 k (half as many as before).  Back to back (tools/native/gemm3_check time): to_out
 // 21.9 -> 18.9 us, FeedForward-out 26.3 -> 22.4, dgrad to_qkv 45.0 -> 36.4 (720 TFLOP/s), dgrad FeedForward-in 42.4 -> 34.0.
+#ifndef VBX_V9_ABL
+#define VBX_V9_ABL 0  // diagnostic builds (tools/native/v9_abl.sh): 1 no DMA behind the prologue, 2 no fragment reads, 4 no barrier, 8 no MFMAs, 64 no epilogue
+#endif
 constexpr int V9_A_BYTES = 192 * 128;
 constexpr int V9_B_BYTES = 16384;
 constexpr int V9_STAGE = V9_A_BYTES + V9_B_BYTES;  // 40 KiB
@@ -320,16 +323,27 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160k64(GemmParams p, Epi
     constexpr int STG = decltype(stg_c)::value;
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // k-tile t has landed, t+1 may stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // k-tile t visible to all; every wave is done reading k-tile t-1
+    if (!(VBX_V9_ABL & 4)) __builtin_amdgcn_s_barrier();  // k-tile t visible to all; every wave is done reading k-tile t-1
     Frags9 f;
-    read_frags(stg_c, f);
+    if ((VBX_V9_ABL & 2) && t > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) asm volatile("" : "=v"(f.af[kk][i]));
+#pragma unroll
+        for (int j = 0; j < 2; j++) asm volatile("" : "=v"(f.bfr[kk][j]), "=v"(f.blo[kk][j]), "=v"(f.bhi[kk][j]));
+      }
+    } else {
+      read_frags(stg_c, f);
+    }
     // the DMAs of k-tile t+2 are issued BEHIND the fragment reads: the LDS round trip runs under their issue time (dgrad to_qkv
     // 39.1 -> 36.4 us back to back against issuing them first).  Prefetching the fragments of k-tile t+1 before the MFMAs of
     // k-tile t (two register sets) measured 1 us SLOWER than this order.
-    if (t + 2 < nt) stage((STG + 2) % 3, t + 2);
+    if (t + 2 < nt && !(VBX_V9_ABL & 1)) stage((STG + 2) % 3, t + 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f);
+    if (!(VBX_V9_ABL & 8)) mfmas(f);
+    else asm volatile("" ::"v"(f.af[0][0]), "v"(f.af[1][4]), "v"(f.bfr[0][0]), "v"(f.bfr[1][1]));
   };
   for (int t = 0; t < nt; t += 3) {
     step(std::integral_constant<int, 0>{}, t);
@@ -338,6 +352,15 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160k64(GemmParams p, Epi
   }
   // ---- epilogue: as gemm_kernel_bm160x8
   float* Cs = reinterpret_cast<float*>(smem);
+  if (VBX_V9_ABL & 64) {
+    float tsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) tsum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (tsum == 123.456f) Cs[tid] = tsum;
+    return;
+  }
   const int half = tid >> 8, tq = tid & 255;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
