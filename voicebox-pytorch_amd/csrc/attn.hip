@@ -271,6 +271,26 @@ __device__ unsigned long long* g_attn_trace = nullptr;
 #define ATTN_TRACE_END(TAG)
 #endif
 
+// Diagnostic build only (-DVBX_ATTN_STEPTRACE, tools/attn_fwd_steptrace.sh): eight s_memtime stamps (100 MHz) per key tile and wave of the
+// forward kernel -- 0 step entry, 1 behind the barrier and the DMA issue, 2 first K fragments arrived, 3 / 4 first / second S chain issued, 5 softmax done,
+// 6 / 7 first / second P.V block issued; the time between consecutive stamps is summed over the key loop in scalar registers
+// and written once per wave: [workgroup][wave][8 segment sums (segment 0 = stamp 7 -> next stamp 0), first stamp, last stamp].
+#ifdef VBX_ATTN_STEPTRACE
+__device__ unsigned long long* g_attn_steptrace = nullptr;
+#define ATTN_ST_DECL() unsigned long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev_ = __builtin_amdgcn_s_memtime(), st_first_ = st_prev_
+#define ATTN_ST(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc_[i] += t_ - st_prev_; st_prev_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN_ST_FLUSH()                                                                                        \
+  if (g_attn_steptrace && (threadIdx.x & 63) == 0) {                                                           \
+    unsigned long long* r_ = g_attn_steptrace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) r_[i_] = st_acc_[i_];                                     \
+    r_[8] = st_first_; r_[9] = st_prev_;                                                                       \
+  }
+#else
+#define ATTN_ST_DECL()
+#define ATTN_ST(i)
+#define ATTN_ST_FLUSH()
+#endif
+
 // (Rounds 1-2's forward kernels -- the register-staged double buffer and the 3-slot / 3-per-CU LDS-DMA form "v2" -- were removed in
 //  round 6; their measurements are in docs/history.md.  The helpers of the LDS-DMA ring they introduced follow.)
 
@@ -1035,6 +1055,11 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
   VBX_LAUNCH_CHECK();
   return 0;
 }
+#ifdef VBX_ATTN_STEPTRACE
+extern "C" int vbx_debug_attn_steptrace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_steptrace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" float vbx_attn_q_prescale(float scale) { return scale * LOG2E; }
 extern "C" int vbx_attn_fwd(const void* q16, const void* k16, const void* v, const uint8_t* mask, void* out, void* out_bf16,
                             float* lse, int B, int H, int Np, float scale, void* stream) {
