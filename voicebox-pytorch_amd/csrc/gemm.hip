@@ -195,7 +195,7 @@ constexpr int V9_A_BYTES = 192 * 128;
 constexpr int V9_B_BYTES = 16384;
 constexpr int V9_STAGE = V9_A_BYTES + V9_B_BYTES;  // 40 KiB
 constexpr int GEMM_V9_LDS = 3 * V9_STAGE;          // 120 KiB
-static_assert(GEMM_V9_LDS >= 64 * CS_LD * 4, "C chunk must fit");
+static_assert(GEMM_V9_LDS >= 160 * CS_LD * 4, "the staged C tile must fit");
 
 template <int ROWS, int NTHR = 512>
 struct DmaPlan64 {
@@ -236,6 +236,7 @@ struct FragPlan64 {  // 16 rows [woff + 16 S, +16) x k half KK of a [rows][64] o
   }
 };
 
+template <class Epi> struct v9_onechunk : std::false_type {};  // specialised behind the functors
 template <int MB, class Epi, bool F16>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160k64(GemmParams p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -362,6 +363,22 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_bm160k64(GemmParams p, Epi
     return;
   }
   const int half = tid >> 8, tq = tid & 255;
+  // 16-bit outputs: the whole 160 x 128 fp32 tile is staged at once in the idle ring (84.5 of 120 KiB), two barriers instead of six: the N = dim
+  // dgrads 36.1 -> 35.6, 34.4 -> 33.6 us.  The fp32 + residual functor keeps the three 64-row chunks: staged at once its stores come in one
+  // burst at the end (to_out 18.9 -> 19.3, FeedForward-out 22.4 -> 23.0 us; profiles/r06_ab_v9_onechunk.txt).
+  if (v9_onechunk<Epi>::value) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          Cs[(wm * 80 + i * 16 + (lane >> 4) * 4 + rr) * CS_LD + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][rr];
+    __syncthreads();
+    epi(Cs + half * 80 * CS_LD, m0 + half * 80, n0, tq, 0, p.M, p.N, 80);
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     __syncthreads();
@@ -441,6 +458,11 @@ struct EpiBF16 {
     }
   }
 };
+
+#ifndef VBX_V9_ONECHUNK
+#define VBX_V9_ONECHUNK 1  // 0: three chunks for every functor (A/B builds)
+#endif
+template <> struct v9_onechunk<EpiBF16> : std::integral_constant<bool, VBX_V9_ONECHUNK != 0> {};
 
 struct EpiF32 {
   float* C; long ldc; const float* bias; const float* resid; u16* C2;
