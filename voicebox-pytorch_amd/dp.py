@@ -33,7 +33,10 @@ class GradBucketReducer:
         self.g, self.ranges, self.group, self.bucket_bytes = gflat, stage_ranges, group, bucket_bytes
         # skip_ranges: flat ranges that are NOT exchanged here -- the adaLN projection weight blocks whose gradient travels in factor
         # form (TrainStep(adaln_grads="factors"): all-gather of dada / temb, < 1 MB per rank, instead of 201 MB of products).  A stage
-        # that contains one is exchanged as the pieces around it.
+        # that contains one is exchanged as the pieces around it.  Known cost: a skipped block ends the pending run, so with
+        # factor exchange the buckets are per-layer pieces (~17 MB at dim 512, one or two collectives per layer) and `bucket_bytes` only
+        # caps them; merging across skipped blocks needs the adaLN blocks laid out apart from the layer weights (or a gather through the
+        # staging buffer) and was left out -- the pieces still overlap the backward of the earlier layers.
         self.skip_ranges = sorted((int(a), int(b)) for a, b in skip_ranges)
         self.wire_floats = 0  # floats handed to collectives by this reducer (bench.py reports the wire bytes per step)
         self.shard = bool(shard)
