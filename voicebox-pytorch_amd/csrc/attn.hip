@@ -215,10 +215,11 @@ VBX_DEV void store_rows_qknorm(char* wst, float* red /* [4][64] workgroup scratc
 struct AttnCoord { int tile, h, b; bool ok; };
 // blockIdx -> (128-row tile, head, batch).  The ragged tail tile of every (b, h) (Np % 128 rows: the 16 register-token rows at the
 // benchmark's Np = 1040) is a workgroup with one active wave that still walks the whole key loop: it lives about as long as a full workgroup
-// (it is bound by the tile round trip, not by throughput) while using a fraction of a CU.  Tails therefore go FIRST, where they
-// overlap with full workgroups; dispatched last they were a 30 us drain phase with the chip empty (tools/attn_timeline.py).
+// (it is bound by the tile round trip, not by throughput) while using a fraction of a CU.  Such tails go FIRST, where they
+// overlap with full workgroups; dispatched last they were a 30 us drain phase with the chip empty (tools/attn_timeline.py).  The short
+// <= 16-row tails of round 6 go LAST instead (attn_xmap_for).
 // xmap bit 0: consecutive ids rotate over the 8 XCDs, all tiles of a (b, h) on one XCD sharing its L2 copy of K / V;
-// bit 1 (A/B): tails last.
+// bit 1: tails last.
 VBX_DEV int attn_tail_ids(int Np, int BH, int xmap) { return (Np & 127) ? ((xmap & 1) ? ((BH + 7) >> 3) * 8 : BH) : 0; }
 VBX_DEV AttnCoord attn_coord_id(int id, int H, int Np, int BH, int xmap) {
   const int nfull = Np >> 7;
@@ -1010,6 +1011,17 @@ extern "C" int vbx_debug_attn_trace(void* buf) {  // diagnostic build only: buf 
 #endif
 
 static const float LOG2E = 1.4426950408889634f;
+// Workgroup order of the attention launches (attn_coord_id): bit 0 = XCD-local heads (always), bit 1 = the tail tiles LAST.  A tail of
+// <= 16 rows runs the short 16 x 16-shaped role (round 6): dispatched first it holds 128 of the 1024 slots while the last full tiles wait;
+// dispatched last it fills the drain of the launch -- same call, tails first -> last: train step 8.86 -> 8.73 ms, 64-interval sample
+// 283.6 -> 279.6 ms (profiles/r06_ab_attn_tails_last.txt).  Longer tails (one to four waves walking the whole key loop at the pace of a
+// full tile) still go first, where they overlap with full workgroups.  VBX_ATTN_XMAP=<bits> overrides.
+static int attn_xmap_for(int Np) {
+  static const int forced = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : -1;
+  if (forced >= 0) return forced;
+  const int tail = Np & 127;
+  return (tail != 0 && tail <= 16) ? 3 : 1;
+}
 // Round 5 contract (include/vbx.h): q16 arrives PRE-MULTIPLIED by scale * log2(e), so q . k is already the exponent of exp2 and the
 // kernels that still carry a `scale2` factor get 1; `scale` itself is only the multiplier of dq / dk.
 static const float QK_UNIT = 1.0f;
@@ -1021,7 +1033,7 @@ static int attn_fwd_impl(const void* q16, const void* k16, const void* v, const 
                          float* lse, int B, int H, int Np, float scale, const void* drop_bits_rm, float drop_p, void* stream) {
   VBX_REQUIRE(q16 && k16 && v && out && lse, "vbx_attn_fwd: null pointer");
   VBX_REQUIRE(B > 0 && H > 0 && Np > 0 && scale > 0.f, "vbx_attn_fwd: bad dims");
-  static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;  // 0: A/B against the plain tile order
+  const int xmap = attn_xmap_for(Np);  // VBX_ATTN_XMAP=0: A/B against the plain tile order
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
   if (drop_bits_rm) {  // training-time attention dropout (attend.py:131): the 4-per-CU body with the keep-bit selects
@@ -1119,7 +1131,7 @@ static int attn_bwd_impl(const void* q16, const void* k16, const void* qb, const
     hipLaunchKernelGGL(attn_delta_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, st, (const u16*)out, (const u16*)dout,
                        delta, H, Np, chunks);
   VBX_LAUNCH_CHECK();
-  static const int xmap = getenv("VBX_ATTN_XMAP") ? atoi(getenv("VBX_ATTN_XMAP")) : 1;
+  const int xmap = attn_xmap_for(Np);
   const int BH = B * H;
   dim3 grid(cdiv(Np, 128) * ((xmap & 1) ? cdiv(BH, 8) * 8 : BH));
   AttnBwdArgs a;
